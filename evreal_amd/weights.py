@@ -1,0 +1,148 @@
+"""State-dict schemas of the reference's recurrent networks + a deterministic synthetic
+weight generator.
+
+The reference ships FireNet / FireNet+ checkpoints only (pretrained/*/model.pth); the E2VID,
+E2VID+, SSL-E2VID and HyperE2VID blobs are absent (.MISSING_LARGE_BLOBS).  Parity and
+benchmarks for those layouts therefore run on weights drawn here.  Parameter names and
+shapes are exactly the ones torch's state_dict() of the reference classes yields
+(model/unet.py:40-82, model/submodules.py:8-313, model/legacy.py:32-111,
+model/model.py:147-190), so a real checkpoint drops in unchanged.
+"""
+import hashlib
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+E2VID_KWARGS = dict(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                    kernel_size=5, norm='BN', use_upsample_conv=False,
+                    recurrent_block_type='convlstm', skip_type='sum', final_activation='sigmoid')
+# eval.py:135-137 (SSL-E2VID) -- the layout E2VID+ is believed to share
+E2VID_PLUS_KWARGS = dict(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                         kernel_size=5, norm=None, use_upsample_conv=True,
+                         recurrent_block_type='convlstm', skip_type='sum', final_activation='none')
+
+
+def _conv(shapes, name, cout, cin, k, bias=True):
+    shapes[name + '.weight'] = (cout, cin, k, k)
+    if bias:
+        shapes[name + '.bias'] = (cout,)
+
+
+def _bn(shapes, name, c):
+    shapes[name + '.weight'] = (c,)
+    shapes[name + '.bias'] = (c,)
+    shapes[name + '.running_mean'] = (c,)
+    shapes[name + '.running_var'] = (c,)
+    shapes[name + '.num_batches_tracked'] = ()
+
+
+def _gru(shapes, name, c):
+    for g in ('reset_gate', 'update_gate', 'out_gate'):
+        _conv(shapes, f'{name}.{g}', c, 2 * c, 3)
+
+
+def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                          kernel_size=5, norm=None, use_upsample_conv=False,
+                          recurrent_block_type='convlstm', prefix='unetrecurrent.', **_):
+    """Ordered {name: shape} of E2VIDRecurrent.state_dict() (registration order of
+    UNetRecurrent.__init__, model/unet.py:99-106)."""
+    s = OrderedDict()
+    bn = norm == 'BN'
+    k = kernel_size
+    cin = [base_num_channels * 2 ** i for i in range(num_encoders)]
+    cout = [base_num_channels * 2 ** (i + 1) for i in range(num_encoders)]
+    _conv(s, prefix + 'head.conv2d', base_num_channels, num_bins, k)
+    for i in range(num_encoders):
+        p = f'{prefix}encoders.{i}'
+        _conv(s, p + '.conv.conv2d', cout[i], cin[i], k, bias=not bn)
+        if bn:
+            _bn(s, p + '.conv.norm_layer', cout[i])
+        if recurrent_block_type == 'convlstm':
+            _conv(s, p + '.recurrent_block.Gates', 4 * cout[i], 2 * cout[i], 3)
+        else:
+            _gru(s, p + '.recurrent_block', cout[i])
+    cm = cout[-1]
+    for i in range(num_residual_blocks):
+        p = f'{prefix}resblocks.{i}'
+        _conv(s, p + '.conv1', cm, cm, 3, bias=not bn)
+        if bn:
+            _bn(s, p + '.bn1', cm); _bn(s, p + '.bn2', cm)
+        _conv(s, p + '.conv2', cm, cm, 3, bias=not bn)
+    for i, (ci, co) in enumerate(zip(reversed(cout), reversed(cin))):
+        p = f'{prefix}decoders.{i}'
+        if use_upsample_conv:
+            _conv(s, p + '.conv2d', co, ci, k, bias=not bn)
+        else:
+            s[p + '.transposed_conv2d.weight'] = (ci, co, k, k)
+            if not bn:
+                s[p + '.transposed_conv2d.bias'] = (co,)
+        if bn:
+            _bn(s, p + '.norm_layer', co)
+    _conv(s, prefix + 'pred.conv2d', 1, base_num_channels, 1, bias=not bn)
+    if bn:
+        _bn(s, prefix + 'pred.norm_layer', 1)
+    return s
+
+
+def firenet_legacy_schema(num_bins=5, base_num_channels=16, kernel_size=3, prefix='net.', **_):
+    """FireNet_legacy.state_dict() (model/legacy.py:32-77)."""
+    s = OrderedDict(); c = base_num_channels
+    _conv(s, prefix + 'head.conv.conv2d', c, num_bins, kernel_size)
+    _gru(s, prefix + 'head.recurrent_block', c)
+    _conv(s, prefix + 'resblocks.0.conv.conv1', c, c, 3); _conv(s, prefix + 'resblocks.0.conv.conv2', c, c, 3)
+    _gru(s, prefix + 'resblocks.0.recurrent_block', c)
+    _conv(s, prefix + 'resblocks.1.conv1', c, c, 3); _conv(s, prefix + 'resblocks.1.conv2', c, c, 3)
+    _conv(s, prefix + 'pred.conv2d', 1, c, 1)
+    return s
+
+
+def firenet_schema(num_bins=5, base_num_channels=16, kernel_size=3, **_):
+    """FireNet.state_dict() (model/model.py:154-165), the 'FireNet+' method."""
+    s = OrderedDict(); c = base_num_channels
+    _conv(s, 'head.conv2d', c, num_bins, kernel_size)
+    _gru(s, 'G1', c)
+    _conv(s, 'R1.conv1', c, c, 3); _conv(s, 'R1.conv2', c, c, 3)
+    _gru(s, 'G2', c)
+    _conv(s, 'R2.conv1', c, c, 3); _conv(s, 'R2.conv2', c, c, 3)
+    _conv(s, 'pred.conv2d', 1, c, 1)
+    return s
+
+
+def synth_state_dict(schema, seed=0, gain=1.0):
+    """Deterministic fp32 numpy weights for a schema.  Each tensor is drawn from its own
+    PCG64 stream keyed by (seed, crc32(name)) so adding/removing tensors never shifts the
+    others.  Conv weights ~ U(-a, a), a = gain*sqrt(3/fan_in) (unit-variance preserving);
+    biases small; BN gamma in [0.8,1.2], beta/mean in [-0.1,0.1], var in [0.5,1.5]."""
+    out = OrderedDict()
+    for name, shape in schema.items():
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
+        leaf = name.rsplit('.', 1)[-1]
+        if leaf == 'num_batches_tracked':
+            out[name] = np.array(0, dtype=np.int64)
+        elif leaf == 'running_var':
+            out[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif leaf == 'running_mean':
+            out[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif len(shape) == 4:
+            # ConvTranspose2d weight is [Cin, Cout, k, k]; fan_in there is Cin*k*k/stride^2
+            fan_in = shape[1] * shape[2] * shape[3]
+            if 'transposed_conv2d' in name:
+                fan_in = shape[0] * shape[2] * shape[3] / 4.0
+            a = gain * np.sqrt(3.0 / fan_in)
+            out[name] = rng.uniform(-a, a, shape).astype(np.float32)
+        elif leaf == 'weight':            # BN gamma
+            out[name] = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+        else:                             # conv bias / BN beta
+            out[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+    return out
+
+
+def state_dict_digest(sd):
+    """sha256 over names, shapes and raw bytes (order-independent of dict order)."""
+    h = hashlib.sha256()
+    for name in sorted(sd):
+        a = np.ascontiguousarray(np.asarray(sd[name]))
+        h.update(name.encode()); h.update(str(a.shape).encode()); h.update(str(a.dtype).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()

@@ -1,0 +1,181 @@
+"""Oracle: recurrent-network forward passes on torch-CPU fp32.  TEST INFRASTRUCTURE ONLY.
+
+Functional restatement (state_dict in, tensors out) of the reference's nn.Modules, NCHW:
+  UNetRecurrentOracle   model/unet.py:9-143 (BaseUNet/UNetRecurrent) +
+                        model/model.py:108-144 (E2VIDRecurrent: prefix 'unetrecurrent.')
+  conv_layer            model/submodules.py:8-35   (conv -> BN(eval) -> activation)
+  conv_lstm             model/submodules.py:187-245 (gate order in, remember, out, cell)
+  conv_gru              model/submodules.py:248-287
+  residual_block        model/submodules.py:152-184
+  transposed_conv_layer model/submodules.py:38-66  (stride 2, output_padding 1)
+  upsample_conv_layer   model/submodules.py:69-97  (bilinear x2, align_corners=False)
+  FireNetLegacyOracle   model/legacy.py:32-111,155-187 (prefix 'net.')
+  FireNetOracle         model/model.py:147-190      (FireNet+)
+BatchNorm is applied un-folded in eval mode (running stats), exactly as the reference does
+(eval.py:112), so this oracle also checks the product's BN folding.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(sd, prefix, x):
+    return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'],
+                        sd[prefix + '.weight'], sd[prefix + '.bias'], False, 0.1, 1e-5)
+
+
+def _act(x, activation):
+    if activation is None:
+        return x
+    return getattr(torch, activation)(x)
+
+
+def conv_layer(sd, p, x, stride=1, padding=0, activation='relu', norm=None):
+    x = F.conv2d(x, sd[p + '.conv2d.weight'], sd.get(p + '.conv2d.bias'), stride, padding)
+    if norm == 'BN':
+        x = _bn(sd, p + '.norm_layer', x)
+    return _act(x, activation)
+
+
+def transposed_conv_layer(sd, p, x, padding, activation='relu', norm=None):
+    x = F.conv_transpose2d(x, sd[p + '.transposed_conv2d.weight'], sd.get(p + '.transposed_conv2d.bias'),
+                           stride=2, padding=padding, output_padding=1)
+    if norm == 'BN':
+        x = _bn(sd, p + '.norm_layer', x)
+    return _act(x, activation)
+
+
+def upsample_conv_layer(sd, p, x, padding, activation='relu', norm=None):
+    x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    x = F.conv2d(x, sd[p + '.conv2d.weight'], sd.get(p + '.conv2d.bias'), 1, padding)
+    if norm == 'BN':
+        x = _bn(sd, p + '.norm_layer', x)
+    return _act(x, activation)
+
+
+def conv_lstm(sd, p, x, state):
+    C = x.shape[1]
+    if state is None:
+        z = torch.zeros_like(x)
+        state = (z, z.clone())
+    h, c = state
+    g = F.conv2d(torch.cat((x, h), 1), sd[p + '.Gates.weight'], sd[p + '.Gates.bias'], padding=1)
+    i, r, o, cell = g.chunk(4, 1)
+    i, r, o, cell = torch.sigmoid(i), torch.sigmoid(r), torch.sigmoid(o), torch.tanh(cell)
+    c2 = (r * c) + (i * cell)
+    h2 = o * torch.tanh(c2)
+    return h2, c2
+
+
+def conv_gru(sd, p, x, h):
+    if h is None:
+        h = torch.zeros_like(x)
+    s = torch.cat([x, h], 1)
+    update = torch.sigmoid(F.conv2d(s, sd[p + '.update_gate.weight'], sd[p + '.update_gate.bias'], padding=1))
+    reset = torch.sigmoid(F.conv2d(s, sd[p + '.reset_gate.weight'], sd[p + '.reset_gate.bias'], padding=1))
+    out = torch.tanh(F.conv2d(torch.cat([x, h * reset], 1), sd[p + '.out_gate.weight'],
+                              sd[p + '.out_gate.bias'], padding=1))
+    return h * (1 - update) + out * update
+
+
+def residual_block(sd, p, x, norm=None):
+    out = F.conv2d(x, sd[p + '.conv1.weight'], sd.get(p + '.conv1.bias'), padding=1)
+    if norm == 'BN':
+        out = _bn(sd, p + '.bn1', out)
+    out = torch.relu(out)
+    out = F.conv2d(out, sd[p + '.conv2.weight'], sd.get(p + '.conv2.bias'), padding=1)
+    if norm == 'BN':
+        out = _bn(sd, p + '.bn2', out)
+    return torch.relu(out + x)
+
+
+class UNetRecurrentOracle:
+    """E2VIDRecurrent (model/model.py:108-144) over UNetRecurrent (model/unet.py:85-143)."""
+
+    def __init__(self, sd, num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                 kernel_size=5, norm=None, use_upsample_conv=False, recurrent_block_type='convlstm',
+                 final_activation='none', prefix='unetrecurrent.'):
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        self.pre, self.k, self.norm = prefix, kernel_size, norm
+        self.num_encoders, self.num_res = num_encoders, num_residual_blocks
+        self.up, self.rec = use_upsample_conv, recurrent_block_type
+        self.final = getattr(torch, final_activation, None)
+        self.reset_states()
+
+    def reset_states(self):
+        self.states = [None] * self.num_encoders
+
+    def __call__(self, x, taps=None):
+        sd, pre, k = self.sd, self.pre, self.k
+        x = conv_layer(sd, pre + 'head', x, 1, k // 2, 'relu', None)   # head has norm=None (unet.py:77-82)
+        head = x
+        if taps is not None: taps['head'] = x
+        blocks = []
+        for i in range(self.num_encoders):
+            p = f'{pre}encoders.{i}'
+            x = conv_layer(sd, p + '.conv', x, 2, k // 2, 'relu', self.norm)
+            if taps is not None: taps[f'enc{i}.conv'] = x
+            if self.rec == 'convlstm':
+                st = conv_lstm(sd, p + '.recurrent_block', x, self.states[i]); x = st[0]
+            else:
+                st = conv_gru(sd, p + '.recurrent_block', x, self.states[i]); x = st
+            self.states[i] = st
+            blocks.append(x)
+        for i in range(self.num_res):
+            x = residual_block(sd, f'{pre}resblocks.{i}', x, self.norm)
+            if taps is not None: taps[f'res{i}'] = x
+        for i in range(self.num_encoders):
+            x = x + blocks[self.num_encoders - i - 1]
+            p = f'{pre}decoders.{i}'
+            if self.up:
+                x = upsample_conv_layer(sd, p, x, k // 2, 'relu', self.norm)
+            else:
+                x = transposed_conv_layer(sd, p, x, k // 2, 'relu', self.norm)
+            if taps is not None: taps[f'dec{i}'] = x
+        img = conv_layer(sd, pre + 'pred', x + head, 1, 0, None, self.norm)
+        if self.final is not None:
+            img = self.final(img)
+        return img
+
+
+class FireNetLegacyOracle:
+    """FireNet_legacy / UNetFire (model/legacy.py:32-111,155-187): head conv3+ConvGRU,
+    resblock0 + ConvGRU, resblock1 plain, pred 1x1, no final activation, norm 'none'."""
+
+    def __init__(self, sd, prefix='net.'):
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        self.pre = prefix
+        self.num_encoders = 4            # legacy.py:127-130 default -> cropper pads to /16
+        self.reset_states()
+
+    def reset_states(self):
+        self.states = [None, None]
+
+    def __call__(self, x):
+        sd, pre = self.sd, self.pre
+        x = conv_layer(sd, pre + 'head.conv', x, 1, 1, 'relu', None)
+        x = conv_gru(sd, pre + 'head.recurrent_block', x, self.states[0]); self.states[0] = x
+        x = residual_block(sd, pre + 'resblocks.0.conv', x)
+        x = conv_gru(sd, pre + 'resblocks.0.recurrent_block', x, self.states[1]); self.states[1] = x
+        x = residual_block(sd, pre + 'resblocks.1', x)
+        return conv_layer(sd, pre + 'pred', x, 1, 0, None, None)
+
+
+class FireNetOracle:
+    """FireNet (model/model.py:147-190), the 'FireNet+' method; num_encoders forced 0 (eval.py:154-155)."""
+
+    def __init__(self, sd):
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        self.num_encoders = 0
+        self.reset_states()
+
+    def reset_states(self):
+        self.states = [None, None]
+
+    def __call__(self, x):
+        sd = self.sd
+        x = conv_layer(sd, 'head', x, 1, 1, 'relu', None)
+        x = conv_gru(sd, 'G1', x, self.states[0]); self.states[0] = x
+        x = residual_block(sd, 'R1', x)
+        x = conv_gru(sd, 'G2', x, self.states[1]); self.states[1] = x
+        x = residual_block(sd, 'R2', x)
+        return conv_layer(sd, 'pred', x, 1, 0, None, None)

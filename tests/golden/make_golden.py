@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run only in the build container (needs /root/reference; nothing here travels to the GPU box
+except the .npz/.json outputs):   python tests/golden/make_golden.py
+
+The reference (ercanburak/EVREAL) is imported from /root/reference with in-memory stubs for
+the third-party packages that are absent offline and that the hot path does not need
+(torchvision, cv2, yachalk, ffmpeg, skimage, pyiqa).  Every vector is an (input, output) pair
+of a reference function; inputs are either stored or regenerated from seeds by
+evreal_amd.synth / evreal_amd.weights (digests are stored so drift is detected).
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+for name in ['torchvision', 'torchvision.transforms', 'cv2', 'yachalk', 'ffmpeg', 'skimage',
+             'skimage.metrics', 'pyiqa']:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+sys.modules['yachalk'].chalk = types.SimpleNamespace(
+    cyan=types.SimpleNamespace(bold=str), red=types.SimpleNamespace(bold=str),
+    green=types.SimpleNamespace(bold=str), yellow=types.SimpleNamespace(bold=str), underline=str)
+sys.modules['skimage.metrics'].mean_squared_error = None
+sys.modules['skimage.metrics'].structural_similarity = None
+sys.modules['pyiqa'].list_models = lambda: []
+
+os.chdir(REF)
+from utils.event_utils import events_to_voxel_torch          # noqa: E402
+from utils.util import CropParameters                        # noqa: E402
+from dataset import MemMapDataset                            # noqa: E402
+import model as ref_model                                    # noqa: E402
+import eval as ref_eval                                      # noqa: E402
+
+from evreal_amd import synth, weights                        # noqa: E402
+
+torch.manual_seed(0)
+_orig_load = torch.load
+torch.load = lambda f, map_location=None, **kw: _orig_load(f, map_location=map_location, weights_only=False)
+torch.set_num_threads(1)   # deterministic reduction order for the fp32 goldens
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save_npz(name, **arrs):
+    np.savez_compressed(os.path.join(HERE, name), **arrs)
+    print('wrote', name, {k: getattr(v, 'shape', None) for k, v in arrs.items()})
+
+
+def save_json(name, obj):
+    with open(os.path.join(HERE, name), 'w') as f:
+        json.dump(obj, f, indent=1)
+    print('wrote', name)
+
+
+def ref_voxel(xs, ys, ts, ps, B, H, W):
+    return events_to_voxel_torch(torch.from_numpy(xs), torch.from_numpy(ys), torch.from_numpy(ts),
+                                 torch.from_numpy(ps), B, sensor_size=(H, W)).numpy()
+
+
+# ---------------------------------------------------------------- 1. voxelizer
+def gen_events(seed, n, W, H, burst=False, same_ts=False, weights_p=False):
+    rng = np.random.default_rng(seed)
+    t64 = np.sort(rng.uniform(0, n * 1e-6 + 1e-3, n))
+    if same_ts:
+        t64[:] = t64[0]
+    x = rng.integers(0, W, n); y = rng.integers(0, H, n)
+    if burst and n > 8:           # duplicate-pixel bursts: many events on few pixels
+        hot = rng.integers(0, n, n // 2)
+        x[hot] = x[hot[0]] if n < 64 else rng.integers(0, 3, len(hot))
+        y[hot] = y[hot[0]] if n < 64 else rng.integers(0, 2, len(hot))
+    p = rng.integers(0, 2, n) * 2.0 - 1.0
+    if weights_p:
+        p = rng.normal(size=n)
+    xs = x.astype(np.float32); ys = y.astype(np.float32)
+    ts = (t64 - t64[0]).astype(np.float32); ps = p.astype(np.float32)
+    return xs, ys, ts, ps
+
+
+def make_voxel():
+    small, meta = {}, []
+    cases = [  # name, seed, n, W, H, B, flags
+        ('n1', 1, 1, 48, 32, 5, {}),
+        ('n2', 2, 2, 48, 32, 5, {}),
+        ('n3_same_ts', 3, 3, 48, 32, 5, dict(same_ts=True)),
+        ('n5_same_ts', 4, 5, 48, 32, 5, dict(same_ts=True)),
+        ('n7_same_ts', 5, 7, 48, 32, 5, dict(same_ts=True)),
+        ('n100', 6, 100, 48, 32, 5, {}),
+        ('n5000_burst', 7, 5000, 48, 32, 5, dict(burst=True)),
+        ('n3000_b3', 8, 3000, 48, 32, 3, {}),
+        ('n3000_b10_weights', 9, 3000, 48, 32, 10, dict(weights_p=True)),
+        ('n2000_b1', 10, 2000, 48, 32, 1, {}),
+    ]
+    for name, seed, n, W, H, B, fl in cases:
+        xs, ys, ts, ps = gen_events(seed, n, W, H, **fl)
+        v = ref_voxel(xs, ys, ts, ps, B, H, W)
+        for k, a in zip('xytp', (xs, ys, ts, ps)):
+            small[f'{name}.{k}'] = a
+        small[f'{name}.voxel'] = v
+        meta.append(dict(name=name, n=n, W=W, H=H, B=B))
+    small_meta = json.dumps(meta)
+    save_npz('voxel_small.npz', meta=np.frombuffer(small_meta.encode(), dtype=np.uint8), **small)
+
+    large = []
+    for name, seed, n, W, H, B, fl in [
+            ('ecd_15k', 20, 15000, 240, 180, 5, {}),
+            ('davis346_15k', 21, 15000, 346, 260, 5, {}),
+            ('davis346_50k_burst', 22, 50000, 346, 260, 5, dict(burst=True)),
+            ('vga_15k', 23, 15000, 640, 480, 5, {}),
+            ('vga_200k', 24, 200000, 640, 480, 5, {}),
+            ('bsergb_50k', 25, 50000, 970, 625, 5, {})]:
+        xs, ys, ts, ps = gen_events(seed, n, W, H, **fl)
+        v = ref_voxel(xs, ys, ts, ps, B, H, W)
+        large.append(dict(name=name, seed=seed, n=n, W=W, H=H, B=B, flags=fl,
+                          in_sha=sha(np.stack([xs, ys, ts, ps])), out_sha=sha(v),
+                          nnz=int((v != 0).sum()), sum=float(v.astype(np.float64).sum()),
+                          abs_sum=float(np.abs(v).astype(np.float64).sum())))
+    save_json('voxel_large.json', large)
+
+
+# ---------------------------------------------------------------- 2. dataset windows
+def make_dataset():
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        seq = synth.write_sequence(d, seed=31, n_events=40000, rate_hz=2.0e5, width=48, height=32, fps=50.0)
+        out['seq'] = dict(seed=31, n_events=40000, rate_hz=2.0e5, width=48, height=32, fps=50.0,
+                          t_sha=sha(seq['t']), xy_sha=sha(seq['xy']), p_sha=sha(seq['p']),
+                          images_sha=sha(seq['images']))
+        methods = {
+            'between_frames': {'method': 'between_frames'},
+            'k_events': {'method': 'k_events', 'k': 3000, 'sliding_window_w': 0},
+            'k_events_slide': {'method': 'k_events', 'k': 3000, 'sliding_window_w': 1000},
+            't_seconds': {'method': 't_seconds', 't': 0.013, 'sliding_window_t': 0.0},
+            't_seconds_slide': {'method': 't_seconds', 't': 0.02, 'sliding_window_t': 0.005},
+        }
+        for name, vm in methods.items():
+            ds = MemMapDataset(d, num_bins=5, voxel_method=dict(vm))
+            items = []
+            for i in range(len(ds)):
+                try:
+                    if vm['method'] == 'between_frames':
+                        prev = ds.frames_to_use[i - 1] if i > 0 else 0
+                        idx0 = ds.get_event_indices(prev)[1]; idx1 = ds.get_event_indices(ds.frames_to_use[i])[1]
+                    else:
+                        idx0, idx1 = ds.get_event_indices(i)
+                    it = ds[i]
+                except ValueError:
+                    # reference quirk: with sliding_window_w > 0 the table runs past num_events and
+                    # get_event_indices raises (dataset.py:196-197)
+                    items.append(dict(raises='ValueError'))
+                    continue
+                items.append(dict(idx0=int(idx0), idx1=int(idx1), event_count=int(it['event_count']),
+                                  dt=float(it['dt']), voxel_timestamp=float(it['voxel_timestamp']),
+                                  frame_timestamp=float(it['frame_timestamp']),
+                                  voxel_sha=sha(it['events'].numpy()), frame_sha=sha(it['frame'].numpy())))
+            mn, mx = ds.get_min_max_t()
+            out[name] = dict(voxel_method=vm, length=len(ds), min_t=float(mn), max_t=float(mx),
+                             sensor_resolution=list(ds.sensor_resolution), items=items)
+    save_json('dataset_windows.json', out)
+
+
+# ---------------------------------------------------------------- 3/4/7/8. small helpers
+def make_helpers():
+    rng = np.random.default_rng(41)
+    cases = {}
+    xs, ys, ts, ps = gen_events(42, 15000, 346, 260)
+    v = ref_voxel(xs, ys, ts, ps, 5, 260, 346)[None]
+    cases['vox15k'] = v
+    cases['zeros'] = np.zeros((1, 5, 8, 12), np.float32)
+    one = np.zeros((1, 5, 8, 12), np.float32); one[0, 2, 3, 4] = 0.75
+    cases['single'] = one
+    cases['dense'] = rng.normal(size=(1, 5, 16, 24)).astype(np.float32)
+    arrs = {}
+    for k, a in cases.items():
+        arrs[k + '.in'] = a
+        arrs[k + '.out'] = ref_eval.normalize_event_tensor(torch.from_numpy(a.copy())).numpy()
+    save_npz('normalize.npz', **{k: v for k, v in arrs.items() if not k.startswith('vox15k.in')},
+             **{'vox15k.seed': np.array(42)})
+
+    table = []
+    for (W, H, enc) in [(346, 260, 3), (240, 180, 4), (240, 180, 0), (240, 180, 3), (640, 480, 3),
+                        (970, 625, 3), (485, 312, 3), (48, 32, 3), (100, 50, 2)]:
+        c = CropParameters(W, H, enc)
+        x = torch.zeros(1, 1, H, W)
+        table.append(dict(W=W, H=H, num_encoders=enc, width_crop=c.width_crop_size, height_crop=c.height_crop_size,
+                          pad=[c.padding_left, c.padding_right, c.padding_top, c.padding_bottom],
+                          crop=[c.ix0, c.ix1, c.iy0, c.iy1], padded_shape=list(c.pad(x).shape[-2:])))
+    save_json('crop_table.json', table)
+
+    imgs = {}
+    for k, a in [('unit', rng.random((100, 130)).astype(np.float32)),
+                 ('wide', (rng.normal(size=(60, 80)) * 3).astype(np.float32)),
+                 ('small', rng.random((7, 9)).astype(np.float32)),
+                 ('ties', np.round(rng.random((64, 64)) * 8).astype(np.float32) / 8)]:
+        imgs[k + '.in'] = a
+        for norm in ['robust', 'standard', 'exprobust']:
+            o = ref_eval.post_process_normalization(a.copy(), norm)
+            imgs[f'{k}.{norm}'] = o
+            assert o.dtype == np.float32, o.dtype
+    save_npz('robust_norm.npz', **imgs)
+
+    mt_cases = []
+    for upd in [[('mse', 0.05, 10), ('mse', 0.10, 30)],
+                [('mse', 0.05, 0), ('mse', 0.2, 3), ('ssim', -1, 4), ('ssim', 0.5, 4)],
+                [('lpips', 0.31, 7)]]:
+        mt = ref_eval.MetricTracker()
+        for k, v, c in upd:
+            mt.update(k, v, c)
+        mt_cases.append(dict(updates=upd, data=mt.data_dict))
+    save_json('metric_tracker.json', mt_cases)
+
+
+# ---------------------------------------------------------------- 5. FireNet / FireNet+ (real weights)
+def voxel_sequence(seed, n_frames, B, H, W, density=0.07):
+    """Voxel-like sparse model inputs straight from a seed (evreal_amd.synth.sparse_voxels)."""
+    return synth.sparse_voxels(seed, n_frames, B, H, W, density)
+
+
+def make_firenet():
+    for nm, tag in [('FireNet', 'firenet'), ('FireNet+', 'firenetplus')]:
+        path = f'{REF}/pretrained/{nm}/model.pth'
+        m = ref_eval.get_model_from_checkpoint_path(nm, path)
+        sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+        save_npz(f'{tag}_weights.npz', **sd)
+        H, W = 90, 120
+        crop = CropParameters(W, H, m.num_encoders)
+        vox = voxel_sequence(51, 5, 5, H, W)
+        m.reset_states()
+        outs = []
+        with torch.no_grad():
+            for f in range(len(vox)):
+                x = crop.pad(torch.from_numpy(vox[f:f + 1]))
+                outs.append(crop.crop(m(x)['image']).numpy())
+        states = m.states if nm == 'FireNet' else m._states
+        save_npz(f'{tag}_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([51, 5, 5, H, W]),
+                 images=np.concatenate(outs),
+                 state0_sub=states[0].numpy()[:, :, ::3, ::3].copy(), state1_sub=states[1].numpy()[:, :, ::3, ::3].copy(),
+                 state0_sha=np.array(sha(states[0].numpy())),
+                 num_encoders=np.array(m.num_encoders), weights_sha=np.array(weights.state_dict_digest(sd)))
+
+
+# ---------------------------------------------------------------- 6. E2VID layouts (synthetic weights)
+def make_e2vid():
+    for tag, kw in [('e2vid_bn', weights.E2VID_KWARGS), ('e2vid_plus', weights.E2VID_PLUS_KWARGS),
+                    ('e2vid_gru_tiny', dict(num_bins=5, base_num_channels=32, num_encoders=2, num_residual_blocks=1,
+                                            kernel_size=5, norm=None, use_upsample_conv=False,
+                                            recurrent_block_type='convgru', skip_type='sum',
+                                            final_activation='sigmoid'))]:
+        schema = weights.unet_recurrent_schema(**kw)
+        sd = weights.synth_state_dict(schema, seed=7)
+        m = ref_model.E2VIDRecurrent(dict(kw))
+        ref_sd = m.state_dict()
+        assert list(ref_sd.keys()) == list(sd.keys()), (set(ref_sd) ^ set(sd))
+        for k in ref_sd:
+            assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        m.eval()
+        H, W = 64, 96
+        vox = voxel_sequence(61, 4, 5, H, W)
+        outs, taps = [], {}
+        hooks = []
+        if tag != 'e2vid_gru_tiny':
+            u = m.unetrecurrent
+            def tap(name):
+                def hook(mod, inp, out):
+                    taps.setdefault(name, (out[0] if isinstance(out, tuple) else out).detach().numpy().copy())
+                    return None
+                return hook
+            hooks.append(u.head.register_forward_hook(tap('head')))
+            hooks.append(u.encoders[0].conv.register_forward_hook(tap('enc0.conv')))
+            hooks.append(u.encoders[0].register_forward_hook(tap('enc0.h')))
+            hooks.append(u.encoders[2].register_forward_hook(tap('enc2.h')))
+            hooks.append(u.resblocks[1].register_forward_hook(tap('res1')))
+            hooks.append(u.decoders[0].register_forward_hook(tap('dec0')))
+            hooks.append(u.decoders[2].register_forward_hook(tap('dec2')))
+        with torch.no_grad():
+            for f in range(len(vox)):
+                outs.append(m(torch.from_numpy(vox[f:f + 1]))['image'].numpy())
+                for h in hooks:
+                    h.remove()
+                hooks = []
+        st = m.unetrecurrent.states
+        extra = {}
+        for i, s in enumerate(st):
+            if isinstance(s, tuple):
+                extra[f'h{i}_sub'] = s[0].numpy()[:, ::4].copy(); extra[f'c{i}_sub'] = s[1].numpy()[:, ::4].copy()
+            else:
+                extra[f'h{i}_sub'] = s.numpy()[:, ::4].copy()
+        save_npz(f'{tag}_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([61, 4, 5, H, W]),
+                 images=np.concatenate(outs),
+                 kwargs=np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8), seed=np.array(7),
+                 weights_sha=np.array(weights.state_dict_digest(sd)),
+                 **{'tap.' + k: (v[:, ::4].copy() if v.shape[1] >= 32 else v) for k, v in taps.items()}, **extra)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid']
+    for w in which:
+        {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
+         'firenet': make_firenet, 'e2vid': make_e2vid}[w]()

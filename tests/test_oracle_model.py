@@ -1,0 +1,91 @@
+"""Pin the network oracles (torch-CPU functional restatements) to the reference goldens:
+FireNet / FireNet+ with the REAL shipped weights, E2VID layouts with synthetic weights."""
+import json
+
+import numpy as np
+import torch
+
+from oracle import model as omod
+from oracle.prepost import CropParams
+from evreal_amd import synth, weights
+from conftest import load_npz
+from golden_inputs import sha
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _sd(npz):
+    return {k: torch.from_numpy(npz[k]) for k in npz.files}
+
+
+def _run_fire(tag, cls):
+    z = load_npz(f'{tag}_seq.npz')
+    w = load_npz(f'{tag}_weights.npz')
+    assert weights.state_dict_digest({k: w[k] for k in w.files}) == str(z['weights_sha'])
+    m = cls(_sd(w))
+    assert m.num_encoders == int(z['num_encoders'])
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W)
+    assert sha(vox) == str(z['voxel_sha'])
+    crop = CropParams(W, H, m.num_encoders)
+    torch.set_num_threads(1)
+    for f in range(F):
+        x = torch.from_numpy(crop.pad(vox[f:f + 1]))
+        img = crop.crop(m(x).numpy())
+        np.testing.assert_allclose(img, z['images'][f:f + 1], **TOL)
+    np.testing.assert_allclose(m.states[0].numpy()[:, :, ::3, ::3], z['state0_sub'], **TOL)
+    np.testing.assert_allclose(m.states[1].numpy()[:, :, ::3, ::3], z['state1_sub'], **TOL)
+
+
+def test_firenet_legacy_real_weights():
+    _run_fire('firenet', omod.FireNetLegacyOracle)
+
+
+def test_firenet_plus_real_weights():
+    _run_fire('firenetplus', omod.FireNetOracle)
+
+
+def _run_e2vid(tag):
+    z = load_npz(f'{tag}_seq.npz')
+    kw = json.loads(bytes(z['kwargs']).decode())
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']))
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
+                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    m = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W)
+    assert sha(vox) == str(z['voxel_sha'])
+    torch.set_num_threads(1)
+    for f in range(F):
+        taps = {} if f == 0 else None
+        img = m(torch.from_numpy(vox[f:f + 1]), taps).numpy()
+        np.testing.assert_allclose(img, z['images'][f:f + 1], **TOL)
+        if f == 0:
+            for k in [k for k in z.files if k.startswith('tap.')]:
+                name = k[4:]
+                got = taps['enc0.h' if name == 'enc0.h' else name] if name in taps else None
+                if name == 'enc0.h':
+                    got = m.states[0][0] if isinstance(m.states[0], tuple) else m.states[0]
+                if name == 'enc2.h':
+                    got = m.states[2][0]
+                got = got.numpy()
+                got = got[:, ::4] if got.shape[1] >= 32 else got
+                np.testing.assert_allclose(got, z[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    for i, s in enumerate(m.states):
+        h = s[0] if isinstance(s, tuple) else s
+        np.testing.assert_allclose(h.numpy()[:, ::4], z[f'h{i}_sub'], rtol=1e-4, atol=1e-5)
+        if isinstance(s, tuple):
+            np.testing.assert_allclose(s[1].numpy()[:, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=1e-5)
+
+
+def test_e2vid_bn_layout():
+    _run_e2vid('e2vid_bn')
+
+
+def test_e2vid_plus_layout():
+    _run_e2vid('e2vid_plus')
+
+
+def test_e2vid_gru_tiny():
+    _run_e2vid('e2vid_gru_tiny')
