@@ -1,0 +1,88 @@
+// Convolution building blocks of the recurrent networks (NHWC fp32 activations on device).
+#pragma once
+#include "common.h"
+
+namespace evr {
+
+constexpr int MAX_TAPS = 25;
+constexpr int MAX_PHASES = 4;
+
+enum InMode { IN_SINGLE = 0, IN_CAT = 1 };
+enum Epilogue {
+    EPI_BIAS = 0,           // out = acc + bias
+    EPI_BIAS_RELU = 1,      // out = relu(acc + bias)
+    EPI_RESIDUAL_RELU = 2,  // out = relu(acc + bias + residual)       (ResidualBlock, submodules.py:169-184)
+    EPI_LSTM = 3,           // ConvLSTM gates (submodules.py:227-245); needs NB == 4 and permuted rows
+    EPI_GRU_ZR = 4,         // ConvGRU update/reset (submodules.py:281-282): z -> aux0, h*r -> out
+    EPI_GRU_OUT = 5         // ConvGRU candidate + blend (submodules.py:283-285): h' in place in `state`
+};
+
+struct ConvPhase {
+    int ntaps;
+    int w_off;        // float offset of this phase's [Cout][ntaps*Cin] weight block
+    int ofy, ofx;     // output pixel = (my*os + ofy, mx*os + ofx)
+    int tap[MAX_TAPS];   // (dy & 0xffff) | (dx << 16): dwords so the kernel fetches them with s_load
+    void set_tap(int i, int dy, int dx) { tap[i] = (dy & 0xffff) | (dx * 65536); }
+};
+
+struct ConvArgs {
+    const float* in0; const float* in1;
+    int c0, c1;               // channels of in0/in1 (IN_SINGLE: c1 == 0)
+    int in_mode;
+    int n, hin, win;          // input tensor [n, hin, win, c]
+    int hm, wm;               // M-grid per image; GEMM M = n*hm*wm
+    int stride;               // input pixel = m*stride + tap offset
+    int nphases;
+    ConvPhase ph[MAX_PHASES];
+    const float* wgt;         // per phase [cout][ntaps*(cin_total)], K contiguous
+    const float* bias;        // [cout]
+    int cout;                 // GEMM N (multiple of 32*NB; rows >= n_valid are zero padding)
+    int n_valid;              // real output channels
+    float* out; int hout, wout, cout_total, os;   // NHWC output [n, hout, wout, cout_total]
+    int epi;
+    const float* residual;    // EPI_RESIDUAL_RELU: same shape as out
+    const float* post_add;    // optional, plain epilogues: out = f(acc) + post_add (fused skip_sum)
+    float* state;             // EPI_LSTM: cell state (in place); EPI_GRU_*: hidden state h
+    float* aux0;              // EPI_GRU_ZR: z out; EPI_GRU_OUT: z in
+    int hidden;               // EPI_LSTM / GRU: number of hidden channels C
+};
+
+// kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
+// `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
+// kernel reads it with scalar loads; it is uploaded once per shape, not per launch).
+int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream);
+// picks (wm, nb) for the shape: fills the 256 CUs when M is small
+void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);
+
+// Direct small-Cin head convolution: planar vox [n,B,H,W] (unpadded; optional on-the-fly event-tensor
+// normalization, eval.py:398-410) -> zero pad to (hp,wp) -> conv kxk s1 p k/2 -> bias -> relu -> NHWC [n,hp,wp,cout].
+struct HeadArgs {
+    const float* vox; const double* stats;   // stats: [n,3] {sum,sumsq,nnz} or null
+    int n, B, H, W, hp, wp, pad_top, pad_left;
+    int k, cout;
+    const float* wgt;    // [B*k*k][cout]
+    const float* bias;   // [cout]
+    float* out;
+    int relu;
+};
+int launch_head_conv(const HeadArgs& a, hipStream_t stream);
+
+// Prediction layer: 1x1 conv C->1 on (x [+ skip]) + bias [+ sigmoid], centre crop -> planar img [n,1,H,W].
+struct PredArgs {
+    const float* x; const float* skip;   // NHWC [n,hp,wp,c]; skip may be null
+    int n, hp, wp, c;
+    const float* wgt; float bias;        // BN folded
+    int sigmoid;
+    int H, W, iy0, ix0;                  // crop window
+    float* img;
+};
+int launch_pred(const PredArgs& a, hipStream_t stream);
+
+// Bilinear x2 (align_corners=False) of (x + skip): NHWC [n,h,w,c] -> [n,2h,2w,c]  (submodules.py:88)
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, hipStream_t stream);
+// out = x + y (skip_sum, model_util.py:4-5) when it cannot be fused into a producer epilogue
+int launch_add(const float* x, const float* y, float* out, int64_t n, hipStream_t stream);
+// NHWC -> NCHW copy (debug/parity reads)
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, hipStream_t stream);
+
+}  // namespace evr

@@ -1,0 +1,467 @@
+// Convolutions of the recurrent networks as implicit GEMM on the fp32 matrix cores of gfx950.
+//
+// Reference ops (model/submodules.py): ConvLayer :8-35, TransposedConvLayer :38-66,
+// UpsampleConvLayer :69-97, ResidualBlock :152-184, ConvLSTM :187-245, ConvGRU :248-287; wired by
+// model/unet.py:107-143 and model/legacy.py:79-111.  The reference dispatches them to aten conv2d /
+// conv_transpose2d on NCHW tensors; here every contraction is ONE kernel family:
+//
+//   GEMM view   M = n*hm*wm output pixels, N = output channels, K = taps x input channels
+//   data        activations NHWC fp32 (a K chunk of 16/32 channels of one pixel = one 64/128-B line);
+//               weights pre-laid as [N][K] (K contiguous) at model creation, BatchNorm folded
+//   MFMA        v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 157 TF peak): the 1e-4 parity gate of
+//               the recurrent state rules out a reduced-precision fast path for now
+//   tile        block = WM waves stacked along M; a wave owns 32 pixels x (NB*32) channels, i.e. NB
+//               accumulators of 16 VGPRs; for ConvLSTM NB = 4 and the weight rows are permuted so
+//               the four 32-column blocks are the in/remember/out/cell gates of the SAME 32 hidden
+//               channels -> the LSTM cell update is a pure register epilogue
+//   LDS         per K step: A tile [32*WM][KC] + B tile [32*NB][KC], double buffered, 16-B slots
+//               XOR-swizzled by row so both the ds_write_b128 staging and the ds_read_b128 fragment
+//               reads are bank-conflict free; a float4 read hands a lane 4 consecutive k, which feed
+//               4 MFMAs (the k order inside an MFMA pair is free as long as A and B agree)
+//   im2col      on the fly: per K step one tap (dy,dx) and one channel chunk go HBM/L2 -> LDS by
+//               `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR staging); zero padding and ragged M
+//               come from the buffer descriptor's range check (out-of-range offset reads 0); channel
+//               concat (x|h) switches descriptors per chunk; ConvTranspose2d(k,s=2) runs as 4
+//               sub-pixel phases (blockIdx-selected tap lists); skip-sum is fused into the producer
+//   epilogues   bias/ReLU, residual+ReLU, ConvLSTM cell, ConvGRU (update/reset, candidate+blend)
+//   grid        1-D, remapped so every XCD (private L2) walks a contiguous range of tiles with the N
+//               tile fastest: an A tile is reused from L2 across its N tiles and neighbouring M tiles
+#include "conv.h"
+
+namespace evr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int KC>
+__device__ __forceinline__ int swz(int row) {
+    return (KC == 32) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+// __amdgpu_buffer_rsrc_t and the LDS-DMA builtins exist only in the device pass of hipcc; the host pass
+// just needs the kernel's signature to emit the launch stub, so the body is compiled for the device only.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+#endif
+
+template <int KC, int WM, int NB>
+__global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
+    constexpr int SP = KC / 4;                 // 16-B slots per row
+    constexpr int NT = 64 * WM;
+    constexpr int A_F4 = 32 * WM * SP, B_F4 = 32 * NB * SP;
+    constexpr int A_PER = A_F4 / NT;           // = SP/2 wave-wide 1-KiB DMA pieces per wave
+    constexpr int B_PER = (B_F4 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float4 lds[2][A_F4 + B_F4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = a.hm * a.wm;
+    const int M = a.n * hw;
+    const int mtiles = (M + 32 * WM - 1) / (32 * WM);
+    const int ntiles = a.cout / (32 * NB);
+
+    // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+    int lin;
+    {
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ntile = lin % ntiles;
+    const int rest = lin / ntiles;
+    const int mtile = rest % mtiles;
+    const int phase = rest / mtiles;
+    const ConvPhase& ph = a.ph[phase];
+    const int m0 = mtile * 32 * WM, n0 = ntile * 32 * NB;
+
+    const int c0 = a.c0, c1 = a.c1;
+    const int cin_total = c0 + (a.in_mode == IN_CAT ? c1 : 0);
+    const int nchunks = cin_total / KC;
+    const int nsteps = ph.ntaps * nchunks;
+    const int ktot = nsteps * KC;
+    const int hin = a.hin, win = a.win;
+
+    // buffer descriptors: out-of-range offsets read as 0.0f -> zero padding and ragged M for free
+    const unsigned in_pix = (unsigned)a.n * hin * win;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt + ph.w_off, (unsigned)a.cout * ktot * 4u);
+
+    // LDS image is lane-linear per DMA piece (64 lanes x 16 B): float4 index idx = piece*64 + lane holds
+    // row idx/SP, slot idx%SP; the XOR swizzle is applied to the SOURCE quad (and again on the fragment read)
+    int r_iy[A_PER], r_ix[A_PER], r_pix[A_PER];
+    unsigned a_q4[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int idx = tid + j * NT;
+        const int row = idx / SP;
+        a_q4[j] = (unsigned)(((idx % SP) ^ swz<KC>(row)) * 4);
+        const int m = m0 + row;
+        if (m < M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int my = rem / a.wm, mx = rem - my * a.wm;
+            r_pix[j] = img * hin; r_iy[j] = my * a.stride; r_ix[j] = mx * a.stride;
+        } else {
+            r_pix[j] = 0; r_iy[j] = -(1 << 28); r_ix[j] = 0;
+        }
+    }
+    unsigned b_off[B_PER];   // float offset of this lane's weight quad at step 0
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int idx = tid + j * NT;
+        const int row = idx / SP;
+        b_off[j] = (unsigned)((n0 + row) * ktot + ((idx % SP) ^ swz<KC>(row)) * 4);
+    }
+
+    auto issue = [&](int s, int buf) {
+        const int t = s / nchunks, cc = s - t * nchunks;
+        int coff = cc * KC;
+        const bool second = coff >= c0;
+        const int csrc = second ? c1 : c0;
+        if (second) coff -= c0;
+        const int tp = ph.tap[t];
+        const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int iy = r_iy[j] + dy, ix = r_ix[j] + dx;
+            unsigned voff = OOB_OFFSET;
+            if ((unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win)
+                voff = ((unsigned)((r_pix[j] + iy) * win + ix) * (unsigned)csrc + (unsigned)coff + a_q4[j]) * 4u;
+            lds_ptr_t dst = (lds_ptr_t)&lds[buf][(wmi + j * WM) * 64];
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            if (B_F4 % NT == 0 || (wmi + j * WM) * 64 < B_F4) {   // wave-uniform
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf][A_F4 + (wmi + j * WM) * 64];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[j] + (unsigned)(s * KC)) * 4u, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
+
+    issue(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        __syncthreads();                       // (waits vmcnt(0)) tile s landed; everyone left tile s-1
+        if (s + 1 < nsteps) issue(s + 1, buf ^ 1);   // DMA of the next tile flies under the MFMAs
+        const float4* la = &lds[buf][(wmi * 32 + r) * SP];
+        const float4* lb = &lds[buf][A_F4 + r * SP];
+#pragma unroll
+        for (int i = 0; i < KC / 8; ++i) {
+            const int q = (2 * i + h) ^ sw;
+            const float4 av = la[q];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 bv = lb[nb * 32 * SP + q];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // C layout of 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int epi = a.epi;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wmi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (m >= M) continue;
+        int64_t opix;   // output pixel index in [n, hout, wout]
+        if (a.os == 1 && a.hout == a.hm && a.wout == a.wm) {
+            opix = m;
+        } else {
+            const int img = m / hw, rem = m - img * hw;
+            const int my = rem / a.wm, mx = rem - my * a.wm;
+            opix = ((int64_t)img * a.hout + (my * a.os + ph.ofy)) * a.wout + (mx * a.os + ph.ofx);
+        }
+        if (epi == EPI_LSTM) {
+            if constexpr (NB == 4) {
+                const int c = (n0 >> 2) + r;   // hidden channel: N tile of 128 = 4 gates x 32 channels
+                const float gi = sigmoidf_(acc[0][reg] + a.bias[n0 + r]);
+                const float gf = sigmoidf_(acc[1][reg] + a.bias[n0 + 32 + r]);
+                const float go = sigmoidf_(acc[2][reg] + a.bias[n0 + 64 + r]);
+                const float gc = tanhf(acc[3][reg] + a.bias[n0 + 96 + r]);
+                const int64_t o = opix * a.hidden + c;
+                const float cprev = a.state[o];
+                const float cn = __fadd_rn(__fmul_rn(gf, cprev), __fmul_rn(gi, gc));   // submodules.py:242
+                a.state[o] = cn;
+                a.out[o] = go * tanhf(cn);                                            // submodules.py:243
+            }
+            continue;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = n0 + nb * 32 + r;
+            float v = acc[nb][reg] + a.bias[n];
+            if (epi == EPI_GRU_ZR) {
+                const int C = a.hidden;
+                if (n < C) {
+                    a.aux0[opix * C + n] = sigmoidf_(v);                 // update gate z
+                } else if (n < 2 * C) {
+                    const int c = n - C;
+                    a.out[opix * C + c] = a.state[opix * C + c] * sigmoidf_(v);   // h * reset
+                }
+            } else if (epi == EPI_GRU_OUT) {
+                const int C = a.hidden;
+                if (n < C) {
+                    const int64_t o = opix * C + n;
+                    const float z = a.aux0[o], hp = a.state[o];
+                    const float cand = tanhf(v);
+                    // submodules.py:285: prev*(1-update) + out*update
+                    a.state[o] = __fadd_rn(__fmul_rn(hp, 1.0f - z), __fmul_rn(cand, z));
+                }
+            } else if (n < a.n_valid) {
+                const int64_t o = opix * a.cout_total + n;
+                if (epi == EPI_RESIDUAL_RELU) v += a.residual[o];
+                if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
+                if (a.post_add) v += a.post_add[o];   // skip_sum fused into the producer (model_util.py:4-5)
+                a.out[o] = v;
+            }
+        }
+    }
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
+template <int KC, int WM, int NB>
+static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream) {
+    const int M = a.n * a.hm * a.wm;
+    const int mtiles = (M + 32 * WM - 1) / (32 * WM);
+    const int ntiles = a.cout / (32 * NB);
+    const int total = mtiles * ntiles * a.nphases;
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB>), dim3(total), dim3(64 * WM), 0, stream, d_args);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream) {
+    EVR_REQUIRE(a.cout % (32 * nb) == 0, "conv_igemm: cout %d not a multiple of %d", a.cout, 32 * nb);
+    EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
+    EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
+    EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
+#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_>(a, d_args, stream);
+    EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
+    EVR_CASE(32, 4, 2) EVR_CASE(32, 2, 2) EVR_CASE(32, 1, 2)
+    EVR_CASE(32, 4, 1) EVR_CASE(32, 2, 1) EVR_CASE(32, 1, 1)
+    EVR_CASE(16, 4, 1) EVR_CASE(16, 2, 1) EVR_CASE(16, 1, 1)
+#undef EVR_CASE
+    set_error("conv_igemm: no kernel for kc=%d wm=%d nb=%d", kc, wm, nb);
+    return EVR_ERR_UNSUPPORTED;
+}
+
+void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb) {
+    int n_b = (a.cout % 128 == 0) ? 4 : (a.cout % 64 == 0) ? 2 : 1;
+    if (kc == 16) n_b = 1;
+    if (a.epi == EPI_LSTM) n_b = 4;
+    const int64_t M = (int64_t)a.n * a.hm * a.wm;
+    const int ntiles = a.cout / (32 * n_b);
+    int w = 4;
+    // shrink the M tile until the launch has >= 2 workgroups per CU (256 CUs) or the tile is one wave
+    while (w > 1 && ((M + 32 * w - 1) / (32 * w)) * ntiles * a.nphases < 512) w >>= 1;
+    *wm = w; *nb = n_b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Head convolution: tiny Cin (num_bins), so K = B*k*k is too ragged for the MFMA tiles; a direct
+// VALU kernel with the input tile in LDS and wave-uniform weights is HBM-bound on its NHWC output.
+template <int K, int COUT>
+__global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
+    constexpr int TS = 16, IS = TS + K - 1;
+    extern __shared__ float tile[];   // [B][IS][IS]
+    const int n = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
+
+    bool norm = false;
+    float mean = 0.f, sd = 1.f;
+    if (a.stats) {   // eval.py:398-410 fused into the load (statistics from evr_voxelize)
+        const double s1 = a.stats[n * 3], s2 = a.stats[n * 3 + 1], nz = a.stats[n * 3 + 2];
+        if (nz > 0.0) {
+            const float nf = (float)nz;
+            mean = (float)s1 / nf;
+            const float ex2 = (float)s2 / nf;
+            sd = sqrtf(__fsub_rn(ex2, __fmul_rn(mean, mean)));
+            if (sd == sd) sd = fmaxf(sd, 1e-6f);
+            norm = true;
+        }
+    }
+    const float* vin = a.vox + (int64_t)n * a.B * a.H * a.W;
+    for (int i = tid; i < a.B * IS * IS; i += 256) {
+        const int b = i / (IS * IS), rr = (i / IS) % IS, cc = i % IS;
+        const int y = ty0 + rr - K / 2 - a.pad_top, x = tx0 + cc - K / 2 - a.pad_left;
+        float v = 0.f;
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
+            v = vin[((int64_t)b * a.H + y) * a.W + x];
+            if (norm) {
+                const float mask = (v != 0.f) ? 1.f : 0.f;
+                v = __fmul_rn(mask, __fsub_rn(v, mean)) / sd;
+            }
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int ly = tid / TS, lx = tid % TS;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = a.bias[co];
+    for (int b = 0; b < a.B; ++b) {
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float v = tile[(b * IS + ly + ky) * IS + lx + kx];
+                const float* w = a.wgt + ((b * K + ky) * K + kx) * COUT;   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+            }
+        }
+    }
+    if (oy < a.hp && ox < a.wp) {
+        float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; co += 4) {
+            float4 v = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(float4*)(o + co) = v;
+        }
+    }
+}
+
+int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
+    const dim3 grid((a.wp + 15) / 16, (a.hp + 15) / 16, a.n);
+    const int IS = 16 + a.k - 1;
+    const size_t lds = (size_t)a.B * IS * IS * sizeof(float);
+    EVR_REQUIRE(lds <= 64 * 1024, "head_conv: num_bins %d too large", a.B);
+#define EVR_HEAD(K_, C_) if (a.k == K_ && a.cout == C_) { hipLaunchKernelGGL((head_conv_kernel<K_, C_>), grid, dim3(256), lds, stream, a); EVR_LAUNCH_CHECK(); return EVR_OK; }
+    EVR_HEAD(5, 32) EVR_HEAD(3, 16) EVR_HEAD(3, 32) EVR_HEAD(5, 16)
+#undef EVR_HEAD
+    set_error("head_conv: unsupported kernel_size %d / base channels %d", a.k, a.cout);
+    return EVR_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.n * a.H * a.W;
+    if (i >= total) return;
+    const int n = (int)(i / ((int64_t)a.H * a.W));
+    const int rem = (int)(i - (int64_t)n * a.H * a.W);
+    const int y = rem / a.W, x = rem - y * a.W;
+    const int64_t pix = ((int64_t)n * a.hp + (y + a.iy0)) * a.wp + (x + a.ix0);
+    const float4* px = (const float4*)(a.x + pix * a.c);
+    const float4* ps = a.skip ? (const float4*)(a.skip + pix * a.c) : nullptr;
+    float acc = 0.f;
+    for (int c4 = 0; c4 < a.c / 4; ++c4) {
+        float4 v = px[c4];
+        if (ps) { const float4 u = ps[c4]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        const float* w = a.wgt + c4 * 4;
+        acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
+    }
+    acc += a.bias;
+    if (a.sigmoid) acc = sigmoidf_(acc);
+    a.img[i] = acc;
+}
+
+int launch_pred(const PredArgs& a, hipStream_t stream) {
+    EVR_REQUIRE(a.c % 4 == 0, "pred: channels %d not a multiple of 4", a.c);
+    const int64_t total = (int64_t)a.n * a.H * a.W;
+    hipLaunchKernelGGL(pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) of (x + skip), NHWC.
+__global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                              float* __restrict__ out, int n, int h, int w, int c) {
+    const int c4n = c / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * 2 * h * 2 * w * c4n;
+    if (i >= total) return;
+    const int c4 = (int)(i % c4n);
+    int64_t p = i / c4n;
+    const int ox = (int)(p % (2 * w)); p /= 2 * w;
+    const int oy = (int)(p % (2 * h));
+    const int img = (int)(p / (2 * h));
+    // aten area_pixel_compute_source_index: src = 0.5*(dst+0.5)-0.5, clamped at 0
+    float sy = 0.5f * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = 0.5f * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    auto ld = [&](int yy, int xx) {
+        const int64_t o = (((int64_t)img * h + yy) * w + xx) * c + c4 * 4;
+        float4 v = *(const float4*)(x + o);
+        if (skip) { const float4 u = *(const float4*)(skip + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        return v;
+    };
+    const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
+    float4 o4;
+    o4.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o4.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o4.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o4.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    *(float4*)(out + ((((int64_t)img * 2 * h + oy) * 2 * w + ox) * c + c4 * 4)) = o4;
+}
+
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, hipStream_t stream) {
+    EVR_REQUIRE(c % 4 == 0, "upsample: channels %d not a multiple of 4", c);
+    const int64_t total = (int64_t)n * 4 * h * w * (c / 4);
+    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float4* __restrict__ x, const float4* __restrict__ y, float4* __restrict__ o, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = x[i], b = y[i];
+        o[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+int launch_add(const float* x, const float* y, float* out, int64_t n, hipStream_t stream) {
+    EVR_REQUIRE(n % 4 == 0, "add: element count not a multiple of 4");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float4*)x, (const float4*)y, (float4*)out, n / 4);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * h * w * c;
+    if (i >= total) return;
+    const int x = (int)(i % w); int64_t p = i / w;
+    const int y = (int)(p % h); p /= h;
+    const int ch = (int)(p % c);
+    const int img = (int)(p / c);
+    dst[i] = src[(((int64_t)img * h + y) * w + x) * c + ch];
+}
+
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, hipStream_t stream) {
+    const int64_t total = (int64_t)n * h * w * c;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+}  // namespace evr

@@ -1,0 +1,711 @@
+// Recurrent-network executor behind evr_model_* (include/evreal_hip.h).
+//
+// Reference: eval.py:109-158 (model construction/loading), :196-197,226-230 (reset, pad, forward,
+// crop); model/unet.py:9-143, model/model.py:108-190, model/legacy.py:32-187, model/submodules.py.
+//
+// Creation (once per checkpoint): the reference's state_dict is re-laid for the implicit-GEMM kernels
+// of conv.hip -- [Cout][tap][Cin] (K contiguous), BatchNorm (eval mode, eval.py:112) folded into
+// weights and bias in fp64, ConvLSTM gate rows permuted so one 128-column tile holds the four gates of
+// 32 hidden channels, ConvGRU update|reset stacked into one GEMM, ConvTranspose2d split into its four
+// stride-2 sub-pixel phases -- and uploaded.
+// Reset (once per sequence shape): activations (NHWC fp32) and recurrent state are allocated for
+// n_seq sequences and zeroed; every layer's launch plan (ConvArgs) is built for both ping-pong parities
+// and kept RESIDENT IN DEVICE MEMORY, so a frame is a fixed chain of kernel launches with 8-byte
+// kernargs, no host arithmetic and no synchronisation.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+using namespace evr;
+
+namespace {
+
+struct HostTensor {
+    const float* data = nullptr;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+
+struct DevTensor {   // NHWC activation / state
+    float* p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0;
+    int64_t numel() const { return (int64_t)n * h * w * c; }
+};
+
+struct Conv {   // one prepared implicit-GEMM convolution
+    std::string name;
+    int kc = 32;
+    int cin0 = 0, cin1 = 0;     // input channels (cat)
+    int n_gemm = 0, n_valid = 0;
+    int k = 3, stride = 1;
+    bool transposed = false;
+    int epi = EPI_BIAS, hidden = 0;
+    int nphases = 1;
+    ConvPhase ph[MAX_PHASES];
+    std::vector<float> w, b;    // host, prepared layout
+    float* d_w = nullptr; float* d_b = nullptr;
+    // per shape
+    ConvArgs args[2];
+    int wm = 4, nb = 4;
+    int arg_slot = -1;
+    double flops = 0.0;
+};
+
+enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED };
+struct Step {
+    StepKind kind;
+    int conv = -1;
+    const float* a[2] = {nullptr, nullptr};   // parity-dependent operands (upsample/add/pred x)
+    const float* b[2] = {nullptr, nullptr};
+    float* out = nullptr;
+    int h = 0, w = 0, c = 0;
+};
+
+}  // namespace
+
+struct evr_model {
+    evr_model_desc desc;
+    std::map<std::string, HostTensor> sd;
+    std::vector<Conv> convs;
+    // head / pred parameters
+    std::vector<float> head_w, head_b, pred_w;
+    float pred_b = 0.f;
+    float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
+    // shape-dependent
+    int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
+    std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes)
+    std::map<std::string, DevTensor> named[2];   // debug names -> tensor valid after a frame of parity p
+    std::vector<Step> steps;
+    ConvArgs* d_args = nullptr;
+    int64_t frame = 0;
+    double flops = 0.0;
+    HeadArgs head;
+    const float* pred_x[2] = {nullptr, nullptr};
+    const float* pred_skip[2] = {nullptr, nullptr};
+    int pred_c = 0;
+
+    ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
+                   if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
+    void release_shape() {
+        for (auto& pr : allocs) (void)hipFree(pr.first);
+        allocs.clear();
+        if (d_args) { (void)hipFree(d_args); d_args = nullptr; }
+        steps.clear(); named[0].clear(); named[1].clear();
+        n_seq = 0;
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// state_dict access
+int find(const evr_model* m, const std::string& name, const HostTensor** out, bool required = true) {
+    auto it = m->sd.find(name);
+    if (it == m->sd.end()) {
+        *out = nullptr;
+        if (required) { set_error("state_dict is missing '%s'", name.c_str()); return EVR_ERR_MISSING_TENSOR; }
+        return EVR_OK;
+    }
+    *out = &it->second;
+    return EVR_OK;
+}
+
+struct Affine { std::vector<double> scale, shift; };   // y = conv*scale + shift (bias and BN folded)
+
+// bias (optional) then BatchNorm in eval mode (optional): y = ((conv + b) - mean)/sqrt(var+eps)*gamma + beta
+int make_affine(const evr_model* m, const std::string& bias_name, const std::string& bn_prefix, bool bn, int cout, Affine* out) {
+    out->scale.assign(cout, 1.0); out->shift.assign(cout, 0.0);
+    const HostTensor* b = nullptr;
+    int rc = find(m, bias_name, &b, false);
+    if (rc) return rc;
+    if (b) { EVR_REQUIRE(b->numel() == cout, "'%s' has %lld elements, expected %d", bias_name.c_str(), (long long)b->numel(), cout);
+             for (int i = 0; i < cout; ++i) out->shift[i] = b->data[i]; }
+    if (bn) {
+        const HostTensor *g, *be, *mu, *var;
+        if ((rc = find(m, bn_prefix + ".weight", &g))) return rc;
+        if ((rc = find(m, bn_prefix + ".bias", &be))) return rc;
+        if ((rc = find(m, bn_prefix + ".running_mean", &mu))) return rc;
+        if ((rc = find(m, bn_prefix + ".running_var", &var))) return rc;
+        EVR_REQUIRE(g->numel() == cout && be->numel() == cout && mu->numel() == cout && var->numel() == cout, "BatchNorm '%s' size mismatch", bn_prefix.c_str());
+        for (int i = 0; i < cout; ++i) {
+            const double s = (double)g->data[i] / std::sqrt((double)var->data[i] + 1e-5);
+            out->shift[i] = (out->shift[i] - (double)mu->data[i]) * s + (double)be->data[i];
+            out->scale[i] = s;
+        }
+    } else {
+        EVR_REQUIRE(b != nullptr || bias_name.empty(), "missing bias '%s'", bias_name.c_str());
+    }
+    return EVR_OK;
+}
+
+int upload(const std::vector<float>& h, float** d) {
+    EVR_HIP(hipMalloc((void**)d, h.size() * sizeof(float) + 64));
+    EVR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return EVR_OK;
+}
+
+int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Conv2d weight [cout, cin, k, k] -> [n_gemm][k*k][cin]; row_of(co) gives the GEMM row of output channel co.
+template <typename RowFn>
+int prep_conv2d(Conv& c, const HostTensor* w, const Affine& af, int cout, int cin, int k, int pad, RowFn row_of, int n_gemm) {
+    EVR_REQUIRE(w->ndim == 4 && w->shape[0] == cout && w->shape[1] == cin && w->shape[2] == k && w->shape[3] == k,
+                "'%s': weight shape [%lld,%lld,%lld,%lld], expected [%d,%d,%d,%d]", c.name.c_str(), (long long)w->shape[0],
+                (long long)w->shape[1], (long long)w->shape[2], (long long)w->shape[3], cout, cin, k, k);
+    const int taps = k * k;
+    EVR_REQUIRE(taps <= MAX_TAPS, "kernel_size %d too large", k);
+    c.w.assign((size_t)n_gemm * taps * cin, 0.f);
+    c.b.assign(n_gemm, 0.f);
+    for (int co = 0; co < cout; ++co) {
+        const int row = row_of(co);
+        c.b[row] = (float)af.shift[co];
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                c.w[((size_t)row * taps + t) * cin + ci] = (float)((double)w->data[((size_t)co * cin + ci) * taps + t] * af.scale[co]);
+    }
+    c.nphases = 1;
+    c.ph[0].ntaps = taps; c.ph[0].w_off = 0; c.ph[0].ofy = 0; c.ph[0].ofx = 0;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) c.ph[0].set_tap(ky * k + kx, ky - pad, kx - pad);
+    c.n_gemm = n_gemm; c.k = k;
+    return EVR_OK;
+}
+
+// ConvTranspose2d(k, stride 2, padding pad, output_padding 1) weight [cin, cout, k, k] -> four sub-pixel phases.
+// out[2my+py] takes ky with (py + pad - ky) even, from input row my + (py + pad - ky)/2.
+int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout, int k, int pad, int n_gemm) {
+    EVR_REQUIRE(w->ndim == 4 && w->shape[0] == cin && w->shape[1] == cout && w->shape[2] == k && w->shape[3] == k,
+                "'%s': transposed weight shape mismatch", c.name.c_str());
+    c.w.clear();
+    c.b.assign(n_gemm, 0.f);
+    for (int co = 0; co < cout; ++co) c.b[co] = (float)af.shift[co];
+    c.nphases = 4;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            ConvPhase& ph = c.ph[py * 2 + px];
+            ph.ntaps = 0; ph.ofy = py; ph.ofx = px; ph.w_off = (int)c.w.size();
+            std::vector<std::pair<int, int>> kk;
+            for (int ky = 0; ky < k; ++ky) {
+                if (((py + pad - ky) & 1) != 0) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    if (((px + pad - kx) & 1) != 0) continue;
+                    ph.set_tap(ph.ntaps++, (py + pad - ky) / 2, (px + pad - kx) / 2);
+                    kk.push_back({ky, kx});
+                }
+            }
+            const size_t base = c.w.size();
+            c.w.resize(base + (size_t)n_gemm * ph.ntaps * cin, 0.f);
+            for (int co = 0; co < cout; ++co)
+                for (int t = 0; t < ph.ntaps; ++t)
+                    for (int ci = 0; ci < cin; ++ci)
+                        c.w[base + ((size_t)co * ph.ntaps + t) * cin + ci] =
+                            (float)((double)w->data[(((size_t)ci * cout + co) * k + kk[t].first) * k + kk[t].second] * af.scale[co]);
+        }
+    c.n_gemm = n_gemm; c.k = k; c.transposed = true;
+    return EVR_OK;
+}
+
+int finish_conv(evr_model* m, Conv& c) {
+    int rc;
+    if ((rc = upload(c.w, &c.d_w))) return rc;
+    if ((rc = upload(c.b, &c.d_b))) return rc;
+    m->convs.push_back(std::move(c));
+    return EVR_OK;
+}
+
+int pick_kc(int c0, int c1) { return (c0 % 32 == 0 && (c1 == 0 || c1 % 32 == 0)) ? 32 : 16; }
+
+// plain conv: prefix.{weight,bias}; bn under bn_prefix
+int add_conv(evr_model* m, const std::string& name, const std::string& wname, const std::string& bname, const std::string& bn_prefix,
+             bool bn, int cin, int cout, int k, int stride, int epi) {
+    Conv c; c.name = name;
+    const HostTensor* w; int rc;
+    if ((rc = find(m, wname, &w))) return rc;
+    Affine af;
+    if ((rc = make_affine(m, bn ? std::string() : bname, bn_prefix, bn, cout, &af))) return rc;
+    EVR_REQUIRE(cin % 16 == 0, "'%s': %d input channels (need a multiple of 16)", name.c_str(), cin);
+    c.kc = pick_kc(cin, 0);
+    c.cin0 = cin; c.cin1 = 0; c.stride = stride; c.epi = epi; c.n_valid = cout;
+    if ((rc = prep_conv2d(c, w, af, cout, cin, k, k / 2, [](int co) { return co; }, round_up(cout, 32)))) return rc;
+    return finish_conv(m, c);
+}
+
+int add_tconv(evr_model* m, const std::string& name, const std::string& prefix, bool bn, int cin, int cout, int k) {
+    Conv c; c.name = name;
+    const HostTensor* w; int rc;
+    if ((rc = find(m, prefix + ".transposed_conv2d.weight", &w))) return rc;
+    Affine af;
+    if ((rc = make_affine(m, bn ? std::string() : prefix + ".transposed_conv2d.bias", prefix + ".norm_layer", bn, cout, &af))) return rc;
+    c.kc = pick_kc(cin, 0);
+    c.cin0 = cin; c.stride = 1; c.epi = EPI_BIAS_RELU; c.n_valid = cout;
+    if ((rc = prep_tconv(c, w, af, cin, cout, k, k / 2, round_up(cout, 32)))) return rc;
+    return finish_conv(m, c);
+}
+
+// ConvLSTM Gates conv (submodules.py:205,227-231): rows permuted to (c/32)*128 + gate*32 + c%32
+int add_lstm(evr_model* m, const std::string& name, const std::string& prefix, int C) {
+    EVR_REQUIRE(C % 32 == 0, "ConvLSTM with %d hidden channels (need a multiple of 32)", C);
+    Conv c; c.name = name;
+    const HostTensor* w; int rc;
+    if ((rc = find(m, prefix + ".Gates.weight", &w))) return rc;
+    Affine af;
+    if ((rc = make_affine(m, prefix + ".Gates.bias", "", false, 4 * C, &af))) return rc;
+    c.kc = 32; c.cin0 = C; c.cin1 = C; c.stride = 1; c.epi = EPI_LSTM; c.hidden = C; c.n_valid = 4 * C;
+    if ((rc = prep_conv2d(c, w, af, 4 * C, 2 * C, 3, 1, [C](int co) { const int g = co / C, ch = co % C; return (ch / 32) * 128 + g * 32 + (ch % 32); }, 4 * C))) return rc;
+    return finish_conv(m, c);
+}
+
+// ConvGRU (submodules.py:255-285): GEMM 1 = [update | reset] over (x|h); GEMM 2 = candidate over (x|h*r)
+int add_gru(evr_model* m, const std::string& name, const std::string& prefix, int C) {
+    EVR_REQUIRE(C % 16 == 0, "ConvGRU with %d hidden channels (need a multiple of 16)", C);
+    int rc;
+    const HostTensor *wz, *wr, *wo;
+    if ((rc = find(m, prefix + ".update_gate.weight", &wz))) return rc;
+    if ((rc = find(m, prefix + ".reset_gate.weight", &wr))) return rc;
+    if ((rc = find(m, prefix + ".out_gate.weight", &wo))) return rc;
+    Affine az, ar, ao;
+    if ((rc = make_affine(m, prefix + ".update_gate.bias", "", false, C, &az))) return rc;
+    if ((rc = make_affine(m, prefix + ".reset_gate.bias", "", false, C, &ar))) return rc;
+    if ((rc = make_affine(m, prefix + ".out_gate.bias", "", false, C, &ao))) return rc;
+    {
+        Conv c; c.name = name + ".zr";
+        c.kc = pick_kc(C, C); c.cin0 = C; c.cin1 = C; c.stride = 1; c.epi = EPI_GRU_ZR; c.hidden = C; c.n_valid = 2 * C;
+        const int ng = round_up(2 * C, 32);
+        Conv tmp; tmp.name = c.name;
+        if ((rc = prep_conv2d(c, wz, az, C, 2 * C, 3, 1, [](int co) { return co; }, ng))) return rc;
+        if ((rc = prep_conv2d(tmp, wr, ar, C, 2 * C, 3, 1, [C](int co) { return C + co; }, ng))) return rc;
+        for (size_t i = (size_t)C * 9 * 2 * C; i < (size_t)2 * C * 9 * 2 * C; ++i) c.w[i] = tmp.w[i];
+        for (int i = C; i < 2 * C; ++i) c.b[i] = tmp.b[i];
+        if ((rc = finish_conv(m, c))) return rc;
+    }
+    {
+        Conv c; c.name = name + ".out";
+        c.kc = pick_kc(C, C); c.cin0 = C; c.cin1 = C; c.stride = 1; c.epi = EPI_GRU_OUT; c.hidden = C; c.n_valid = C;
+        if ((rc = prep_conv2d(c, wo, ao, C, 2 * C, 3, 1, [](int co) { return co; }, round_up(C, 32)))) return rc;
+        if ((rc = finish_conv(m, c))) return rc;
+    }
+    return EVR_OK;
+}
+
+int conv_index(const evr_model* m, const std::string& name) {
+    for (size_t i = 0; i < m->convs.size(); ++i) if (m->convs[i].name == name) return (int)i;
+    return -1;
+}
+
+// head: Conv2d(num_bins -> C, k) [B*k*k][C]; pred: 1x1 C -> 1 (+BN)
+int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::string& pred_prefix, bool pred_bn, int C) {
+    const evr_model_desc& d = m->desc;
+    const HostTensor* w; int rc;
+    if ((rc = find(m, head_prefix + ".weight", &w))) return rc;
+    const int B = d.num_bins, k = d.kernel_size;
+    EVR_REQUIRE(w->ndim == 4 && w->shape[0] == C && w->shape[1] == B && w->shape[2] == k && w->shape[3] == k, "head weight shape mismatch");
+    Affine af;
+    if ((rc = make_affine(m, head_prefix + ".bias", "", false, C, &af))) return rc;
+    m->head_w.assign((size_t)B * k * k * C, 0.f); m->head_b.assign(C, 0.f);
+    for (int co = 0; co < C; ++co) {
+        m->head_b[co] = (float)af.shift[co];
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < k * k; ++t) m->head_w[((size_t)b * k * k + t) * C + co] = w->data[((size_t)co * B + b) * k * k + t];
+    }
+    if ((rc = find(m, pred_prefix + ".conv2d.weight", &w))) return rc;
+    EVR_REQUIRE(w->numel() == C, "pred weight has %lld elements, expected %d", (long long)w->numel(), C);
+    Affine ap;
+    if ((rc = make_affine(m, pred_bn ? std::string() : pred_prefix + ".conv2d.bias", pred_prefix + ".norm_layer", pred_bn, 1, &ap))) return rc;
+    m->pred_w.assign(C, 0.f);
+    for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
+    m->pred_b = (float)ap.shift[0];
+    if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
+    if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
+    if ((rc = upload(m->pred_w, &m->d_pred_w))) return rc;
+    return EVR_OK;
+}
+
+int build_unet(evr_model* m) {
+    const evr_model_desc& d = m->desc;
+    const std::string pre = "unetrecurrent.";
+    const bool bn = d.norm == EVR_NORM_BN;
+    const int E = d.num_encoders, base = d.base_num_channels, k = d.kernel_size;
+    EVR_REQUIRE(E >= 1 && E <= 6 && base % 32 == 0, "UNetRecurrent: num_encoders %d / base_num_channels %d unsupported", E, base);
+    int rc;
+    if ((rc = prep_head_pred(m, pre + "head.conv2d", pre + "pred", bn, base))) return rc;
+    for (int i = 0; i < E; ++i) {
+        const int cin = base << i, cout = base << (i + 1);
+        const std::string p = pre + "encoders." + std::to_string(i);
+        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", bn, cin, cout, k, 2, EPI_BIAS_RELU))) return rc;
+        if (d.recurrent_block == EVR_REC_CONVLSTM) rc = add_lstm(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout);
+        else rc = add_gru(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout);
+        if (rc) return rc;
+    }
+    const int cm = base << E;
+    for (int i = 0; i < d.num_residual_blocks; ++i) {
+        const std::string p = pre + "resblocks." + std::to_string(i), n = "res" + std::to_string(i);
+        if ((rc = add_conv(m, n + ".conv1", p + ".conv1.weight", p + ".conv1.bias", p + ".bn1", bn, cm, cm, 3, 1, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, n + ".conv2", p + ".conv2.weight", p + ".conv2.bias", p + ".bn2", bn, cm, cm, 3, 1, EPI_RESIDUAL_RELU))) return rc;
+    }
+    for (int i = 0; i < E; ++i) {
+        const int cin = base << (E - i), cout = base << (E - i - 1);
+        const std::string p = pre + "decoders." + std::to_string(i), n = "dec" + std::to_string(i);
+        if (d.use_upsample_conv) rc = add_conv(m, n, p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", bn, cin, cout, k, 1, EPI_BIAS_RELU);
+        else rc = add_tconv(m, n, p, bn, cin, cout, k);
+        if (rc) return rc;
+    }
+    return EVR_OK;
+}
+
+int build_firenet(evr_model* m) {
+    const evr_model_desc& d = m->desc;
+    const bool legacy = d.arch == EVR_ARCH_FIRENET_LEGACY;
+    const int C = d.base_num_channels;
+    EVR_REQUIRE(C % 16 == 0, "FireNet: base_num_channels %d unsupported", C);
+    const std::string head = legacy ? "net.head.conv.conv2d" : "head.conv2d";
+    const std::string g1 = legacy ? "net.head.recurrent_block" : "G1";
+    const std::string r1 = legacy ? "net.resblocks.0.conv" : "R1";
+    const std::string g2 = legacy ? "net.resblocks.0.recurrent_block" : "G2";
+    const std::string r2 = legacy ? "net.resblocks.1" : "R2";
+    const std::string pred = legacy ? "net.pred" : "pred";
+    int rc;
+    if ((rc = prep_head_pred(m, head, pred, false, C))) return rc;
+    if ((rc = add_gru(m, "g1", g1, C))) return rc;
+    if ((rc = add_conv(m, "r1.conv1", r1 + ".conv1.weight", r1 + ".conv1.bias", "", false, C, C, 3, 1, EPI_BIAS_RELU))) return rc;
+    if ((rc = add_conv(m, "r1.conv2", r1 + ".conv2.weight", r1 + ".conv2.bias", "", false, C, C, 3, 1, EPI_RESIDUAL_RELU))) return rc;
+    if ((rc = add_gru(m, "g2", g2, C))) return rc;
+    if ((rc = add_conv(m, "r2.conv1", r2 + ".conv1.weight", r2 + ".conv1.bias", "", false, C, C, 3, 1, EPI_BIAS_RELU))) return rc;
+    if ((rc = add_conv(m, "r2.conv2", r2 + ".conv2.weight", r2 + ".conv2.bias", "", false, C, C, 3, 1, EPI_RESIDUAL_RELU))) return rc;
+    return EVR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shape-dependent planning
+int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream) {
+    t->n = n; t->h = h; t->w = w; t->c = c;
+    EVR_HIP(hipMalloc((void**)&t->p, (size_t)t->numel() * sizeof(float) + 256));
+    m->allocs.push_back({t->p, (size_t)t->numel() * sizeof(float)});
+    EVR_HIP(hipMemsetAsync(t->p, 0, (size_t)t->numel() * sizeof(float), stream));
+    EVR_REQUIRE(t->numel() * 4 < 0xFFFFFF00LL, "activation tensor of %lld elements exceeds the 4 GiB buffer-descriptor range; lower n_seq", (long long)t->numel());
+    return EVR_OK;
+}
+
+// fills both parities of a conv's launch plan; in0/in1/out/... given per parity
+struct ConvIO {
+    const float* in0[2]; const float* in1[2]; float* out[2];
+    const float* residual[2] = {nullptr, nullptr}; const float* post_add[2] = {nullptr, nullptr};
+    float* state[2] = {nullptr, nullptr}; float* aux0[2] = {nullptr, nullptr};
+};
+
+void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, int cout_total) {
+    Conv& c = m->convs[ci];
+    for (int p = 0; p < 2; ++p) {
+        ConvArgs& a = c.args[p];
+        memset(&a, 0, sizeof(a));
+        a.in0 = io.in0[p]; a.in1 = io.in1[p];
+        a.c0 = c.cin0; a.c1 = c.cin1; a.in_mode = c.cin1 ? IN_CAT : IN_SINGLE;
+        a.n = n; a.hin = hin; a.win = win;
+        if (c.transposed) { a.hm = hin; a.wm = win; a.stride = 1; a.os = 2; a.hout = 2 * hin; a.wout = 2 * win; }
+        else { a.hm = hin / c.stride; a.wm = win / c.stride; a.stride = c.stride; a.os = 1; a.hout = a.hm; a.wout = a.wm; }
+        a.nphases = c.nphases;
+        for (int i = 0; i < c.nphases; ++i) a.ph[i] = c.ph[i];
+        a.wgt = c.d_w; a.bias = c.d_b; a.cout = c.n_gemm; a.n_valid = c.n_valid;
+        a.out = io.out[p]; a.cout_total = cout_total;
+        a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
+        a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden;
+    }
+    pick_conv_tile(c.args[0], c.kc, &c.wm, &c.nb);
+    double taps = 0;
+    for (int i = 0; i < c.nphases; ++i) taps += c.ph[i].ntaps;
+    c.flops = 2.0 * (double)n * c.args[0].hm * c.args[0].wm * taps * (c.cin0 + c.cin1) * c.n_valid;
+    m->flops += c.flops;
+}
+
+void push_conv(evr_model* m, int ci) { Step s; s.kind = ST_CONV; s.conv = ci; m->steps.push_back(s); }
+
+void name2(evr_model* m, const std::string& name, const DevTensor& t0, const DevTensor& t1) { m->named[0][name] = t0; m->named[1][name] = t1; }
+
+int plan_unet(evr_model* m, hipStream_t stream) {
+    const evr_model_desc& d = m->desc;
+    const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
+    const bool lstm = d.recurrent_block == EVR_REC_CONVLSTM;
+    int rc;
+    DevTensor head;
+    if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream))) return rc;
+    name2(m, "head", head, head);
+    m->head.out = head.p;
+
+    // x[p]: current activation pointer per parity
+    const float* x[2] = {head.p, head.p};
+    int h = m->hp, w = m->wp;
+    std::vector<DevTensor> blk0(E), blk1(E);   // encoder outputs (skip connections) per parity
+    for (int i = 0; i < E; ++i) {
+        const int cout = base << (i + 1);
+        const std::string en = "enc" + std::to_string(i);
+        DevTensor cv;
+        if ((rc = alloc(m, &cv, n, h / 2, w / 2, cout, stream))) return rc;
+        ConvIO io{};
+        io.in0[0] = x[0]; io.in0[1] = x[1]; io.in1[0] = io.in1[1] = nullptr; io.out[0] = io.out[1] = cv.p;
+        const int ci = conv_index(m, en + ".conv");
+        plan_conv(m, ci, n, h, w, io, cout);
+        push_conv(m, ci);
+        name2(m, en + ".conv", cv, cv);
+        h /= 2; w /= 2;
+        if (lstm) {
+            DevTensor hb[2], cb;
+            if ((rc = alloc(m, &hb[0], n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &hb[1], n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &cb, n, h, w, cout, stream))) return rc;
+            ConvIO r{};
+            for (int p = 0; p < 2; ++p) { r.in0[p] = cv.p; r.in1[p] = hb[p].p; r.out[p] = hb[1 - p].p; r.state[p] = cb.p; }
+            const int ri = conv_index(m, en + ".rec");
+            plan_conv(m, ri, n, h, w, r, cout);
+            push_conv(m, ri);
+            x[0] = hb[1].p; x[1] = hb[0].p;
+            blk0[i] = hb[1]; blk1[i] = hb[0];
+            name2(m, "h" + std::to_string(i), hb[1], hb[0]);
+            name2(m, "c" + std::to_string(i), cb, cb);
+        } else {
+            DevTensor hs, z, hr;
+            if ((rc = alloc(m, &hs, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &z, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &hr, n, h, w, cout, stream))) return rc;
+            ConvIO a{}, b{};
+            for (int p = 0; p < 2; ++p) {
+                a.in0[p] = cv.p; a.in1[p] = hs.p; a.out[p] = hr.p; a.state[p] = hs.p; a.aux0[p] = z.p;
+                b.in0[p] = cv.p; b.in1[p] = hr.p; b.out[p] = hs.p; b.state[p] = hs.p; b.aux0[p] = z.p;
+            }
+            const int zi = conv_index(m, en + ".rec.zr"), oi = conv_index(m, en + ".rec.out");
+            plan_conv(m, zi, n, h, w, a, cout); push_conv(m, zi);
+            plan_conv(m, oi, n, h, w, b, cout); push_conv(m, oi);
+            x[0] = x[1] = hs.p;
+            blk0[i] = blk1[i] = hs;
+            name2(m, "h" + std::to_string(i), hs, hs);
+        }
+    }
+    const int cm = base << E;
+    // where the first decoder's skip-sum can be fused: into the last plain conv before it
+    const bool fuse = !d.use_upsample_conv;
+    int last_plain = -1;   // conv index whose epilogue may take post_add
+    for (int i = 0; i < d.num_residual_blocks; ++i) {
+        const std::string rn = "res" + std::to_string(i);
+        DevTensor t, o;
+        if ((rc = alloc(m, &t, n, h, w, cm, stream))) return rc;
+        if ((rc = alloc(m, &o, n, h, w, cm, stream))) return rc;
+        ConvIO a{}, b{};
+        for (int p = 0; p < 2; ++p) {
+            a.in0[p] = x[p]; a.out[p] = t.p;
+            b.in0[p] = t.p; b.out[p] = o.p; b.residual[p] = x[p];
+        }
+        const int c1 = conv_index(m, rn + ".conv1"), c2 = conv_index(m, rn + ".conv2");
+        plan_conv(m, c1, n, h, w, a, cm); push_conv(m, c1);
+        plan_conv(m, c2, n, h, w, b, cm); push_conv(m, c2);
+        x[0] = x[1] = o.p;
+        name2(m, rn, o, o);
+        last_plain = c2;
+    }
+    for (int i = 0; i < E; ++i) {
+        const int cin = base << (E - i), cout = base << (E - i - 1);
+        const DevTensor sk[2] = {blk0[E - 1 - i], blk1[E - 1 - i]};
+        const std::string dn = "dec" + std::to_string(i);
+        const int di = conv_index(m, dn);
+        DevTensor o;
+        if (d.use_upsample_conv) {
+            DevTensor up;
+            if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
+            Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin;
+            for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
+            m->steps.push_back(s);
+            h *= 2; w *= 2;
+            if ((rc = alloc(m, &o, n, h, w, cout, stream))) return rc;
+            ConvIO a{};
+            for (int p = 0; p < 2; ++p) { a.in0[p] = up.p; a.out[p] = o.p; }
+            plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
+        } else {
+            const float* xin[2] = {x[0], x[1]};
+            if (fuse && last_plain >= 0) {
+                // skip_sum (model_util.py:4-5) folded into the producer's epilogue
+                for (int p = 0; p < 2; ++p) m->convs[last_plain].args[p].post_add = sk[p].p;
+            } else {
+                DevTensor sum;
+                if ((rc = alloc(m, &sum, n, h, w, cin, stream))) return rc;
+                Step s; s.kind = ST_ADD; s.out = sum.p; s.h = h; s.w = w; s.c = cin;
+                for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
+                m->steps.push_back(s);
+                xin[0] = xin[1] = sum.p;
+            }
+            if ((rc = alloc(m, &o, n, 2 * h, 2 * w, cout, stream))) return rc;
+            ConvIO a{};
+            for (int p = 0; p < 2; ++p) { a.in0[p] = xin[p]; a.out[p] = o.p; }
+            plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
+            h *= 2; w *= 2;
+            last_plain = di;
+        }
+        x[0] = x[1] = o.p;
+        name2(m, dn, o, o);
+    }
+    m->pred_x[0] = x[0]; m->pred_x[1] = x[1];
+    m->pred_skip[0] = m->pred_skip[1] = head.p;
+    m->pred_c = base;
+    return EVR_OK;
+}
+
+int plan_firenet(evr_model* m, hipStream_t stream) {
+    const int C = m->desc.base_num_channels, n = m->n_seq, h = m->hp, w = m->wp;
+    int rc;
+    DevTensor x0, hs[2], z, hr, t, r[2];
+    if ((rc = alloc(m, &x0, n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &hs[0], n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &hs[1], n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &z, n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &hr, n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &t, n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &r[0], n, h, w, C, stream))) return rc;
+    if ((rc = alloc(m, &r[1], n, h, w, C, stream))) return rc;
+    m->head.out = x0.p;
+    name2(m, "head", x0, x0);
+    const float* x = x0.p;
+    const char* gn[2] = {"g1", "g2"};
+    const char* rn[2] = {"r1", "r2"};
+    for (int s = 0; s < 2; ++s) {
+        ConvIO a{}, b{};
+        for (int p = 0; p < 2; ++p) {
+            a.in0[p] = x; a.in1[p] = hs[s].p; a.out[p] = hr.p; a.state[p] = hs[s].p; a.aux0[p] = z.p;
+            b.in0[p] = x; b.in1[p] = hr.p; b.out[p] = hs[s].p; b.state[p] = hs[s].p; b.aux0[p] = z.p;
+        }
+        const int zi = conv_index(m, std::string(gn[s]) + ".zr"), oi = conv_index(m, std::string(gn[s]) + ".out");
+        plan_conv(m, zi, n, h, w, a, C); push_conv(m, zi);
+        plan_conv(m, oi, n, h, w, b, C); push_conv(m, oi);
+        name2(m, "h" + std::to_string(s), hs[s], hs[s]);
+        ConvIO c1{}, c2{};
+        for (int p = 0; p < 2; ++p) {
+            c1.in0[p] = hs[s].p; c1.out[p] = t.p;
+            c2.in0[p] = t.p; c2.out[p] = r[s].p; c2.residual[p] = hs[s].p;
+        }
+        const int i1 = conv_index(m, std::string(rn[s]) + ".conv1"), i2 = conv_index(m, std::string(rn[s]) + ".conv2");
+        plan_conv(m, i1, n, h, w, c1, C); push_conv(m, i1);
+        plan_conv(m, i2, n, h, w, c2, C); push_conv(m, i2);
+        name2(m, "res" + std::to_string(s), r[s], r[s]);
+        x = r[s].p;
+    }
+    m->pred_x[0] = m->pred_x[1] = x;
+    m->pred_skip[0] = m->pred_skip[1] = nullptr;
+    m->pred_c = C;
+    return EVR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* tensors, int n_tensors, evr_model** out) {
+    EVR_REQUIRE(desc && out && (tensors || n_tensors == 0), "evr_model_create: null argument");
+    *out = nullptr;
+    evr_model* m = new evr_model();
+    m->desc = *desc;
+    for (int i = 0; i < n_tensors; ++i) {
+        HostTensor t; t.data = tensors[i].data_host; t.ndim = tensors[i].ndim;
+        if (!tensors[i].name || t.ndim < 0 || t.ndim > 4) { delete m; set_error("evr_model_create: bad tensor #%d", i); return EVR_ERR_INVALID; }
+        for (int k = 0; k < t.ndim; ++k) t.shape[k] = tensors[i].shape[k];
+        m->sd[tensors[i].name] = t;
+    }
+    int rc;
+    if (desc->arch == EVR_ARCH_UNET_RECURRENT) rc = build_unet(m);
+    else if (desc->arch == EVR_ARCH_FIRENET_LEGACY || desc->arch == EVR_ARCH_FIRENET) rc = build_firenet(m);
+    else { set_error("evr_model_create: unknown arch %d", desc->arch); rc = EVR_ERR_UNSUPPORTED; }
+    m->sd.clear();   // host pointers are only valid during this call
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return EVR_OK;
+}
+
+extern "C" int evr_model_destroy(evr_model* m) {
+    delete m;
+    return EVR_OK;
+}
+
+extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    EVR_REQUIRE(m && n_seq >= 1 && H >= 1 && W >= 1, "evr_model_reset_states: bad arguments");
+    if (m->n_seq == n_seq && m->H == H && m->W == W && !m->allocs.empty()) {
+        // same shape: zero everything that carries state (all activations are cheap to clear too)
+        for (auto& pr : m->allocs) EVR_HIP(hipMemsetAsync(pr.first, 0, pr.second, stream));
+        m->frame = 0;
+        return EVR_OK;
+    }
+    EVR_HIP(hipStreamSynchronize(stream));
+    m->release_shape();
+    m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
+    // CropParameters (utils/util.py:30-59)
+    const int f = 1 << m->desc.pad_multiple_log2;
+    m->hp = (H + f - 1) / f * f; m->wp = (W + f - 1) / f * f;
+    m->pad_top = (m->hp - H + 1) / 2; m->pad_left = (m->wp - W + 1) / 2;     // ceil(0.5*(crop - size))
+    m->iy0 = m->hp / 2 - H / 2; m->ix0 = m->wp / 2 - W / 2;                  // cy - floor(H/2)
+    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT)
+        EVR_REQUIRE(m->hp % (1 << m->desc.num_encoders) == 0 && m->wp % (1 << m->desc.num_encoders) == 0,
+                    "padded size %dx%d not divisible by 2^num_encoders", m->wp, m->hp);
+    memset(&m->head, 0, sizeof(m->head));
+    m->head.n = n_seq; m->head.B = m->desc.num_bins; m->head.H = H; m->head.W = W; m->head.hp = m->hp; m->head.wp = m->wp;
+    m->head.pad_top = m->pad_top; m->head.pad_left = m->pad_left; m->head.k = m->desc.kernel_size;
+    m->head.cout = m->desc.base_num_channels; m->head.wgt = m->d_head_w; m->head.bias = m->d_head_b; m->head.relu = 1;
+    int rc = (m->desc.arch == EVR_ARCH_UNET_RECURRENT) ? plan_unet(m, stream) : plan_firenet(m, stream);
+    if (rc) { m->release_shape(); return rc; }
+    m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
+    m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->pred_c;
+    // upload the launch plans
+    std::vector<ConvArgs> all;
+    for (auto& c : m->convs) { c.arg_slot = (int)all.size(); all.push_back(c.args[0]); all.push_back(c.args[1]); }
+    EVR_HIP(hipMalloc((void**)&m->d_args, all.size() * sizeof(ConvArgs)));
+    EVR_HIP(hipMemcpyAsync(m->d_args, all.data(), all.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, stream));
+    EVR_HIP(hipStreamSynchronize(stream));
+    return EVR_OK;
+}
+
+extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stats, float* img, unsigned flags, evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    EVR_REQUIRE(m && vox && img, "evr_model_step: null argument");
+    EVR_REQUIRE(m->n_seq > 0, "evr_model_step: call evr_model_reset_states first");
+    EVR_REQUIRE(!(flags & 1u) || stats, "evr_model_step: normalization requested without stats");
+    const int p = (int)(m->frame & 1);
+    int rc;
+    HeadArgs ha = m->head;
+    ha.vox = vox; ha.stats = (flags & 1u) ? stats : nullptr;
+    if ((rc = launch_head_conv(ha, stream))) return rc;
+    for (const Step& s : m->steps) {
+        switch (s.kind) {
+            case ST_CONV: {
+                const Conv& c = m->convs[s.conv];
+                if ((rc = launch_conv_igemm(c.args[p], m->d_args + c.arg_slot + p, c.kc, c.wm, c.nb, stream))) return rc;
+                break;
+            }
+            case ST_UPSAMPLE:
+                if ((rc = launch_upsample2x_sum(s.a[p], s.b[p], s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
+                break;
+            case ST_ADD:
+                if ((rc = launch_add(s.a[p], s.b[p], s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream))) return rc;
+                break;
+            default: break;
+        }
+    }
+    PredArgs pa{};
+    pa.x = m->pred_x[p]; pa.skip = m->pred_skip[p]; pa.n = m->n_seq; pa.hp = m->hp; pa.wp = m->wp; pa.c = m->pred_c;
+    pa.wgt = m->d_pred_w; pa.bias = m->pred_b; pa.sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
+    pa.H = m->H; pa.W = m->W; pa.iy0 = m->iy0; pa.ix0 = m->ix0; pa.img = img;
+    if ((rc = launch_pred(pa, stream))) return rc;
+    m->frame++;
+    return EVR_OK;
+}
+
+extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst, int64_t dst_elems, int64_t* n_out, evr_stream_t stream) {
+    EVR_REQUIRE(m && name, "evr_model_read_tensor: null argument");
+    EVR_REQUIRE(m->frame > 0, "evr_model_read_tensor: no frame has run yet");
+    const int p = (int)((m->frame - 1) & 1);
+    auto it = m->named[p].find(name);
+    if (it == m->named[p].end()) { set_error("evr_model_read_tensor: unknown tensor '%s'", name); return EVR_ERR_INVALID; }
+    const DevTensor& t = it->second;
+    if (n_out) *n_out = t.numel();
+    if (!dst) return EVR_OK;
+    EVR_REQUIRE(dst_elems >= t.numel(), "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)t.numel());
+    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, (hipStream_t)stream);
+}
+
+extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }

@@ -1,0 +1,202 @@
+// Pre/post-processing around the network on gfx950.
+//
+//   evr_event_tensor_normalize   eval.py:398-410  (normalize_event_tensor), per window
+//   evr_percentile_normalize     eval.py:380-395  (post_process_normalization) +
+//                                utils/eval_utils.py:15-35 (np.percentile, 'linear' method)
+//
+// Both are HBM/L2-bound elementwise passes around small reductions; fp32 with one rounding per
+// operation (built with -ffp-contract=off) so the elementwise arithmetic matches numpy/torch.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- event-tensor normalization
+constexpr int NRM_BLOCKS = 32;   // partial reductions per window
+
+__global__ __launch_bounds__(256) void nrm_partial_kernel(const float* __restrict__ vox, double* __restrict__ partials,
+                                                           int64_t vol) {
+    __shared__ double sh[3][4];
+    const int w = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* v = vox + (int64_t)w * vol;
+    const int64_t per = (vol + NRM_BLOCKS - 1) / NRM_BLOCKS;
+    const int64_t b0 = per * blk, b1 = min(vol, b0 + per);
+    double s1 = 0, s2 = 0, nz = 0;
+    for (int64_t i = b0 + tid; i < b1; i += 256) {
+        const float a = v[i];
+        s1 += (double)a; s2 += (double)a * (double)a; nz += (a != 0.f) ? 1.0 : 0.0;
+    }
+    s1 = evr_wave_sum(s1); s2 = evr_wave_sum(s2); nz = evr_wave_sum(nz);
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; sh[2][wave] = nz; }
+    __syncthreads();
+    if (tid < 3) partials[((int64_t)w * NRM_BLOCKS + blk) * 3 + tid] = ((sh[tid][0] + sh[tid][1]) + sh[tid][2]) + sh[tid][3];
+}
+
+// stats layout: [n][n_part][3] doubles {sum, sumsq, nnz}; partials summed in fixed order
+__global__ __launch_bounds__(256) void nrm_apply_kernel(float* __restrict__ vox, const double* __restrict__ stats,
+                                                         int n_part, int64_t vol) {
+    const int w = blockIdx.y;
+    double s1 = 0, s2 = 0, nz = 0;
+    for (int k = 0; k < n_part; ++k) {
+        const double* p = stats + ((int64_t)w * n_part + k) * 3;
+        s1 += p[0]; s2 += p[1]; nz += p[2];
+    }
+    if (nz <= 0.0) return;                          // identity when there are no non-zeros
+    // eval.py:402-407 in fp32: sums are fp32 tensors, nnz an integer tensor
+    const float nf = (float)nz;
+    const float mean = (float)s1 / nf;
+    const float ex2 = (float)s2 / nf;
+    const float m2 = mean * mean;
+    float sd = sqrtf(ex2 - m2);
+    if (sd == sd) sd = fmaxf(sd, 1e-6f);            // torch.max propagates NaN
+    float* v = vox + (int64_t)w * vol;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    const bool vec = ((vol & 3) == 0) && ((((uintptr_t)vox) & 15) == 0);
+    for (int64_t i = i0; i < vol; i += stride) {
+        if (vec) {
+            float4 a = *(float4*)&v[i];
+            float r[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float mask = (r[k] != 0.f) ? 1.f : 0.f;
+                const float d = r[k] - mean;
+                const float md = mask * d;
+                r[k] = md / sd;
+            }
+            *(float4*)&v[i] = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+            for (int k = 0; k < 4 && i + k < vol; ++k) {
+                const float a = v[i + k];
+                const float mask = (a != 0.f) ? 1.f : 0.f;
+                const float d = a - mean;
+                const float md = mask * d;
+                v[i + k] = md / sd;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- percentile normalization
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+constexpr int PCT_THREADS = 1024;
+
+// k-th smallest (0-based) of v[0..n) by MSB-first 8-bit radix select; all threads of the block call it.
+__device__ unsigned radix_select(const float* __restrict__ v, int n, int k, unsigned* hist, unsigned* bcast) {
+    unsigned prefix = 0, pmask = 0;
+    int kk = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += PCT_THREADS) {
+            const unsigned key = f2key(v[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned acc = 0; int d = 0;
+            for (; d < 256; ++d) {
+                const unsigned c = hist[d];
+                if ((unsigned)kk < acc + c) break;
+                acc += c;
+            }
+            bcast[0] = (unsigned)d; bcast[1] = acc;
+        }
+        __syncthreads();
+        prefix |= bcast[0] << shift;
+        pmask |= 255u << shift;
+        kk -= (int)bcast[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ img, int n, float q_lo, float q_hi,
+                                                           int do_exp) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned bcast[2];
+    __shared__ float lohi[2];
+    float* v = img + (int64_t)blockIdx.x * n;
+    if (do_exp) {   // 'exprobust' (eval.py:391-393)
+        for (int i = threadIdx.x; i < n; i += PCT_THREADS) v[i] = expf(v[i]);
+        __syncthreads();
+    }
+    float res[2];
+    for (int which = 0; which < 2; ++which) {
+        // numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear'
+        const float q = (which ? q_hi : q_lo) / 100.0f;
+        const float vi = (float)(n - 1) * q;
+        int prev = (int)floorf(vi), next = prev + 1;
+        float gamma;
+        if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma = vi - (-1.0f); }
+        else if (vi < 0.f) { prev = next = 0; gamma = vi - 0.0f; }
+        else gamma = vi - (float)prev;
+        const float a = key2f(radix_select(v, n, prev, hist, bcast));
+        const float b = (next == prev) ? a : key2f(radix_select(v, n, next, hist, bcast));
+        // numpy _lerp
+        const float diff = b - a;
+        float r = a + diff * gamma;
+        if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
+        res[which] = r;
+    }
+    if (threadIdx.x == 0) { lohi[0] = res[0]; lohi[1] = res[1]; }
+    __syncthreads();
+    const float lo = lohi[0], range = lohi[1] - lohi[0];
+    for (int i = threadIdx.x; i < n; i += PCT_THREADS) {
+        const float d = v[i] - lo;
+        v[i] = d / range;
+    }
+}
+
+}  // namespace
+
+extern "C" int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W, const double* stats,
+                                          void* workspace, size_t workspace_bytes, evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    EVR_REQUIRE(n >= 0 && B >= 1 && H >= 1 && W >= 1, "evr_event_tensor_normalize: bad shape");
+    if (n == 0) return EVR_OK;
+    EVR_REQUIRE(vox != nullptr, "evr_event_tensor_normalize: null tensor");
+    const int64_t vol = (int64_t)B * H * W;
+    int n_part = 1;
+    if (!stats) {
+        const size_t need = (size_t)n * NRM_BLOCKS * 3 * sizeof(double);
+        if (!workspace || workspace_bytes < need) {
+            evr::set_error("evr_event_tensor_normalize: workspace %zu B < required %zu B", workspace_bytes, need);
+            return EVR_ERR_WORKSPACE;
+        }
+        hipLaunchKernelGGL(nrm_partial_kernel, dim3(NRM_BLOCKS, n), dim3(256), 0, stream, vox, (double*)workspace, vol);
+        EVR_LAUNCH_CHECK();
+        stats = (const double*)workspace;
+        n_part = NRM_BLOCKS;
+    }
+    int gx = (int)((vol / 4 + 255) / 256);
+    if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(nrm_apply_kernel, dim3(gx, n), dim3(256), 0, stream, vox, stats, n_part, vol);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+extern "C" size_t evr_percentile_normalize_workspace_bytes(int n, int H, int W) {
+    (void)n; (void)H; (void)W;
+    return 0;
+}
+
+extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q_lo, float q_hi, int do_exp,
+                                        void* workspace, size_t workspace_bytes, evr_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
+    EVR_REQUIRE(n >= 0 && H >= 1 && W >= 1, "evr_percentile_normalize: bad shape");
+    EVR_REQUIRE(q_lo >= 0.f && q_hi <= 100.f && q_lo <= q_hi, "evr_percentile_normalize: percentiles must be in [0,100]");
+    EVR_REQUIRE((int64_t)H * W < (1LL << 30), "evr_percentile_normalize: image too large");
+    if (n == 0) return EVR_OK;
+    EVR_REQUIRE(img != nullptr, "evr_percentile_normalize: null image");
+    hipLaunchKernelGGL(pct_kernel, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}

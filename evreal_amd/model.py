@@ -1,0 +1,213 @@
+"""Method plugins: the reference's model classes (model/__init__.py:1-4) backed by evr_model_*.
+
+Same contract as the reference (eval.py:163,197,228,230): an object with `.num_encoders`,
+`.reset_states()` and `__call__(voxel[N,B,H,W] fp32 on the GPU) -> {'image': [N,1,H,W]}`.
+N is the number of independent sequences advanced together (the reference always uses 1).
+The zero padding / centre crop of utils/util.py:30-59 happens inside the library, so the caller
+may pass either the raw HxW voxel grid or an already padded one (then both are no-ops).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+ARCH_UNET, ARCH_FIRENET_LEGACY, ARCH_FIRENET = 0, 1, 2
+
+
+def _np_state_dict(state_dict):
+    out = {}
+    for k, v in state_dict.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.dtype.kind != 'f':
+            continue            # num_batches_tracked
+        out[k] = np.ascontiguousarray(v, dtype=np.float32)
+    return out
+
+
+class _HipModel:
+    arch = None
+
+    def __init__(self):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.handle = None
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self._shape = None
+        self._needs_reset = True
+
+    # -- construction ----------------------------------------------------------------------
+    def _desc(self):
+        raise NotImplementedError
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = _np_state_dict(state_dict)
+        tensors = (_lib.Tensor * len(sd))()
+        keep = []
+        for i, (k, v) in enumerate(sd.items()):
+            name = k.encode()
+            keep.append((name, v))
+            tensors[i].name = name
+            tensors[i].data_host = v.ctypes.data_as(ctypes.c_void_p)
+            tensors[i].ndim = v.ndim
+            for d in range(v.ndim):
+                tensors[i].shape[d] = v.shape[d]
+        self.destroy()
+        h = ctypes.c_void_p()
+        desc = self._desc()
+        _lib.check(self.lib.evr_model_create(ctypes.byref(desc), tensors, len(sd), ctypes.byref(h)),
+                   'evr_model_create')
+        self.handle = h
+        self._shape = None
+        self._needs_reset = True
+        return self
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def destroy(self):
+        if self.handle is not None:
+            self.lib.evr_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- plugin contract -------------------------------------------------------------------
+    def reset_states(self):
+        """eval.py:197 -- recurrent state is per sequence; buffers are (re)built lazily."""
+        self._needs_reset = True
+
+    def _ensure(self, n, H, W):
+        if self.handle is None:
+            raise _lib.EvrError("model has no weights: call load_state_dict first")
+        if self._needs_reset or self._shape != (n, H, W):
+            _lib.check(self.lib.evr_model_reset_states(self.handle, n, H, W, _lib.stream_ptr()),
+                       'evr_model_reset_states')
+            self._shape = (n, H, W)
+            self._needs_reset = False
+
+    def forward(self, voxel, stats=None, out=None):
+        assert voxel.is_cuda and voxel.dtype == torch.float32 and voxel.dim() == 4
+        voxel = voxel.contiguous()
+        n, B, H, W = voxel.shape
+        self._ensure(n, H, W)
+        if out is None:
+            out = torch.empty((n, 1, H, W), dtype=torch.float32, device=voxel.device)
+        flags = 1 if stats is not None else 0
+        _lib.check(self.lib.evr_model_step(self.handle, _lib.ptr(voxel), _lib.ptr(stats), _lib.ptr(out), flags,
+                                           _lib.stream_ptr()), 'evr_model_step')
+        return {'image': out}
+
+    __call__ = forward
+
+    # -- parity/debug helpers --------------------------------------------------------------
+    def read_tensor(self, name):
+        n = ctypes.c_int64(0)
+        _lib.check(self.lib.evr_model_read_tensor(self.handle, name.encode(), None, 0, ctypes.byref(n),
+                                                  _lib.stream_ptr()), 'evr_model_read_tensor')
+        buf = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.evr_model_read_tensor(self.handle, name.encode(), _lib.ptr(buf), n.value,
+                                                  ctypes.byref(n), _lib.stream_ptr()), 'evr_model_read_tensor')
+        return buf
+
+    def flops_per_step(self):
+        return float(self.lib.evr_model_flops_per_step(self.handle))
+
+
+class E2VIDRecurrent(_HipModel):
+    """model/model.py:108-144 over model/unet.py:85-143 (E2VID, E2VID+, SSL-E2VID layouts)."""
+
+    def __init__(self, unet_kwargs):
+        super().__init__()
+        kw = dict(unet_kwargs)
+        self.kwargs = kw
+        self.num_bins = kw['num_bins']
+        self.num_encoders = kw['num_encoders']
+        if kw.get('skip_type', 'sum') != 'sum':
+            raise _lib.EvrError("only skip_type='sum' exists in the reference (model/unet.py:4,31)")
+        if kw.get('use_dynamic_decoder', False):
+            raise _lib.EvrError("HyperE2VID's dynamic decoder is not built yet (SURVEY 8a a21)")
+        if kw.get('norm') not in (None, 'none', 'BN'):
+            raise _lib.EvrError(f"norm={kw.get('norm')!r} is not supported (BN or none)")
+        if kw.get('num_output_channels', 1) != 1:
+            raise _lib.EvrError("only num_output_channels=1 (image) is supported")
+
+    def _desc(self):
+        kw = self.kwargs
+        d = _lib.ModelDesc()
+        d.arch = ARCH_UNET
+        d.num_bins = kw['num_bins']
+        d.base_num_channels = kw.get('base_num_channels', 32)
+        d.num_encoders = kw['num_encoders']
+        d.num_residual_blocks = kw.get('num_residual_blocks', 2)
+        d.kernel_size = kw.get('kernel_size', 5)
+        d.norm = 1 if kw.get('norm') == 'BN' else 0
+        d.use_upsample_conv = 1 if kw.get('use_upsample_conv', True) else 0
+        d.recurrent_block = 0 if kw.get('recurrent_block_type', 'convlstm') == 'convlstm' else 1
+        # getattr(torch, name, None) in model/unet.py:95-96: only 'sigmoid' is used by the reference
+        fa = kw.get('final_activation', 'none')
+        if fa not in ('none', '', None, 'sigmoid'):
+            raise _lib.EvrError(f"final_activation={fa!r} is not supported")
+        d.final_activation = 1 if fa == 'sigmoid' else 0
+        d.pad_multiple_log2 = kw['num_encoders']
+        return d
+
+
+class FireNet_legacy(_HipModel):
+    """model/legacy.py:155-187 (the "FireNet" method): cropper pads to a multiple of 16 because
+    num_encoders silently defaults to 4 (legacy.py:127-130)."""
+
+    def __init__(self, config=None, unet_kwargs=None):
+        super().__init__()
+        cfg = dict(unet_kwargs or config or {})
+        self.config = cfg
+        self.num_bins = int(cfg['num_bins'])
+        self.num_encoders = int(cfg.get('num_encoders', 4))
+        if str(cfg.get('recurrent_block_type', 'convgru')) != 'convgru':
+            raise _lib.EvrError("FireNet_legacy: only convgru is supported")
+        if cfg.get('recurrent_blocks', {'resblock': [0]}) != {'resblock': [0]}:
+            raise _lib.EvrError("FireNet_legacy: only recurrent_blocks={'resblock':[0]} is supported")
+        if str(cfg.get('norm', 'none')) not in ('none', 'None'):
+            raise _lib.EvrError("FireNet_legacy: norm must be 'none'")
+
+    def _desc(self):
+        d = _lib.ModelDesc()
+        d.arch = ARCH_FIRENET_LEGACY
+        d.num_bins = self.num_bins
+        d.base_num_channels = int(self.config.get('base_num_channels', 32))
+        d.num_residual_blocks = int(self.config.get('num_residual_blocks', 2))
+        d.kernel_size = int(self.config.get('kernel_size', 5))
+        d.pad_multiple_log2 = self.num_encoders
+        return d
+
+
+class FireNet(_HipModel):
+    """model/model.py:147-190 (the "FireNet+" method; eval.py:154-155 forces num_encoders = 0)."""
+
+    def __init__(self, num_bins=5, base_num_channels=16, kernel_size=3):
+        super().__init__()
+        self.num_bins, self.base_num_channels, self.kernel_size = num_bins, base_num_channels, kernel_size
+        self.num_encoders = 0
+
+    def _desc(self):
+        d = _lib.ModelDesc()
+        d.arch = ARCH_FIRENET
+        d.num_bins = self.num_bins
+        d.base_num_channels = self.base_num_channels
+        d.num_residual_blocks = 2
+        d.kernel_size = self.kernel_size
+        d.pad_multiple_log2 = self.num_encoders
+        return d

@@ -1,0 +1,76 @@
+"""Host side of the tensorizer: same call shape as the reference's
+utils/event_utils.py:27-59 (events_to_voxel_torch) plus the batched form the C ABI offers."""
+import torch
+
+from . import lib as _lib
+
+
+class Voxelizer:
+    """Owns the workspace for evr_voxelize and keeps it across calls (no per-call allocation)."""
+
+    def __init__(self, device='cuda:0'):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.ws = None
+
+    def _workspace(self, n_events, n_windows, B, H, W):
+        need = self.lib.evr_voxelize_workspace_bytes(n_events, n_windows, B, H, W)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def voxelize(self, x, y, t, p, win_offsets, num_bins, sensor_size, out=None, stats=None, stream=None):
+        """x,y,t,p: fp32 cuda tensors [n]; win_offsets: int64 cuda tensor [n_windows+1].
+        Returns out [n_windows, B, H, W] fp32 (every cell written)."""
+        H, W = sensor_size
+        n = int(x.numel()); nw = int(win_offsets.numel()) - 1
+        for a in (x, y, t, p):
+            assert a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == n
+        assert win_offsets.is_cuda and win_offsets.dtype == torch.int64
+        if out is None:
+            out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=x.device)
+        ws = self._workspace(n, nw, num_bins, H, W)
+        rc = self.lib.evr_voxelize(_lib.ptr(x), _lib.ptr(y), _lib.ptr(t), _lib.ptr(p), _lib.ptr(win_offsets),
+                                   nw, n, num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws),
+                                   ws.numel(), _lib.stream_ptr(stream))
+        _lib.check(rc, 'evr_voxelize')
+        return out
+
+    def voxelize_raw(self, xy, ts, pol, win_offsets, num_bins, sensor_size, out=None, stats=None, stream=None):
+        """Raw memmap form (dataset.py:222-228 fused): xy int16 [n,2], ts float64 [n], pol uint8 [n]."""
+        H, W = sensor_size
+        n = int(ts.numel()); nw = int(win_offsets.numel()) - 1
+        assert xy.dtype == torch.int16 and ts.dtype == torch.float64 and pol.dtype == torch.uint8
+        assert xy.is_contiguous() and ts.is_contiguous() and pol.is_contiguous()
+        if out is None:
+            out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=ts.device)
+        ws = self._workspace(n, nw, num_bins, H, W)
+        rc = self.lib.evr_voxelize_raw(_lib.ptr(xy), _lib.ptr(ts), _lib.ptr(pol), _lib.ptr(win_offsets), nw, n,
+                                       num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws), ws.numel(),
+                                       _lib.stream_ptr(stream))
+        _lib.check(rc, 'evr_voxelize_raw')
+        return out
+
+    def dropped(self):
+        import ctypes
+        v = ctypes.c_int64(0)
+        _lib.check(self.lib.evr_voxelize_dropped(_lib.ptr(self.ws), ctypes.byref(v), _lib.stream_ptr()),
+                   'evr_voxelize_dropped')
+        return v.value
+
+
+_default = None
+
+
+def events_to_voxel_torch(xs, ys, ts, ps, num_bins, device=None, sensor_size=(180, 240)):
+    """Drop-in for utils/event_utils.py:27-59: one window, tensors in, [B,H,W] tensor out.
+    Inputs are moved to the GPU; the result stays there."""
+    global _default
+    if _default is None:
+        _default = Voxelizer()
+    dev = _default.device
+    assert len(xs) == len(ys) == len(ts) == len(ps)
+    f = lambda a: a.to(device=dev, dtype=torch.float32).contiguous()
+    offs = torch.tensor([0, len(xs)], dtype=torch.int64, device=dev)
+    return _default.voxelize(f(xs), f(ys), f(ts), f(ps), offs, num_bins, tuple(sensor_size))[0]

@@ -1,0 +1,168 @@
+/* evreal_hip.h -- C ABI of libevreal_hip.so, the MI355X (gfx950) hot path of EVREAL.
+ *
+ * The reference (ercanburak/EVREAL) is pure Python and has no FFI of its own; the boundary a
+ * maintainer binds is its Python plugin surface.  Each entry point below replaces
+ * one stretch of that surface and cites it (paths relative to the reference root).  The Python
+ * host in evreal_amd/ binds these with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - plain C types only; every pointer is CALLER-OWNED DEVICE memory unless suffixed _host;
+ *   - every call takes a hipStream_t (passed as void*) and is asynchronous on it;
+ *   - return 0 on success, a negative evr_status on failure; evr_last_error() gives a
+ *     thread-local message; nothing throws across the boundary;
+ *   - opaque handles own persistent device state and are freed by the matching _destroy;
+ *     one handle is used from one host thread at a time;
+ *   - tensors are dense fp32, layouts as in the reference (NCHW) at the boundary.
+ */
+#ifndef EVREAL_HIP_H
+#define EVREAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* evr_stream_t; /* hipStream_t */
+
+enum evr_status {
+    EVR_OK = 0,
+    EVR_ERR_INVALID = -1,   /* bad argument */
+    EVR_ERR_HIP = -2,       /* a HIP runtime call failed */
+    EVR_ERR_WORKSPACE = -3, /* workspace too small */
+    EVR_ERR_UNSUPPORTED = -4,
+    EVR_ERR_MISSING_TENSOR = -5
+};
+
+/* Message for the last failure on this thread ("" if none). */
+const char* evr_last_error(void);
+/* ABI version (major*1000 + minor). */
+int evr_version(void);
+/* Device facts used by bench.py's roofline block: CU count, clock (MHz), name. */
+int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_t name_len);
+
+/* ----------------------------------------------------------------------------------------------
+ * Events -> voxel grid.  Replaces utils/event_utils.py:27-59 (events_to_voxel_torch) and :4-24
+ * (events_to_image_torch) as called from dataset.py:205-216 (MemMapDataset.get_voxel_grid), for
+ * many windows per launch.
+ *
+ *   x, y, t, p     fp32 [n_events_total]: the four arrays MemMapDataset.__getitem__ builds
+ *                  (dataset.py:48-57): x,y pixel coordinates, t = float32(ts - ts[window start]),
+ *                  p = polarity weight (+-1).  Events are time-ordered inside a window.
+ *   win_offsets    int64 [n_windows+1] (device): window w = events [win_offsets[w], win_offsets[w+1]);
+ *                  an empty window yields zeros (dataset.py:200-203).
+ *   out            fp32 [n_windows, B, H, W]; every cell is written (zero fill included).
+ *   stats          optional (may be NULL): double [n_windows, 3] = {sum, sum of squares, nnz} of
+ *                  each window's voxel grid, the reductions eval.py:402-405 needs.
+ * Results are BIT-IDENTICAL to the reference's CPU path: per-cell adds happen in event order.
+ * Events whose pixel falls outside [0,W)x[0,H) are dropped and counted (evr_voxelize_dropped).
+ */
+size_t evr_voxelize_workspace_bytes(int64_t n_events_total, int n_windows, int B, int H, int W);
+int evr_voxelize(const float* x, const float* y, const float* t, const float* p,
+                 const int64_t* win_offsets, int n_windows, int64_t n_events_total,
+                 int B, int H, int W, float* out, double* stats,
+                 void* workspace, size_t workspace_bytes, evr_stream_t stream);
+/* Reads (synchronously) the out-of-range-event counter the last evr_voxelize on this workspace
+ * left behind.  The reference raises from index_put_ in that case. */
+int evr_voxelize_dropped(const void* workspace, int64_t* n_dropped_host, evr_stream_t stream);
+
+/* Raw-format variant: events straight from the memmaps (dataset.py:222-228 + :53-57 fused):
+ * xy int16 [n,2], ts float64 [n] (absolute seconds), pol uint8 {0,1}.  Same output. */
+int evr_voxelize_raw(const int16_t* xy, const double* ts, const uint8_t* pol,
+                     const int64_t* win_offsets, int n_windows, int64_t n_events_total,
+                     int B, int H, int W, float* out, double* stats,
+                     void* workspace, size_t workspace_bytes, evr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Event-tensor normalization.  Replaces eval.py:398-410 (normalize_event_tensor), applied per
+ * window: over non-zeros mean = sum/nnz, std = sqrt(sumsq/nnz - mean^2) clamped to 1e-6,
+ * out = mask*(v-mean)/std; identity when nnz == 0.  In place on vox [n, B, H, W].
+ * stats: optional double [n,3] from evr_voxelize (skips the reduction pass); NULL -> computed here
+ * into workspace (needs n*3*8 bytes).
+ */
+int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W, const double* stats,
+                               void* workspace, size_t workspace_bytes, evr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Recurrent-network inference.  Replaces get_model_from_checkpoint_path/load_model
+ * (eval.py:109-115,124-158), cropper.pad / model(voxel) / cropper.crop (eval.py:226-230,
+ * utils/util.py:30-59) and model.reset_states() (eval.py:197) for
+ *   EVR_ARCH_UNET_RECURRENT  model/model.py:108-144 E2VIDRecurrent over model/unet.py:85-143
+ *                            (E2VID, E2VID+, SSL-E2VID layouts: BN or no norm, transposed or
+ *                            bilinear-upsample decoders, ConvLSTM or ConvGRU, optional sigmoid)
+ *   EVR_ARCH_FIRENET_LEGACY  model/legacy.py:32-111,155-187 (the "FireNet" method)
+ *   EVR_ARCH_FIRENET         model/model.py:147-190 (the "FireNet+" method)
+ * Weights are handed over as the reference's own state_dict: names + host fp32 arrays.
+ */
+enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2 };
+enum evr_norm { EVR_NORM_NONE = 0, EVR_NORM_BN = 1 };
+enum evr_recurrent { EVR_REC_CONVLSTM = 0, EVR_REC_CONVGRU = 1 };
+enum evr_activation { EVR_ACT_NONE = 0, EVR_ACT_SIGMOID = 1 };
+
+typedef struct evr_model_desc {
+    int arch;                /* evr_arch */
+    int num_bins;            /* input channels */
+    int base_num_channels;
+    int num_encoders;        /* UNet only; also drives the crop/pad size (utils/util.py:41-48) */
+    int num_residual_blocks;
+    int kernel_size;         /* head/encoder/decoder kernel (5 for E2VID, 3 for FireNet) */
+    int norm;                /* evr_norm */
+    int use_upsample_conv;   /* 0: ConvTranspose2d decoders, 1: bilinear x2 + conv */
+    int recurrent_block;     /* evr_recurrent */
+    int final_activation;    /* evr_activation */
+    int pad_multiple_log2;   /* cropper's num_encoders (FireNet legacy: 4, FireNet+: 0) */
+    int reserved[5];
+} evr_model_desc;
+
+typedef struct evr_tensor {
+    const char* name;        /* state_dict key */
+    const float* data_host;  /* fp32, contiguous, host memory */
+    int ndim;
+    int64_t shape[4];
+} evr_tensor;
+
+typedef struct evr_model evr_model;
+
+int evr_model_create(const evr_model_desc* desc, const evr_tensor* tensors, int n_tensors,
+                     evr_model** out);
+int evr_model_destroy(evr_model* m);
+/* (Re)allocate activations/state for n_seq sequences of H x W frames and zero the recurrent
+ * state (model.reset_states(), eval.py:197). */
+int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr_stream_t stream);
+/* One frame for each of the n_seq sequences: vox [n_seq, B, H, W] (unpadded) -> img
+ * [n_seq, 1, H, W] (cropped).  Zero padding to a multiple of 2^pad_multiple_log2 and the centre
+ * crop happen inside (utils/util.py:41-59).  flags: bit 0 = apply event-tensor normalization
+ * (eval.py:222-223) to vox on the fly using `stats` (double [n_seq,3]). */
+int evr_model_step(evr_model* m, const float* vox, const double* stats, float* img, unsigned flags,
+                   evr_stream_t stream);
+/* Debug/parity access: copy a named internal activation or state (NCHW fp32) to device memory.
+ * Names: "head", "enc{i}.conv", "h{i}", "c{i}", "res{i}", "dec{i}".  Returns element count in *n. */
+int evr_model_read_tensor(evr_model* m, const char* name, float* dst, int64_t dst_elems,
+                          int64_t* n_out, evr_stream_t stream);
+/* Direct-convolution FLOPs (2*MAC) of one evr_model_step at the current shape. */
+double evr_model_flops_per_step(const evr_model* m);
+
+/* ----------------------------------------------------------------------------------------------
+ * Post-processing.  Replaces post_process_normalization (eval.py:380-395) + normalize
+ * (utils/eval_utils.py:15-35): img <- (img - P_qlo) / (P_qhi - P_qlo) with numpy's default linear
+ * percentile; do_exp applies exp() first ('exprobust').  Per image of [n, H, W], in place.
+ */
+size_t evr_percentile_normalize_workspace_bytes(int n, int H, int W);
+int evr_percentile_normalize(float* img, int n, int H, int W, float q_lo, float q_hi, int do_exp,
+                             void* workspace, size_t workspace_bytes, evr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Per-frame metrics.  Replaces EvalMetricsTracker.update's clip (utils/eval_metrics.py:253-255),
+ * MseMetric.calculate (:82-84) and SsimMetric.calculate (:95-97; gaussian_weights=True, sigma=1.5,
+ * use_sample_covariance=False, data_range=1.0).  img, ref: [n, H, W]; out: double [n, 2] = {mse, ssim}.
+ * which: bit 0 = mse, bit 1 = ssim.  clip: clamp both inputs to [0,1] first.
+ */
+int evr_metrics(const float* img, const float* ref, int n, int H, int W, unsigned which, int clip,
+                double* out, void* workspace, size_t workspace_bytes, evr_stream_t stream);
+size_t evr_metrics_workspace_bytes(int n, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVREAL_HIP_H */

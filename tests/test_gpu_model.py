@@ -1,0 +1,132 @@
+"""GPU parity: the recurrent networks (HIP implicit-GEMM convolutions through the C ABI) vs the oracle
+and the reference goldens.  Tolerance: 1e-4 absolute per pixel on images (north_star), 1e-4 relative /
+1e-5 absolute on states -- fp32 everywhere, only the summation order differs from the reference."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from golden_inputs import sha
+
+pytestmark = pytest.mark.gpu
+IMG_ATOL = 1e-4
+
+
+def _fire(tag, cls_name):
+    from evreal_amd import model, synth, weights
+    z = load_npz(f'{tag}_seq.npz')
+    w = load_npz(f'{tag}_weights.npz')
+    sd = {k: w[k] for k in w.files}
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    if cls_name == 'FireNet_legacy':
+        m = model.FireNet_legacy(unet_kwargs=dict(num_bins=5, skip_type='no_skip', recurrent_block_type='convgru',
+                                                  base_num_channels=16, num_residual_blocks=2,
+                                                  recurrent_blocks={'resblock': [0]}, kernel_size=3, norm='none'))
+    else:
+        m = model.FireNet(num_bins=5, base_num_channels=16, kernel_size=3)
+    m.load_state_dict(sd)
+    assert m.num_encoders == int(z['num_encoders'])
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W)
+    assert sha(vox) == str(z['voxel_sha'])
+    m.reset_states()
+    for f in range(F):
+        img = m(torch.from_numpy(vox[f:f + 1]).cuda())['image'].cpu().numpy()
+        np.testing.assert_allclose(img, z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')
+    # states live on the padded grid; the golden stores a ::3 subsample of the reference's padded state
+    hp = (H + 15) // 16 * 16 if cls_name == 'FireNet_legacy' else H
+    for i in range(2):
+        h = m.read_tensor(f'h{i}').cpu().numpy().reshape(1, 16, hp, W)
+        np.testing.assert_allclose(h[:, :, ::3, ::3], z[f'state{i}_sub'], rtol=1e-4, atol=1e-5)
+
+
+def test_firenet_legacy_real_weights():
+    _fire('firenet', 'FireNet_legacy')
+
+
+def test_firenet_plus_real_weights():
+    _fire('firenetplus', 'FireNet')
+
+
+def _e2vid(tag, n_seq=1):
+    from evreal_amd import model, synth, weights
+    z = load_npz(f'{tag}_seq.npz')
+    kw = json.loads(bytes(z['kwargs']).decode())
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']))
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    m = model.E2VIDRecurrent(kw)
+    m.load_state_dict(sd)
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W)
+    assert sha(vox) == str(z['voxel_sha'])
+    m.reset_states()
+    for f in range(F):
+        x = torch.from_numpy(vox[f:f + 1]).cuda()
+        if n_seq > 1:   # replicate the sequence: every replica must reproduce the golden
+            x = x.repeat(n_seq, 1, 1, 1)
+        img = m(x)['image'].cpu().numpy()
+        for s in range(n_seq):
+            np.testing.assert_allclose(img[s:s + 1], z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f} seq {s}')
+        if f == 0 and n_seq == 1:
+            for k in [k for k in z.files if k.startswith('tap.')]:
+                name = k[4:]
+                if name in ('res1', 'dec0', 'dec2') and not kw['use_upsample_conv']:
+                    continue          # those buffers hold the fused skip-sum; covered by the later layers
+                dname = {'enc0.h': 'h0', 'enc2.h': 'h2'}.get(name, name)
+                got = m.read_tensor(dname).cpu().numpy()
+                want = z[k]
+                got = got.reshape(1, -1, want.shape[2], want.shape[3])
+                got = got[:, ::4] if got.shape[1] >= 32 else got
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=k)
+    for i in range(kw['num_encoders']):
+        want = z[f'h{i}_sub']
+        h = m.read_tensor(f'h{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
+        np.testing.assert_allclose(h[:1, ::4], want, rtol=1e-4, atol=2e-5, err_msg=f'h{i}')
+        if f'c{i}_sub' in z.files:
+            c = m.read_tensor(f'c{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
+            np.testing.assert_allclose(c[:1, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=2e-5, err_msg=f'c{i}')
+
+
+def test_e2vid_bn_layout():
+    _e2vid('e2vid_bn')
+
+
+def test_e2vid_plus_layout():
+    _e2vid('e2vid_plus')
+
+
+def test_e2vid_gru_tiny():
+    _e2vid('e2vid_gru_tiny')
+
+
+def test_e2vid_bn_batched_sequences():
+    _e2vid('e2vid_bn', n_seq=3)
+
+
+def test_e2vid_full_size_vs_oracle_with_padding_and_norm():
+    """346x260 (pads to 352x264), fused event-tensor normalization, 3 frames, against the torch-CPU oracle."""
+    from evreal_amd import model, synth, weights
+    from evreal_amd.voxel import Voxelizer
+    from oracle import model as omod, prepost as op, voxel as ov
+    from golden_inputs import gen_events
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=3)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
+                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    H, W = 260, 346
+    crop = op.CropParams(W, H, 3)
+    vz = Voxelizer()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    m.reset_states()
+    for f in range(3):
+        x, y, t, p = gen_events(900 + f, 15000, W, H)
+        st = torch.zeros((1, 3), dtype=torch.float64, device='cuda')
+        g = vz.voxelize(d(x), d(y), d(t), d(p), d(np.array([0, 15000], dtype=np.int64)), 5, (H, W), stats=st)
+        img = m(g, stats=st)['image'].cpu().numpy()
+        v = op.normalize_event_tensor(ov.events_to_voxel(x, y, t, p, 5, (H, W))[None])
+        want = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())
+        np.testing.assert_allclose(img, want, rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')

@@ -1,0 +1,117 @@
+"""GPU parity: HIP tensorizer (through the C ABI) vs the oracle and the reference goldens -- BIT exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, load_json
+from golden_inputs import gen_events, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def vox():
+    from evreal_amd.voxel import Voxelizer
+    return Voxelizer()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def run(vox, x, y, t, p, offs, B, H, W, stats=False):
+    st = torch.zeros((len(offs) - 1, 3), dtype=torch.float64, device='cuda') if stats else None
+    out = vox.voxelize(dev(x), dev(y), dev(t), dev(p), dev(np.asarray(offs, dtype=np.int64)), B, (H, W), stats=st)
+    torch.cuda.synchronize()
+    return (out.cpu().numpy(), st.cpu().numpy()) if stats else out.cpu().numpy()
+
+
+def test_small_goldens_bit_exact(vox):
+    z = load_npz('voxel_small.npz')
+    for m in json.loads(bytes(z['meta']).decode()):
+        n = m['name']
+        x, y, t, p = (z[n + '.' + k] for k in 'xytp')
+        v = run(vox, x, y, t, p, [0, len(x)], m['B'], m['H'], m['W'])[0]
+        assert np.array_equal(v.view(np.uint32), z[n + '.voxel'].view(np.uint32)), n
+
+
+def test_large_goldens_hash(vox):
+    for c in load_json('voxel_large.json'):
+        x, y, t, p = gen_events(c['seed'], c['n'], c['W'], c['H'], **c['flags'])
+        v, st = run(vox, x, y, t, p, [0, c['n']], c['B'], c['H'], c['W'], stats=True)
+        assert sha(v[0]) == c['out_sha'], c['name']
+        assert int(st[0, 2]) == c['nnz']
+        assert abs(st[0, 0] - c['sum']) < 1e-6 * max(1.0, c['abs_sum'])
+        assert vox.dropped() == 0
+
+
+def test_many_windows_vs_oracle(vox):
+    from oracle import voxel as ov
+    rng = np.random.default_rng(3)
+    W, H, B = 346, 260, 5
+    sizes = [0, 1, 2, 15000, 0, 777, 64, 65, 20000, 3, 0]
+    xs, ys, ts, ps, offs = [], [], [], [], [0]
+    for i, n in enumerate(sizes):
+        x, y, t, p = gen_events(100 + i, n, W, H, burst=(i % 3 == 0), same_ts=(n == 3))
+        xs.append(x); ys.append(y); ts.append(t); ps.append(p); offs.append(offs[-1] + n)
+    x, y, t, p = map(np.concatenate, (xs, ys, ts, ps))
+    got, st = run(vox, x, y, t, p, offs, B, H, W, stats=True)
+    want = ov.voxelize_windows(x, y, t, p, offs, B, (H, W))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for w in range(len(sizes)):
+        assert int(st[w, 2]) == int((want[w] != 0).sum())
+        np.testing.assert_allclose(st[w, 0], want[w].astype(np.float64).sum(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(st[w, 1], (want[w].astype(np.float64) ** 2).sum(), rtol=1e-12, atol=1e-12)
+
+
+def test_raw_form_matches_dataset_path(vox):
+    """evr_voxelize_raw on memmap-typed arrays == dataset.py:222-228,53-57 followed by the tensorizer."""
+    from oracle import voxel as ov
+    from evreal_amd import synth
+    t, x, y, p = synth.poisson_events(5, 60000, 1.0e6, 346, 260)
+    xy = np.stack([x, y], axis=1)
+    offs = np.array([0, 15000, 30000, 30000, 60000], dtype=np.int64)
+    out = vox.voxelize_raw(dev(xy), dev(t), dev(p), dev(offs), 5, (260, 346))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for w in range(4):
+        a, b = int(offs[w]), int(offs[w + 1])
+        if b > a:
+            xs, ys, ts, ps = synth.window_events_f32(t, xy, p, a, b)
+            want = ov.events_to_voxel(xs, ys, ts, ps, 5, (260, 346))
+        else:
+            want = np.zeros((5, 260, 346), np.float32)
+        assert np.array_equal(got[w].view(np.uint32), want.view(np.uint32)), w
+
+
+def test_out_of_range_events_are_dropped_and_counted(vox):
+    x = np.array([1, 400, 3, -2], np.float32); y = np.array([1, 2, 300, 5], np.float32)
+    t = np.array([0, 1e-3, 2e-3, 3e-3], np.float32); p = np.ones(4, np.float32)
+    v = run(vox, x, y, t, p, [0, 4], 5, 260, 346)
+    assert vox.dropped() == 3
+    assert v[0, 0, 1, 1] == 1.0 and np.count_nonzero(v) == 1
+
+
+def test_full_size_properties(vox):
+    """BASELINE config size (346x260, 15k events, 5 bins), 256 windows: size-independent properties --
+    linearity in p, per-window sum == sum(p), empty windows stay zero, determinism."""
+    W, H, B, n, nw = 346, 260, 5, 15000, 256
+    t, x, y, p = __import__('evreal_amd.synth', fromlist=['x']).poisson_events(11, n * nw, 1.0e6, W, H)
+    offs = np.arange(nw + 1, dtype=np.int64) * n
+    xs = x.astype(np.float32); ys = y.astype(np.float32)
+    ts = np.concatenate([(t[a:a + n] - t[a]).astype(np.float32) for a in offs[:-1]])
+    ps = (p * 2.0 - 1.0).astype(np.float32)
+    a = run(vox, xs, ys, ts, ps, offs, B, H, W)
+    b = run(vox, xs, ys, ts, ps, offs, B, H, W)
+    assert np.array_equal(a, b)
+    c = run(vox, xs, ys, ts, 2.0 * ps, offs, B, H, W)
+    assert np.array_equal(c, 2.0 * a)            # exact: scaling by 2 commutes with fp32 rounding
+    sums = a.astype(np.float64).reshape(nw, -1).sum(1)
+    psum = ps.astype(np.float64).reshape(nw, n).sum(1)
+    np.testing.assert_allclose(sums, psum, atol=2e-2)
+    assert np.abs(a).max() <= 64
