@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reconstructed frames/s (+ Mevents/s voxelized) of the E2VID hot path at 346x260,
+5 bins, 15k events/window on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-seq S]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one frame for each of S independent synthetic sequences per GPU (sequences shard across GPUs,
+SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
+forward (fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM against the
+reference frame.  LPIPS is not built yet and is NOT part of the step (stated in config.workload).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_, H_, BINS, K_EVENTS = 346, 260, 5, 15000
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_inputs(rank, n_seq, n_steps, device):
+    """Step-major resident event arrays: window (step, seq) = 15k consecutive events of sequence `seq`."""
+    from evreal_amd import synth
+    k = K_EVENTS
+    xy = np.empty((n_steps, n_seq, k, 2), np.int16)
+    ts = np.empty((n_steps, n_seq, k), np.float64)
+    pol = np.empty((n_steps, n_seq, k), np.uint8)
+    refs = np.empty((n_seq, H_, W_), np.float32)
+    for s in range(n_seq):
+        seed = rank * n_seq + s
+        t, x, y, p = synth.poisson_events(seed, n_steps * k, 1.0e6, W_, H_)
+        xy[:, s, :, 0] = x.reshape(n_steps, k); xy[:, s, :, 1] = y.reshape(n_steps, k)
+        ts[:, s] = t.reshape(n_steps, k); pol[:, s] = p.reshape(n_steps, k)
+        refs[s] = synth.smooth_frames(seed, 1, W_, H_)[0, :, :, 0].astype(np.float32) / 255
+    offs = (np.arange(n_steps)[:, None] * (n_seq * k) + np.arange(n_seq + 1)[None, :] * k).astype(np.int64)
+    d = lambda a: torch.from_numpy(a).to(device)
+    return d(xy.reshape(-1, 2)), d(ts.reshape(-1)), d(pol.reshape(-1)), d(offs), d(refs), (xy, ts, pol, refs)
+
+
+def cpu_baseline(host_inputs, sd, kw, n_frames):
+    """Oracle ("port") timed on the host cores: C voxelizer (1 thread) + numpy normalization + torch-CPU
+    E2VID forward (all cores) + numpy percentile + MSE + scipy SSIM, batch 1 like the reference."""
+    import ctypes
+    from oracle import model as omod, prepost as op, metrics as omet
+    from evreal_amd import synth
+    xy, ts, pol, refs = host_inputs
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
+    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
+                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    crop = op.CropParams(W_, H_, kw['num_encoders'])
+    torch.set_num_threads(os.cpu_count())
+    offs = np.array([0, K_EVENTS], dtype=np.int64)
+    out = np.empty((1, BINS, H_, W_), np.float32)
+    f = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    times = {'voxel': 0.0, 'norm': 0.0, 'forward': 0.0, 'post': 0.0, 'metrics': 0.0}
+    n_warm = 2
+    for i in range(n_frames + n_warm):
+        w = i % xy.shape[0]
+        t0 = time.perf_counter()
+        xs, ys, tf, ps = synth.window_events_f32(ts[w, 0], xy[w, 0], pol[w, 0], 0, K_EVENTS)
+        lib.oracle_voxelize(f(xs), f(ys), f(tf), f(ps), f(offs), 1, BINS, H_, W_, f(out))
+        t1 = time.perf_counter()
+        v = op.normalize_event_tensor(out)
+        t2 = time.perf_counter()
+        with torch.no_grad():
+            img = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())[0, 0]
+        t3 = time.perf_counter()
+        img = op.post_process_normalization(img, 'robust')
+        t4 = time.perf_counter()
+        a, b = omet.clip01(img), omet.clip01(refs[0])
+        omet.mse(a, b); omet.ssim(a, b)
+        t5 = time.perf_counter()
+        if i >= n_warm:
+            for k, dt in zip(times, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                times[k] += dt
+    total = sum(times.values())
+    return {"value": round(n_frames / total, 3), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_frames} frames of one 346x260 sequence, batch 1 (C voxelizer 1 thread; torch-CPU forward "
+                      f"{torch.get_num_threads()} threads, torch {torch.__version__})",
+            "ms_per_frame": {k: round(1e3 * v / n_frames, 3) for k, v in times.items()},
+            "mevents_per_s_voxelizer": round(K_EVENTS * n_frames / times['voxel'] / 1e6, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--n-seq', type=int, default=16, help='independent sequences advanced together per GPU')
+    ap.add_argument('--cpu-frames', type=int, default=40, help='frames of the CPU baseline (0 disables)')
+    ap.add_argument('--profile-filter', default='rec', help='layers bracketed with HIP events (roofline block)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from evreal_amd import model, weights
+    from evreal_amd.pipeline import HotPath
+    from evreal_amd.dist import reduce_metric_sums
+
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
+    net = model.E2VIDRecurrent(kw)
+    net.load_state_dict(sd)
+    n_seq, K, Wm = args.n_seq, args.steps, args.warmup
+    xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, K + Wm, device)
+    hp = HotPath(net, BINS, (H_, W_), n_seq, event_tensor_normalization=True, post_process_norm='robust',
+                 metrics=('mse', 'ssim'), device=str(device))
+    scores = torch.zeros((K + Wm, n_seq, 2), dtype=torch.float64, device=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(Wm):
+        hp.step_raw(xy, ts, pol, offs[s], refs, scores[s])
+    net.profile(args.profile_filter)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(Wm, Wm + K):
+        hp.step_raw(xy, ts, pol, offs[s], refs, scores[s])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = net.profile_read()
+    net.profile(None)
+
+    # metric aggregation exactly as MetricTracker.update (eval.py:259-266): sum(mean*count), count
+    sc = scores[Wm:].cpu().numpy()                       # [K, n_seq, 2]
+    seq_mean = sc.mean(axis=0)                           # per sequence
+    sums = np.array([[seq_mean[:, 0].sum() * K, seq_mean[:, 1].sum() * K, n_seq * K]], dtype=np.float64)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = reduce_metric_sums(torch.from_numpy(sums).to(device), dist)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        frames = n_seq * K * world
+        fps = frames / elapsed
+        flops_step = net.flops_per_step()
+        lstm = [p for p in prof if '.rec' in p['name']]
+        rl_flops = sum(p['flops_per_launch'] * p['launches'] for p in lstm)
+        rl_ms = sum(p['ms'] for p in lstm)
+        rl_launches = sum(p['launches'] for p in lstm)
+        achieved = rl_flops / (rl_ms * 1e-3) / 1e12 if rl_ms > 0 else 0.0
+        pmc = None
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path)).get('conv_igemm_lstm_bytes_per_launch')
+        out = {
+            "metric": "reconstructed frames/sec + Mevents/sec voxelized, E2VID 346x260 B=5",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mevents_per_s": round(frames * K_EVENTS / elapsed / 1e6, 2),
+            "model_tflops": round(flops_step * K * world / elapsed / 1e12, 2),
+            "config": {"workload": "E2VID (synthetic weights, BN folded) on synthetic 346x260 Poisson events, 5 bins, "
+                                   "15k events/window (k_events), %d sequences per GPU advanced together; per frame: "
+                                   "voxelize(raw)+event-tensor norm+pad+forward+crop+robust norm+clip+MSE+SSIM "
+                                   "(LPIPS not built yet, not in the step)" % n_seq,
+                       "sequences_per_gpu": n_seq, "events_per_window": K_EVENTS, "sensor": [W_, H_], "bins": BINS,
+                       "gflop_per_frame": round(flops_step / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
+                       "scores": {"mse": tot[0, 0] / tot[0, 2], "ssim": tot[0, 1] / tot[0, 2], "count": int(tot[0, 2])}},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc,
+                         "kernel": "conv_igemm_kernel<32,WM,4,LSTM=true> (ConvLSTM gate convolutions)",
+                         "gflop_per_launch": round(rl_flops / max(rl_launches, 1) / 1e9, 3),
+                         "avg_launch_us": round(1e3 * rl_ms / max(rl_launches, 1), 2), "launches": rl_launches,
+                         "layers": {p['name']: {"us": round(1e3 * p['ms'] / p['launches'], 2),
+                                                "tflops": round(p['flops_per_launch'] * p['launches'] / (p['ms'] * 1e-3) / 1e12, 2)}
+                                    for p in prof}},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(host_inputs, sd, kw, args.cpu_frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -50,7 +50,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 #endif
 
-template <int KC, int WM, int NB>
+// LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
+// bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
+template <int KC, int WM, int NB, bool LSTM>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
@@ -194,8 +196,9 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             const int my = rem / a.wm, mx = rem - my * a.wm;
             opix = ((int64_t)img * a.hout + (my * a.os + ph.ofy)) * a.wout + (mx * a.os + ph.ofx);
         }
-        if (epi == EPI_LSTM) {
-            if constexpr (NB == 4) {
+        if constexpr (LSTM) {
+            static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
+            {
                 const int c = (n0 >> 2) + r;   // hidden channel: N tile of 128 = 4 gates x 32 channels
                 const float gi = sigmoidf_(acc[0][reg] + a.bias[n0 + r]);
                 const float gf = sigmoidf_(acc[1][reg] + a.bias[n0 + 32 + r]);
@@ -242,13 +245,13 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KC, int WM, int NB>
+template <int KC, int WM, int NB, bool LSTM>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
     const int total = mtiles * ntiles * a.nphases;
-    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB>), dim3(total), dim3(64 * WM), 0, stream, d_args);
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -258,7 +261,13 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
-#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_>(a, d_args, stream);
+    if (a.epi == EPI_LSTM) {
+        EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
+        if (wm == 4) return launch_t<32, 4, 4, true>(a, d_args, stream);
+        if (wm == 2) return launch_t<32, 2, 4, true>(a, d_args, stream);
+        return launch_t<32, 1, 4, true>(a, d_args, stream);
+    }
+#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false>(a, d_args, stream);
     EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
     EVR_CASE(32, 4, 2) EVR_CASE(32, 2, 2) EVR_CASE(32, 1, 2)
     EVR_CASE(32, 4, 1) EVR_CASE(32, 2, 1) EVR_CASE(32, 1, 1)

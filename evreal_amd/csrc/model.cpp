@@ -13,6 +13,7 @@
 // and kept RESIDENT IN DEVICE MEMORY, so a frame is a fixed chain of kernel launches with 8-byte
 // kernargs, no host arithmetic and no synchronisation.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <string>
@@ -88,6 +89,13 @@ struct evr_model {
     const float* pred_x[2] = {nullptr, nullptr};
     const float* pred_skip[2] = {nullptr, nullptr};
     int pred_c = 0;
+    // per-layer event timing (evr_model_profile_*)
+    bool prof_on = false;
+    std::string prof_filter;
+    struct ProfPair { int conv; hipEvent_t a, b; };
+    std::vector<ProfPair> prof_pending;
+    std::vector<double> prof_ms;
+    std::vector<int64_t> prof_n;
 
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
@@ -674,7 +682,14 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
         switch (s.kind) {
             case ST_CONV: {
                 const Conv& c = m->convs[s.conv];
+                const bool prof = m->prof_on && c.name.find(m->prof_filter) != std::string::npos;
+                evr_model::ProfPair pp{s.conv, nullptr, nullptr};
+                if (prof) {
+                    EVR_HIP(hipEventCreate(&pp.a)); EVR_HIP(hipEventCreate(&pp.b));
+                    EVR_HIP(hipEventRecord(pp.a, stream));
+                }
                 if ((rc = launch_conv_igemm(c.args[p], m->d_args + c.arg_slot + p, c.kc, c.wm, c.nb, stream))) return rc;
+                if (prof) { EVR_HIP(hipEventRecord(pp.b, stream)); m->prof_pending.push_back(pp); }
                 break;
             }
             case ST_UPSAMPLE:
@@ -709,3 +724,37 @@ extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst,
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }
+
+extern "C" int evr_model_profile_enable(evr_model* m, const char* filter) {
+    EVR_REQUIRE(m != nullptr, "evr_model_profile_enable: null model");
+    for (auto& pp : m->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
+    m->prof_pending.clear();
+    m->prof_ms.assign(m->convs.size(), 0.0);
+    m->prof_n.assign(m->convs.size(), 0);
+    m->prof_on = filter != nullptr;
+    m->prof_filter = filter ? filter : "";
+    return EVR_OK;
+}
+
+extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names, double* ms, double* flops_per_launch,
+                                      int64_t* launches, int* n_layers, evr_stream_t stream) {
+    EVR_REQUIRE(m && names && ms && flops_per_launch && launches && n_layers, "evr_model_profile_read: null argument");
+    EVR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (m->prof_ms.size() != m->convs.size()) { m->prof_ms.assign(m->convs.size(), 0.0); m->prof_n.assign(m->convs.size(), 0); }
+    for (auto& pp : m->prof_pending) {
+        float t = 0.f;
+        EVR_HIP(hipEventElapsedTime(&t, pp.a, pp.b));
+        m->prof_ms[pp.conv] += t; m->prof_n[pp.conv] += 1;
+        (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b);
+    }
+    m->prof_pending.clear();
+    int k = 0;
+    for (size_t i = 0; i < m->convs.size() && k < max_layers; ++i) {
+        if (m->prof_n[i] == 0) continue;
+        snprintf(names + (size_t)k * 64, 64, "%s", m->convs[i].name.c_str());
+        ms[k] = m->prof_ms[i]; flops_per_launch[k] = m->convs[i].flops; launches[k] = m->prof_n[i];
+        ++k;
+    }
+    *n_layers = k;
+    return EVR_OK;
+}

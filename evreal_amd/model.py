@@ -123,6 +123,25 @@ class _HipModel:
                                                   ctypes.byref(n), _lib.stream_ptr()), 'evr_model_read_tensor')
         return buf
 
+    def profile(self, filter=''):
+        """Bracket conv launches whose layer name contains `filter` with HIP events (None: off)."""
+        _lib.check(self.lib.evr_model_profile_enable(self.handle, None if filter is None else filter.encode()),
+                   'evr_model_profile_enable')
+
+    def profile_read(self):
+        """-> list of dict(name, ms, flops_per_launch, launches) since profile() was enabled."""
+        mx = 128
+        names = ctypes.create_string_buffer(mx * 64)
+        ms = (ctypes.c_double * mx)(); fl = (ctypes.c_double * mx)()
+        ln = (ctypes.c_int64 * mx)(); n = ctypes.c_int(0)
+        _lib.check(self.lib.evr_model_profile_read(self.handle, mx, names, ms, fl, ln, ctypes.byref(n),
+                                                   _lib.stream_ptr()), 'evr_model_profile_read')
+        out = []
+        for i in range(n.value):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b'\0', 1)[0].decode()
+            out.append(dict(name=nm, ms=ms[i], flops_per_launch=fl[i], launches=ln[i]))
+        return out
+
     def flops_per_step(self):
         return float(self.lib.evr_model_flops_per_step(self.handle))
 

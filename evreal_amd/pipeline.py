@@ -1,0 +1,52 @@
+"""The per-frame hot loop of eval.py:203-238 for a batch of independent sequences, fully on the GPU:
+
+    events window -> voxel grid (+stats) -> [normalize] -> pad -> network -> crop -> [robust norm]
+                  -> clip -> MSE / SSIM
+
+All launches go to one HIP stream through the C ABI; nothing synchronises with the host inside a
+step (the reference forces a cuda.synchronize() and a D2H copy per frame, eval.py:227-233).
+"""
+import torch
+
+from . import lib as _lib
+from .prepost import Metrics, post_process_normalization
+from .voxel import Voxelizer
+
+
+class HotPath:
+    def __init__(self, model, num_bins, sensor_size, n_seq, event_tensor_normalization=True,
+                 post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0'):
+        _lib.require_gpu()
+        self.model, self.B, (self.H, self.W), self.n = model, num_bins, sensor_size, n_seq
+        self.norm_in, self.post = event_tensor_normalization, post_process_norm
+        self.want_mse, self.want_ssim = 'mse' in metrics, 'ssim' in metrics
+        self.dev = torch.device(device)
+        self.vox = Voxelizer(device)
+        self.met = Metrics()
+        self.grid = torch.empty((n_seq, num_bins, self.H, self.W), dtype=torch.float32, device=self.dev)
+        self.stats = torch.zeros((n_seq, 3), dtype=torch.float64, device=self.dev)
+        self.img = torch.empty((n_seq, 1, self.H, self.W), dtype=torch.float32, device=self.dev)
+        model.reset_states()
+
+    def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
+        """One frame for every sequence.  xy/ts/pol: resident raw event arrays; win_offsets: int64
+        [n_seq+1] device tensor delimiting this step's n_seq windows.  ref: [n_seq,H,W] reference
+        frames (already /255) or None.  Returns (img [n_seq,1,H,W], scores [n_seq,2] or None)."""
+        self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
+        return self._rest(ref, scores_out)
+
+    def step(self, x, y, t, p, win_offsets, ref=None, scores_out=None):
+        self.vox.voxelize(x, y, t, p, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
+        return self._rest(ref, scores_out)
+
+    def _rest(self, ref, scores_out):
+        self.model(self.grid, stats=self.stats if self.norm_in else None, out=self.img)
+        im = self.img.view(self.n, self.H, self.W)
+        if self.post != 'none':
+            post_process_normalization(im, self.post)
+        scores = None
+        if ref is not None and (self.want_mse or self.want_ssim):
+            scores = self.met(im, ref, mse=self.want_mse, ssim=self.want_ssim, clip=True)
+            if scores_out is not None:
+                scores_out.copy_(scores)
+        return self.img, scores

@@ -142,6 +142,13 @@ int evr_model_read_tensor(evr_model* m, const char* name, float* dst, int64_t ds
                           int64_t* n_out, evr_stream_t stream);
 /* Direct-convolution FLOPs (2*MAC) of one evr_model_step at the current shape. */
 double evr_model_flops_per_step(const evr_model* m);
+/* Per-layer timing for the roofline block of bench.py.  While enabled, evr_model_step brackets every
+ * convolution launch whose layer name contains `filter` ("" = all layers) with HIP events on the launch
+ * stream; filter == NULL disables.  evr_model_profile_read synchronises the stream, then returns per
+ * layer: name (64 bytes each), summed elapsed milliseconds, direct-conv FLOPs per launch, launch count. */
+int evr_model_profile_enable(evr_model* m, const char* filter);
+int evr_model_profile_read(evr_model* m, int max_layers, char* names, double* ms, double* flops_per_launch,
+                           int64_t* launches, int* n_layers, evr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Post-processing.  Replaces post_process_normalization (eval.py:380-395) + normalize

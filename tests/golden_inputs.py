@@ -10,6 +10,9 @@ def sha(a):
 
 
 def gen_events(seed, n, W, H, burst=False, same_ts=False, weights_p=False):
+    if n == 0:
+        z = np.zeros(0, np.float32)
+        return z, z.copy(), z.copy(), z.copy()
     rng = np.random.default_rng(seed)
     t64 = np.sort(rng.uniform(0, n * 1e-6 + 1e-3, n))
     if same_ts:

@@ -36,9 +36,9 @@ def _fire(tag, cls_name):
         img = m(torch.from_numpy(vox[f:f + 1]).cuda())['image'].cpu().numpy()
         np.testing.assert_allclose(img, z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')
     # states live on the padded grid; the golden stores a ::3 subsample of the reference's padded state
-    hp = (H + 15) // 16 * 16 if cls_name == 'FireNet_legacy' else H
+    hp, wp = ((H + 15) // 16 * 16, (W + 15) // 16 * 16) if cls_name == 'FireNet_legacy' else (H, W)
     for i in range(2):
-        h = m.read_tensor(f'h{i}').cpu().numpy().reshape(1, 16, hp, W)
+        h = m.read_tensor(f'h{i}').cpu().numpy().reshape(1, 16, hp, wp)
         np.testing.assert_allclose(h[:, :, ::3, ::3], z[f'state{i}_sub'], rtol=1e-4, atol=1e-5)
 
 
