@@ -1,0 +1,72 @@
+"""N>1 path on CPU: world-size-2 gloo process group reproduces MetricTracker's weighted average
+(eval.py:259-266) from per-rank partial sums, and the sequence assignment is a deterministic partition."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from evreal_amd.dist import assign_sequences, reduce_metric_sums
+from oracle.metrics import MetricTracker
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+SEQS = [  # (name, n_evaluated, {metric: mean score}) -- includes an un-evaluated sequence and a -1 mean
+    ('a', 10, {'mse': 0.05, 'ssim': 0.61}), ('b', 30, {'mse': 0.10, 'ssim': 0.40}),
+    ('c', 0, {'mse': -1, 'ssim': -1}), ('d', 7, {'mse': 0.31, 'ssim': 0.12}), ('e', 19, {'mse': 0.02, 'ssim': 0.88}),
+]
+COSTS = [5.0, 9.0, 1.0, 3.0, 7.0]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = assign_sequences(COSTS, world)[rank]
+    sums = torch.zeros((1, 3), dtype=torch.float64)
+    for i in mine:
+        _, n, sc = SEQS[i]
+        if n == 0:
+            continue                               # eval.py:260-261
+        sums[0, 0] += sc['mse'] * n; sums[0, 1] += sc['ssim'] * n; sums[0, 2] += n
+    tot = reduce_metric_sums(sums, dist)
+    q.put((rank, mine, tot.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_matches_metric_tracker():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    mt = MetricTracker()
+    for _, n, sc in SEQS:
+        for k, v in sc.items():
+            mt.update(k, v, n)
+    seen = sorted(i for _, mine, _ in res for i in mine)
+    assert seen == list(range(len(SEQS)))          # a partition: every sequence on exactly one rank
+    for _, _, tot in res:                           # every rank holds the global totals
+        t = np.array(tot)
+        assert int(t[0, 2]) == mt.count('mse') == 66
+        assert abs(t[0, 0] / t[0, 2] - mt.average('mse')) < 1e-15
+        assert abs(t[0, 1] / t[0, 2] - mt.average('ssim')) < 1e-15
+
+
+def test_assign_sequences_lpt():
+    plan = assign_sequences([5, 9, 1, 3, 7], 2)
+    assert sorted(sum(plan, [])) == [0, 1, 2, 3, 4]
+    loads = [sum([5, 9, 1, 3, 7][i] for i in p) for p in plan]
+    assert abs(loads[0] - loads[1]) <= 3
+    assert assign_sequences([5, 9, 1, 3, 7], 2) == plan             # deterministic
+    assert assign_sequences([1.0] * 3, 8)[3:] == [[]] * 5           # more ranks than sequences
+    assert reduce_metric_sums(torch.ones((1, 3), dtype=torch.float64)).tolist() == [[1.0, 1.0, 1.0]]
