@@ -45,12 +45,17 @@ struct ConvArgs {
     float* state;             // EPI_LSTM: cell state (in place); EPI_GRU_*: hidden state h
     float* aux0;              // EPI_GRU_ZR: z out; EPI_GRU_OUT: z in
     int hidden;               // EPI_LSTM / GRU: number of hidden channels C
+    // fused prediction layer (model/unet.py:136-138): when pred_w != null and the GEMM has ONE N tile, the
+    // epilogue reduces (value [+ post_add]) . pred_w over the channels, adds pred_b, applies the final
+    // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
+    const float* pred_w; float pred_b; int pred_sigmoid;
+    int crop_h, crop_w, crop_y0, crop_x0;
 };
 
 // kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
 // kernel reads it with scalar loads; it is uploaded once per shape, not per launch).
-int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream);
+int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img = nullptr);
 // picks (wm, nb) for the shape: fills the 256 CUs when M is small
 void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
 template <int KC, int WM, int NB, bool LSTM>
-__global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap) {
+__global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
     constexpr int SP = KC / 4;                 // 16-B slots per row
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             }
             continue;
         }
+        float pred_part = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + nb * 32 + r;
@@ -237,8 +238,24 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                 const int64_t o = opix * a.cout_total + n;
                 if (epi == EPI_RESIDUAL_RELU) v += a.residual[o];
                 if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
+                if (a.pred_w && a.out) a.out[o] = v;          // debug copy of the layer's own output
                 if (a.post_add) v += a.post_add[o];   // skip_sum fused into the producer (model_util.py:4-5)
-                a.out[o] = v;
+                if (!a.pred_w && a.out) a.out[o] = v;
+                if (a.pred_w) pred_part = fmaf(v, a.pred_w[n], pred_part);
+            }
+        }
+        if (a.pred_w) {   // fused 1x1 prediction conv: reduce over the 32 channel lanes of this half-wave
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) pred_part += __shfl_xor(pred_part, o, 64);
+            if (r == 0) {
+                const int hwo = a.hout * a.wout;
+                const int im = (int)(opix / hwo), rem = (int)(opix - (int64_t)im * hwo);
+                const int y = rem / a.wout - a.crop_y0, x = rem % a.wout - a.crop_x0;
+                if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w) {
+                    float sres = pred_part + a.pred_b;
+                    if (a.pred_sigmoid) sres = sigmoidf_(sres);
+                    img_out[((int64_t)im * a.crop_h + y) * a.crop_w + x] = sres;
+                }
             }
         }
     }
@@ -246,28 +263,29 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 }
 
 template <int KC, int WM, int NB, bool LSTM>
-static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream) {
+static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
     const int total = mtiles * ntiles * a.nphases;
-    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args);
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
-int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream) {
+int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
+    EVR_REQUIRE(!a.pred_w || (a.cout == 32 * nb && img), "conv_igemm: fused prediction needs a single N tile and an image pointer");
     EVR_REQUIRE(a.cout % (32 * nb) == 0, "conv_igemm: cout %d not a multiple of %d", a.cout, 32 * nb);
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
-        if (wm == 4) return launch_t<32, 4, 4, true>(a, d_args, stream);
-        if (wm == 2) return launch_t<32, 2, 4, true>(a, d_args, stream);
-        return launch_t<32, 1, 4, true>(a, d_args, stream);
+        if (wm == 4) return launch_t<32, 4, 4, true>(a, d_args, stream, img);
+        if (wm == 2) return launch_t<32, 2, 4, true>(a, d_args, stream, img);
+        return launch_t<32, 1, 4, true>(a, d_args, stream, img);
     }
-#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false>(a, d_args, stream);
+#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false>(a, d_args, stream, img);
     EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
     EVR_CASE(32, 4, 2) EVR_CASE(32, 2, 2) EVR_CASE(32, 1, 2)
     EVR_CASE(32, 4, 1) EVR_CASE(32, 2, 1) EVR_CASE(32, 1, 1)
@@ -368,30 +386,37 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // 8 lanes per pixel, one float4 (4 channels) each per 32-channel group: a wave reads 8 pixels x 128 B
+    // contiguous lines (the thread-per-pixel form over-fetched 3.7x, profiles/r01_pmc_fetch_size_nseq16.md)
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = gid >> 3;
+    const int sub = (int)(gid & 7);
     const int64_t total = (int64_t)a.n * a.H * a.W;
-    if (i >= total) return;
-    const int n = (int)(i / ((int64_t)a.H * a.W));
-    const int rem = (int)(i - (int64_t)n * a.H * a.W);
-    const int y = rem / a.W, x = rem - y * a.W;
-    const int64_t pix = ((int64_t)n * a.hp + (y + a.iy0)) * a.wp + (x + a.ix0);
-    const float4* px = (const float4*)(a.x + pix * a.c);
-    const float4* ps = a.skip ? (const float4*)(a.skip + pix * a.c) : nullptr;
+    const bool live = i < total;
     float acc = 0.f;
-    for (int c4 = 0; c4 < a.c / 4; ++c4) {
-        float4 v = px[c4];
-        if (ps) { const float4 u = ps[c4]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-        const float* w = a.wgt + c4 * 4;
-        acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
+    if (live) {
+        const int n = (int)(i / ((int64_t)a.H * a.W));
+        const int rem = (int)(i - (int64_t)n * a.H * a.W);
+        const int y = rem / a.W, x = rem - y * a.W;
+        const int64_t pix = ((int64_t)n * a.hp + (y + a.iy0)) * a.wp + (x + a.ix0);
+        for (int c4 = sub; c4 < a.c / 4; c4 += 8) {
+            float4 v = *(const float4*)(a.x + pix * a.c + c4 * 4);
+            if (a.skip) { const float4 u = *(const float4*)(a.skip + pix * a.c + c4 * 4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            const float* w = a.wgt + c4 * 4;
+            acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
+        }
     }
-    acc += a.bias;
-    if (a.sigmoid) acc = sigmoidf_(acc);
-    a.img[i] = acc;
+    acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
+    if (live && sub == 0) {
+        acc += a.bias;
+        if (a.sigmoid) acc = sigmoidf_(acc);
+        a.img[i] = acc;
+    }
 }
 
 int launch_pred(const PredArgs& a, hipStream_t stream) {
     EVR_REQUIRE(a.c % 4 == 0, "pred: channels %d not a multiple of 4", a.c);
-    const int64_t total = (int64_t)a.n * a.H * a.W;
+    const int64_t total = (int64_t)a.n * a.H * a.W * 8;
     hipLaunchKernelGGL(pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     EVR_LAUNCH_CHECK();
     return EVR_OK;

@@ -89,6 +89,7 @@ struct evr_model {
     const float* pred_x[2] = {nullptr, nullptr};
     const float* pred_skip[2] = {nullptr, nullptr};
     int pred_c = 0;
+    int pred_fused_conv = -1;   // conv whose epilogue carries the prediction layer (-1: standalone pred kernel)
     // per-layer event timing (evr_model_profile_*)
     bool prof_on = false;
     std::string prof_filter;
@@ -433,6 +434,24 @@ void push_conv(evr_model* m, int ci) { Step s; s.kind = ST_CONV; s.conv = ci; m-
 
 void name2(evr_model* m, const std::string& name, const DevTensor& t0, const DevTensor& t1) { m->named[0][name] = t0; m->named[1][name] = t1; }
 
+// Fold the 1x1 prediction conv (+ skip-sum with `skip`, final activation, centre crop) into conv `ci`'s epilogue
+// when its GEMM has a single N tile; otherwise the standalone pred kernel runs.  reserved[0] bit 0 (debug) keeps
+// the conv's own NHWC output for evr_model_read_tensor.
+void try_fuse_pred(evr_model* m, int ci, const float* skip) {
+    Conv& c = m->convs[ci];
+    m->pred_fused_conv = -1;
+    if (c.n_gemm != 32 * c.nb || c.n_gemm > 128) return;
+    if (c.epi != EPI_BIAS_RELU && c.epi != EPI_RESIDUAL_RELU && c.epi != EPI_BIAS) return;
+    for (int p = 0; p < 2; ++p) {
+        ConvArgs& a = c.args[p];
+        a.post_add = skip;
+        a.pred_w = m->d_pred_w; a.pred_b = m->pred_b; a.pred_sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
+        a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
+        if (!(m->desc.reserved[0] & 1)) a.out = nullptr;
+    }
+    m->pred_fused_conv = ci;
+}
+
 int plan_unet(evr_model* m, hipStream_t stream) {
     const evr_model_desc& d = m->desc;
     const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
@@ -555,6 +574,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     m->pred_x[0] = x[0]; m->pred_x[1] = x[1];
     m->pred_skip[0] = m->pred_skip[1] = head.p;
     m->pred_c = base;
+    try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p);
     return EVR_OK;
 }
 
@@ -599,6 +619,7 @@ int plan_firenet(evr_model* m, hipStream_t stream) {
     m->pred_x[0] = m->pred_x[1] = x;
     m->pred_skip[0] = m->pred_skip[1] = nullptr;
     m->pred_c = C;
+    try_fuse_pred(m, conv_index(m, "r2.conv2"), nullptr);
     return EVR_OK;
 }
 
@@ -688,7 +709,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                     EVR_HIP(hipEventCreate(&pp.a)); EVR_HIP(hipEventCreate(&pp.b));
                     EVR_HIP(hipEventRecord(pp.a, stream));
                 }
-                if ((rc = launch_conv_igemm(c.args[p], m->d_args + c.arg_slot + p, c.kc, c.wm, c.nb, stream))) return rc;
+                if ((rc = launch_conv_igemm(c.args[p], m->d_args + c.arg_slot + p, c.kc, c.wm, c.nb, stream, s.conv == m->pred_fused_conv ? img : nullptr))) return rc;
                 if (prof) { EVR_HIP(hipEventRecord(pp.b, stream)); m->prof_pending.push_back(pp); }
                 break;
             }
@@ -705,7 +726,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
     pa.x = m->pred_x[p]; pa.skip = m->pred_skip[p]; pa.n = m->n_seq; pa.hp = m->hp; pa.wp = m->wp; pa.c = m->pred_c;
     pa.wgt = m->d_pred_w; pa.bias = m->pred_b; pa.sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
     pa.H = m->H; pa.W = m->W; pa.iy0 = m->iy0; pa.ix0 = m->ix0; pa.img = img;
-    if ((rc = launch_pred(pa, stream))) return rc;
+    if (m->pred_fused_conv < 0 && (rc = launch_pred(pa, stream))) return rc;
     m->frame++;
     return EVR_OK;
 }

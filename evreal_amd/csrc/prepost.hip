@@ -86,47 +86,108 @@ __device__ __forceinline__ float key2f(unsigned k) {
 }
 
 constexpr int PCT_THREADS = 1024;
+constexpr int PCT_MAXR = 96;   // keys per thread kept in registers (covers 346x260 = 89,960 pixels)
 
-// k-th smallest (0-based) of v[0..n) by MSB-first 8-bit radix select; all threads of the block call it.
-__device__ unsigned radix_select(const float* __restrict__ v, int n, int k, unsigned* hist, unsigned* bcast) {
+struct PctShared {
+    unsigned hist[4][256];    // one histogram per radix level, memoised across the rank selects
+    unsigned level_prefix[4]; // prefix each memoised histogram was counted under
+    unsigned level_valid[4];
+    unsigned bcast[2];
+    float lohi[2];
+};
+
+// wave-aggregated histogram add: in the first radix level almost every key shares its top byte (sign +
+// exponent), and 64 LDS atomics on one address serialise; a few leader rounds collapse them into one add each.
+__device__ __forceinline__ void hist_add(unsigned* hist, unsigned digit, bool active, bool aggregate) {
+    if (aggregate) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long rem = __ballot(active);
+        for (int it = 0; it < 4 && rem; ++it) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
+            const unsigned long long m = __ballot(active && digit == d);
+            if (lane == leader) atomicAdd(&hist[d], (unsigned)__popcll(m));
+            if (digit == d) active = false;
+            rem &= ~m;
+        }
+    }
+    if (active) atomicAdd(&hist[digit], 1u);
+}
+
+// k-th smallest key (0-based) by MSB-first 8-bit radix select over keys held in registers (REG) or re-read
+// from global memory; histograms are memoised per level so ranks that share a prefix share the counting pass.
+template <bool REG>
+__device__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR], int cnt, const float* __restrict__ v, int n, int k,
+                                 PctShared& sh) {
     unsigned prefix = 0, pmask = 0;
     int kk = k;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    for (int level = 0; level < 4; ++level) {
+        const int shift = 24 - 8 * level;
+        unsigned* hist = sh.hist[level];
+        const bool reuse = sh.level_valid[level] && sh.level_prefix[level] == prefix;   // block-uniform (LDS)
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += PCT_THREADS) {
-            const unsigned key = f2key(v[i]);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        if (!reuse) {
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            if (REG) {
+#pragma unroll 8
+                for (int j = 0; j < PCT_MAXR; ++j) {
+                    const bool in = j < cnt;
+                    const unsigned key = keys[j];
+                    hist_add(hist, (key >> shift) & 255u, in && (key & pmask) == prefix, level == 0);
+                }
+            } else {
+                for (int i0 = 0; i0 < n; i0 += PCT_THREADS) {
+                    const int i = i0 + threadIdx.x;
+                    const unsigned key = (i < n) ? f2key(v[i]) : 0u;
+                    hist_add(hist, (key >> shift) & 255u, i < n && (key & pmask) == prefix, level == 0);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { sh.level_prefix[level] = prefix; sh.level_valid[level] = 1; }
+            // deeper memoised levels were counted under another prefix chain
+            if (threadIdx.x == 0) for (int l = level + 1; l < 4; ++l) sh.level_valid[l] = 0;
         }
-        __syncthreads();
         if (threadIdx.x == 0) {
             unsigned acc = 0; int d = 0;
-            for (; d < 256; ++d) {
+            for (; d < 255; ++d) {
                 const unsigned c = hist[d];
                 if ((unsigned)kk < acc + c) break;
                 acc += c;
             }
-            bcast[0] = (unsigned)d; bcast[1] = acc;
+            sh.bcast[0] = (unsigned)d; sh.bcast[1] = acc;
         }
         __syncthreads();
-        prefix |= bcast[0] << shift;
+        prefix |= sh.bcast[0] << shift;
         pmask |= 255u << shift;
-        kk -= (int)bcast[1];
-        __syncthreads();
+        kk -= (int)sh.bcast[1];
     }
+    __syncthreads();
     return prefix;
 }
 
+template <bool REG>
 __global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ img, int n, float q_lo, float q_hi,
                                                            int do_exp) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned bcast[2];
-    __shared__ float lohi[2];
+    __shared__ PctShared sh;
     float* v = img + (int64_t)blockIdx.x * n;
-    if (do_exp) {   // 'exprobust' (eval.py:391-393)
+    if (threadIdx.x < 4) sh.level_valid[threadIdx.x] = 0;
+    unsigned keys[PCT_MAXR];
+    int cnt = 0;
+    if (REG) {
+        cnt = (n - (int)threadIdx.x + PCT_THREADS - 1) / PCT_THREADS;
+        if (cnt < 0) cnt = 0;
+#pragma unroll 8
+        for (int j = 0; j < PCT_MAXR; ++j) {
+            const int i = threadIdx.x + j * PCT_THREADS;
+            float x = (i < n) ? v[i] : 0.f;
+            if (do_exp) x = expf(x);          // 'exprobust' (eval.py:391-393)
+            keys[j] = f2key(x);
+        }
+    } else if (do_exp) {
         for (int i = threadIdx.x; i < n; i += PCT_THREADS) v[i] = expf(v[i]);
-        __syncthreads();
     }
+    __syncthreads();
     float res[2];
     for (int which = 0; which < 2; ++which) {
         // numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear'
@@ -137,20 +198,25 @@ __global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ im
         if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma = vi - (-1.0f); }
         else if (vi < 0.f) { prev = next = 0; gamma = vi - 0.0f; }
         else gamma = vi - (float)prev;
-        const float a = key2f(radix_select(v, n, prev, hist, bcast));
-        const float b = (next == prev) ? a : key2f(radix_select(v, n, next, hist, bcast));
+        const float a = key2f(radix_select<REG>(keys, cnt, v, n, prev, sh));
+        const float b = (next == prev) ? a : key2f(radix_select<REG>(keys, cnt, v, n, next, sh));
         // numpy _lerp
         const float diff = b - a;
         float r = a + diff * gamma;
         if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
         res[which] = r;
     }
-    if (threadIdx.x == 0) { lohi[0] = res[0]; lohi[1] = res[1]; }
+    if (threadIdx.x == 0) { sh.lohi[0] = res[0]; sh.lohi[1] = res[1]; }
     __syncthreads();
-    const float lo = lohi[0], range = lohi[1] - lohi[0];
-    for (int i = threadIdx.x; i < n; i += PCT_THREADS) {
-        const float d = v[i] - lo;
-        v[i] = d / range;
+    const float lo = sh.lohi[0], range = sh.lohi[1] - sh.lohi[0];
+    if (REG) {
+#pragma unroll 8
+        for (int j = 0; j < PCT_MAXR; ++j) {
+            const int i = threadIdx.x + j * PCT_THREADS;
+            if (i < n) { const float d = key2f(keys[j]) - lo; v[i] = d / range; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += PCT_THREADS) { const float d = v[i] - lo; v[i] = d / range; }
     }
 }
 
@@ -196,7 +262,10 @@ extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q
     EVR_REQUIRE((int64_t)H * W < (1LL << 30), "evr_percentile_normalize: image too large");
     if (n == 0) return EVR_OK;
     EVR_REQUIRE(img != nullptr, "evr_percentile_normalize: null image");
-    hipLaunchKernelGGL(pct_kernel, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
+    if ((int64_t)H * W <= (int64_t)PCT_THREADS * PCT_MAXR)
+        hipLaunchKernelGGL(pct_kernel<true>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
+    else
+        hipLaunchKernelGGL(pct_kernel<false>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

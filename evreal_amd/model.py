@@ -35,6 +35,7 @@ class _HipModel:
         _lib.require_gpu()
         self.lib = _lib.load()
         self.handle = None
+        self.debug_taps = False      # keep every intermediate readable (read_tensor) -- parity tests only
         self.device = torch.device('cuda', torch.cuda.current_device())
         self._shape = None
         self._needs_reset = True
@@ -58,6 +59,7 @@ class _HipModel:
         self.destroy()
         h = ctypes.c_void_p()
         desc = self._desc()
+        desc.reserved[0] = 1 if self.debug_taps else 0
         _lib.check(self.lib.evr_model_create(ctypes.byref(desc), tensors, len(sd), ctypes.byref(h)),
                    'evr_model_create')
         self.handle = h

@@ -57,6 +57,7 @@ def _e2vid(tag, n_seq=1):
     sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']))
     assert weights.state_dict_digest(sd) == str(z['weights_sha'])
     m = model.E2VIDRecurrent(kw)
+    m.debug_taps = (n_seq == 1)      # taps of the last decoder need its (otherwise never stored) output
     m.load_state_dict(sd)
     seed, F, B, H, W = [int(v) for v in z['voxel_args']]
     vox = synth.sparse_voxels(seed, F, B, H, W)
