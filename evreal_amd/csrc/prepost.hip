@@ -86,13 +86,14 @@ __device__ __forceinline__ float key2f(unsigned k) {
 }
 
 constexpr int PCT_THREADS = 1024;
-constexpr int PCT_MAXR = 96;   // keys per thread kept in registers (covers 346x260 = 89,960 pixels)
+constexpr int PCT_MAXR = 1;    // (register-resident keys spill under hipcc's full unroll; keys are re-read from L2 instead)
 
 struct PctShared {
     unsigned hist[4][256];    // one histogram per radix level, memoised across the rank selects
     unsigned level_prefix[4]; // prefix each memoised histogram was counted under
     unsigned level_valid[4];
     unsigned bcast[2];
+    unsigned wsum[4];
     float lohi[2];
 };
 
@@ -117,7 +118,7 @@ __device__ __forceinline__ void hist_add(unsigned* hist, unsigned digit, bool ac
 // k-th smallest key (0-based) by MSB-first 8-bit radix select over keys held in registers (REG) or re-read
 // from global memory; histograms are memoised per level so ranks that share a prefix share the counting pass.
 template <bool REG>
-__device__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR], int cnt, const float* __restrict__ v, int n, int k,
+__device__ __forceinline__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR], int cnt, const float* __restrict__ v, int n, int k,
                                  PctShared& sh) {
     unsigned prefix = 0, pmask = 0;
     int kk = k;
@@ -130,17 +131,27 @@ __device__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR], int cnt, cons
             if (threadIdx.x < 256) hist[threadIdx.x] = 0;
             __syncthreads();
             if (REG) {
-#pragma unroll 8
+#pragma unroll
                 for (int j = 0; j < PCT_MAXR; ++j) {
                     const bool in = j < cnt;
                     const unsigned key = keys[j];
                     hist_add(hist, (key >> shift) & 255u, in && (key & pmask) == prefix, level == 0);
                 }
             } else {
-                for (int i0 = 0; i0 < n; i0 += PCT_THREADS) {
-                    const int i = i0 + threadIdx.x;
-                    const unsigned key = (i < n) ? f2key(v[i]) : 0u;
-                    hist_add(hist, (key >> shift) & 255u, i < n && (key & pmask) == prefix, level == 0);
+                // 8 independent loads in flight per thread: the pass is L2-latency-bound, not bandwidth-bound
+                for (int i0 = 0; i0 < n; i0 += PCT_THREADS * 8) {
+                    float x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * PCT_THREADS + threadIdx.x;
+                        x[u] = (i < n) ? v[i] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * PCT_THREADS + threadIdx.x;
+                        const unsigned key = f2key(x[u]);
+                        hist_add(hist, (key >> shift) & 255u, i < n && (key & pmask) == prefix, level == 0);
+                    }
                 }
             }
             __syncthreads();
@@ -148,14 +159,26 @@ __device__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR], int cnt, cons
             // deeper memoised levels were counted under another prefix chain
             if (threadIdx.x == 0) for (int l = level + 1; l < 4; ++l) sh.level_valid[l] = 0;
         }
-        if (threadIdx.x == 0) {
-            unsigned acc = 0; int d = 0;
-            for (; d < 255; ++d) {
-                const unsigned c = hist[d];
-                if ((unsigned)kk < acc + c) break;
-                acc += c;
+        // parallel search of the bin holding rank kk: 256 threads scan the histogram (a serial walk by one
+        // thread cost ~10 us of dependent LDS reads per level)
+        unsigned c = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            c = hist[threadIdx.x];
+            incl = c;
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
             }
-            sh.bcast[0] = (unsigned)d; sh.bcast[1] = acc;
+            if (lane == 63) sh.wsum[threadIdx.x >> 6] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            unsigned base = 0;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += sh.wsum[w];
+            const unsigned excl = base + incl - c;
+            if (c > 0 && (unsigned)kk >= excl && (unsigned)kk < excl + c) { sh.bcast[0] = threadIdx.x; sh.bcast[1] = excl; }
         }
         __syncthreads();
         prefix |= sh.bcast[0] << shift;
@@ -177,7 +200,7 @@ __global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ im
     if (REG) {
         cnt = (n - (int)threadIdx.x + PCT_THREADS - 1) / PCT_THREADS;
         if (cnt < 0) cnt = 0;
-#pragma unroll 8
+#pragma unroll
         for (int j = 0; j < PCT_MAXR; ++j) {
             const int i = threadIdx.x + j * PCT_THREADS;
             float x = (i < n) ? v[i] : 0.f;
@@ -188,29 +211,39 @@ __global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ im
         for (int i = threadIdx.x; i < n; i += PCT_THREADS) v[i] = expf(v[i]);
     }
     __syncthreads();
-    float res[2];
+    // numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear' (_get_indexes/_get_gamma)
+    int rank[4]; float gamma[2];
+#pragma unroll
     for (int which = 0; which < 2; ++which) {
-        // numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear'
         const float q = (which ? q_hi : q_lo) / 100.0f;
         const float vi = (float)(n - 1) * q;
         int prev = (int)floorf(vi), next = prev + 1;
-        float gamma;
-        if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma = vi - (-1.0f); }
-        else if (vi < 0.f) { prev = next = 0; gamma = vi - 0.0f; }
-        else gamma = vi - (float)prev;
-        const float a = key2f(radix_select<REG>(keys, cnt, v, n, prev, sh));
-        const float b = (next == prev) ? a : key2f(radix_select<REG>(keys, cnt, v, n, next, sh));
-        // numpy _lerp
+        if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma[which] = vi - (-1.0f); }
+        else if (vi < 0.f) { prev = next = 0; gamma[which] = vi - 0.0f; }
+        else gamma[which] = vi - (float)prev;
+        rank[2 * which] = prev; rank[2 * which + 1] = next;
+    }
+    float val[4];
+#pragma unroll 1
+    for (int sel = 0; sel < 4; ++sel) {     // one inlined copy of the select body (keys stay in registers)
+        const int k = (sel == 0) ? rank[0] : (sel == 1) ? rank[1] : (sel == 2) ? rank[2] : rank[3];
+        const float x = key2f(radix_select<REG>(keys, cnt, v, n, k, sh));
+        if (sel == 0) val[0] = x; else if (sel == 1) val[1] = x; else if (sel == 2) val[2] = x; else val[3] = x;
+    }
+    float res[2];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {   // numpy _lerp
+        const float a = val[2 * which], b = val[2 * which + 1];
         const float diff = b - a;
-        float r = a + diff * gamma;
-        if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
+        float r = a + diff * gamma[which];
+        if (gamma[which] >= 0.5f) r = b - diff * (1.0f - gamma[which]);
         res[which] = r;
     }
     if (threadIdx.x == 0) { sh.lohi[0] = res[0]; sh.lohi[1] = res[1]; }
     __syncthreads();
     const float lo = sh.lohi[0], range = sh.lohi[1] - sh.lohi[0];
     if (REG) {
-#pragma unroll 8
+#pragma unroll
         for (int j = 0; j < PCT_MAXR; ++j) {
             const int i = threadIdx.x + j * PCT_THREADS;
             if (i < n) { const float d = key2f(keys[j]) - lo; v[i] = d / range; }
@@ -262,10 +295,7 @@ extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q
     EVR_REQUIRE((int64_t)H * W < (1LL << 30), "evr_percentile_normalize: image too large");
     if (n == 0) return EVR_OK;
     EVR_REQUIRE(img != nullptr, "evr_percentile_normalize: null image");
-    if ((int64_t)H * W <= (int64_t)PCT_THREADS * PCT_MAXR)
-        hipLaunchKernelGGL(pct_kernel<true>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
-    else
-        hipLaunchKernelGGL(pct_kernel<false>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
+    hipLaunchKernelGGL(pct_kernel<false>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
