@@ -76,7 +76,8 @@ __device__ __forceinline__ long long event_pixel(const EventSrc& s, int64_t g, i
 
 template <bool RAW>
 __global__ __launch_bounds__(K1_THREADS) void vox_bucket_kernel(
-    EventSrc src, const int64_t* __restrict__ win_offsets, float4* __restrict__ rec,
+    EventSrc src, const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end,
+    const int64_t* __restrict__ rec_base, float4* __restrict__ rec,
     int* __restrict__ tile_offsets, VoxHeader* hdr, int n_tiles, int T, int B, int H, int W) {
     extern __shared__ int smem[];
     int* cnt = smem;                           // [K1_WAVES][n_tiles]
@@ -85,8 +86,10 @@ __global__ __launch_bounds__(K1_THREADS) void vox_bucket_kernel(
 
     const int w = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t a = win_offsets[w];
-    const int n = (int)(win_offsets[w + 1] - a);
+    const int64_t a = win_begin[w];
+    const int64_t ne = win_end[w] - a;
+    const int n = ne > 0 ? (int)ne : 0;
+    float4* wrec = rec + rec_base[w];   // this window's records (windows may overlap in the event stream)
 
     for (int i = tid; i < K1_WAVES * n_tiles; i += K1_THREADS) cnt[i] = 0;
     __syncthreads();
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(K1_THREADS) void vox_bucket_kernel(
                 else { float d = src.t[a + i] - t0; float q = d / dt; tn = q * bm1; }
                 pv = src.p[a + i];
             }
-            rec[a + dest] = make_float4(__int_as_float((int)(pix - (long long)tile * T)), tn, pv, 0.f);
+            wrec[dest] = make_float4(__int_as_float((int)(pix - (long long)tile * T)), tn, pv, 0.f);
             const bool last = (peers >> lane) == 1ull;   // no higher peer lane
             if (last) cnt[slot] += rank + 1;
         }
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(K1_THREADS) void vox_bucket_kernel(
 
 __global__ __launch_bounds__(64 * K2_WAVES) void vox_tile_kernel(
     const float4* __restrict__ rec, const int* __restrict__ tile_offsets,
-    const int64_t* __restrict__ win_offsets, float* __restrict__ out, double* __restrict__ partials,
+    const int64_t* __restrict__ rec_base, float* __restrict__ out, double* __restrict__ partials,
     int n_windows, int n_tiles, int T, int B, int64_t HW, int vec_ok) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(64 * K2_WAVES) void vox_tile_kernel(
 
     const int* to = tile_offsets + (int64_t)w * (n_tiles + 1);
     const int e0 = to[tile], e1 = to[tile + 1];
-    const float4* r = rec + win_offsets[w];
+    const float4* r = rec + rec_base[w];
 
     for (int batch = e0; batch < e1; batch += 64) {
         const int i = batch + lane;
@@ -301,14 +304,15 @@ VoxPlan make_plan(int64_t n_events_total, int n_windows, int H, int W) {
 }
 
 template <bool RAW>
-int voxelize_impl(const EventSrc& src, const int64_t* win_offsets, int n_windows, int64_t n_events_total,
+int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* win_end, const int64_t* rec_base,
+                  int n_windows, int64_t n_events_total,
                   int B, int H, int W, float* out, double* stats, void* workspace, size_t ws_bytes,
                   hipStream_t stream) {
     EVR_REQUIRE(n_windows >= 0 && B >= 1 && H >= 1 && W >= 1, "evr_voxelize: bad shape n_windows=%d B=%d H=%d W=%d", n_windows, B, H, W);
     EVR_REQUIRE((int64_t)H * W <= 256LL * MAX_TILES * 64, "evr_voxelize: sensor %dx%d too large", W, H);
     EVR_REQUIRE(n_events_total >= 0 && n_events_total < (1LL << 31), "evr_voxelize: n_events_total out of range");
     if (n_windows == 0) return EVR_OK;
-    EVR_REQUIRE(win_offsets && out && workspace, "evr_voxelize: null pointer");
+    EVR_REQUIRE(win_begin && win_end && rec_base && out && workspace, "evr_voxelize: null pointer");
     const VoxPlan pl = make_plan(n_events_total, n_windows, H, W);
     if (ws_bytes < pl.total) {
         evr::set_error("evr_voxelize: workspace %zu B < required %zu B", ws_bytes, pl.total);
@@ -330,14 +334,14 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_offsets, int n_windows
         EVR_HIP(hipFuncSetAttribute((const void*)vox_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[RAW] = true;
     }
-    hipLaunchKernelGGL(vox_bucket_kernel<RAW>, dim3(n_windows), dim3(K1_THREADS), lds1, stream, src, win_offsets,
-                       rec, tile_offsets, hdr, pl.n_tiles, pl.T, B, H, W);
+    hipLaunchKernelGGL(vox_bucket_kernel<RAW>, dim3(n_windows), dim3(K1_THREADS), lds1, stream, src, win_begin, win_end,
+                       rec_base, rec, tile_offsets, hdr, pl.n_tiles, pl.T, B, H, W);
     EVR_LAUNCH_CHECK();
     const int64_t n_waves = (int64_t)n_windows * pl.n_tiles;
     const int64_t HW = (int64_t)H * W;
     const int vec_ok = (HW % 4 == 0) && (((uintptr_t)out & 15) == 0);
     hipLaunchKernelGGL(vox_tile_kernel, dim3((unsigned)((n_waves + K2_WAVES - 1) / K2_WAVES)), dim3(64 * K2_WAVES),
-                       lds2, stream, rec, tile_offsets, win_offsets, out, partials, n_windows, pl.n_tiles, pl.T, B,
+                       lds2, stream, rec, tile_offsets, rec_base, out, partials, n_windows, pl.n_tiles, pl.T, B,
                        HW, vec_ok);
     EVR_LAUNCH_CHECK();
     if (stats) {
@@ -362,8 +366,8 @@ extern "C" int evr_voxelize(const float* x, const float* y, const float* t, cons
     EVR_REQUIRE(n_events_total == 0 || (x && y && t && p), "evr_voxelize: null event arrays");
     EventSrc s{};
     s.x = x; s.y = y; s.t = t; s.p = p;
-    return voxelize_impl<false>(s, win_offsets, n_windows, n_events_total, B, H, W, out, stats, workspace,
-                                workspace_bytes, (hipStream_t)stream);
+    return voxelize_impl<false>(s, win_offsets, win_offsets ? win_offsets + 1 : nullptr, win_offsets, n_windows,
+                                n_events_total, B, H, W, out, stats, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int evr_voxelize_raw(const int16_t* xy, const double* ts, const uint8_t* pol,
@@ -373,8 +377,19 @@ extern "C" int evr_voxelize_raw(const int16_t* xy, const double* ts, const uint8
     EVR_REQUIRE(n_events_total == 0 || (xy && ts && pol), "evr_voxelize_raw: null event arrays");
     EventSrc s{};
     s.xy = xy; s.ts = ts; s.pol = pol;
-    return voxelize_impl<true>(s, win_offsets, n_windows, n_events_total, B, H, W, out, stats, workspace,
-                               workspace_bytes, (hipStream_t)stream);
+    return voxelize_impl<true>(s, win_offsets, win_offsets ? win_offsets + 1 : nullptr, win_offsets, n_windows,
+                               n_events_total, B, H, W, out, stats, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int evr_voxelize_raw_windows(const int16_t* xy, const double* ts, const uint8_t* pol,
+                                        const int64_t* win_begin, const int64_t* win_end, const int64_t* rec_base,
+                                        int n_windows, int64_t n_window_events, int B, int H, int W, float* out,
+                                        double* stats, void* workspace, size_t workspace_bytes, evr_stream_t stream) {
+    EVR_REQUIRE(n_window_events == 0 || (xy && ts && pol), "evr_voxelize_raw_windows: null event arrays");
+    EventSrc s{};
+    s.xy = xy; s.ts = ts; s.pol = pol;
+    return voxelize_impl<true>(s, win_begin, win_end, rec_base, n_windows, n_window_events, B, H, W, out, stats,
+                               workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int evr_voxelize_dropped(const void* workspace, int64_t* n_dropped_host, evr_stream_t stream) {

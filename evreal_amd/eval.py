@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's eval.py (same CLI, same config JSONs, same output files):
+
+    python -m evreal_amd.eval -m E2VID FireNet -c std k15k -d ECD -qm mse ssim
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m evreal_amd.eval ...
+
+Mirrors evaluate() / eval_method_with_config() / eval_method_on_sequence() (eval.py:189-246,333-445) with the
+hot path on the GPU: a sequence's events live in HBM, windows are voxelised in chunks with one launch, the
+recurrent network steps frame by frame without host synchronisation, post-normalisation and MSE/SSIM run per
+chunk.  Under torch.distributed the sequences of every dataset are sharded across ranks and the per-dataset
+totals are folded with ONE all-reduce (evreal_amd.dist).
+"""
+import argparse
+import glob
+import os
+import sys
+import traceback
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from tabulate import tabulate
+
+from . import model as model_arch
+from .config import get_dataset_configs, get_eval_configs, get_method_config
+from .dataset import MemMapDataset
+from .dist import assign_sequences, reduce_metric_sums
+from .eval_metrics import EvalMetricsTracker, MetricTracker
+from .lib import EvrError
+from .prepost import post_process_normalization
+
+CHUNK = 16   # windows voxelised / frames scored per launch
+
+
+# ------------------------------------------------------------------------------------------------
+# datasets (eval.py:38-105)
+def get_sequences(dataset_config, dataset_kwargs):
+    dataset_root = dataset_config['root_path']
+    get_all = dataset_config.get('get_all_sequences', False)
+    has_subfolders = dataset_config.get('has_subfolders', False)
+    dataset_kwargs.update(dataset_config.get('dataset_kwargs', {}))
+    if get_all:
+        pattern = os.path.join(dataset_root, '*', '*') if has_subfolders else os.path.join(dataset_root, '*')
+        sequences_config = OrderedDict()
+        for path in glob.glob(pattern):
+            name = (os.path.basename(os.path.dirname(path)) + "_" + os.path.basename(path)) if has_subfolders \
+                else os.path.basename(path)
+            sequences_config[name] = {'sequence_path': path}
+    else:
+        sequences_config = dataset_config.get('sequences', {})
+    sequences = []
+    for name, sequence in sequences_config.items():
+        sequence = dict(sequence)
+        sequence['name'] = name
+        sequence['sequence_path'] = sequence.get('sequence_path', os.path.join(dataset_root, name))
+        sequence['dataset_kwargs'] = dict(dataset_kwargs)
+        sequences.append(sequence)
+    return sequences
+
+
+def open_sequence(sequence):
+    """Instantiate the reader lazily (only on the rank that owns the sequence)."""
+    if 'dataset' not in sequence:
+        ds = MemMapDataset(sequence['sequence_path'], **sequence['dataset_kwargs'])
+        sequence['dataset'] = ds
+        min_t, max_t = ds.get_min_max_t()
+        sequence.setdefault('start_time_s', min_t)
+        sequence.setdefault('end_time_s', max_t)
+    return sequence['dataset']
+
+
+def get_datasets(dataset_configs, dataset_kwargs):
+    return [{'name': c['name'], 'sequences': get_sequences(c, dict(dataset_kwargs))} for c in dataset_configs]
+
+
+# ------------------------------------------------------------------------------------------------
+# models (eval.py:109-158)
+class _ConfigParserShim:
+    """Stand-in so torch.load can unpickle the `parse_config.ConfigParser` object stored inside the
+    E2VID+/FireNet+/HyperE2VID checkpoints (parse_config.py:1-22 of the reference)."""
+
+    def __getitem__(self, name):
+        return self.config[name]
+
+
+def _load_checkpoint(path):
+    shim = types.ModuleType('parse_config')
+    shim.ConfigParser = _ConfigParserShim
+    had = sys.modules.get('parse_config')
+    sys.modules['parse_config'] = shim
+    try:
+        return torch.load(path, map_location='cpu', weights_only=False)
+    finally:
+        if had is not None:
+            sys.modules['parse_config'] = had
+        else:
+            del sys.modules['parse_config']
+
+
+def get_model_from_checkpoint_path(model_name, checkpoint_path):
+    checkpoint = _load_checkpoint(checkpoint_path)
+    if model_name in ("SPADE-E2VID", "ET-Net"):
+        raise EvrError(f"{model_name} is not part of the MI355X hot path (SURVEY 2.1: out of scope)")
+    if model_name == "SSL-E2VID":      # eval.py:134-139
+        kw = {"base_num_channels": 32, "kernel_size": 5, "num_bins": 5, "num_encoders": 3,
+              "recurrent_block_type": "convlstm", "num_residual_blocks": 2, "skip_type": "sum", "norm": None,
+              "use_upsample_conv": True}
+        model, state_dict = model_arch.E2VIDRecurrent(kw), checkpoint
+    elif model_name == "E2VID":        # eval.py:141-144
+        kw = dict(checkpoint['model']); kw['final_activation'] = 'sigmoid'
+        model, state_dict = model_arch.E2VIDRecurrent(kw), checkpoint['state_dict']
+    elif model_name == "FireNet":      # eval.py:145-148
+        kw = dict(checkpoint['config']['model']); kw['final_activation'] = ''
+        model, state_dict = model_arch.FireNet_legacy(unet_kwargs=kw), checkpoint['state_dict']
+    else:                              # eval.py:149-155: config.init_obj('arch', model_arch)
+        arch = checkpoint['config']['arch']
+        cls = getattr(model_arch, arch['type'], None)
+        if cls is None:
+            raise EvrError(f"architecture {arch['type']!r} is not available in evreal_amd.model")
+        model = cls(**dict(arch['args']))
+        if model_name == "FireNet+":
+            model.num_encoders = 0
+        state_dict = checkpoint['state_dict']
+    model.load_state_dict(state_dict)
+    return model
+
+
+# ------------------------------------------------------------------------------------------------
+def get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics):
+    output_path = os.path.join("outputs", eval_config['name'], dataset_name, sequence['name'], method_name)
+    save_images = eval_config.get('save_images', True)
+    return EvalMetricsTracker(save_images=save_images,
+                              save_processed_images=save_images and eval_config['histeq'] != 'none',
+                              output_dir=output_path, hist_eq=eval_config['histeq'], quan_eval_metric_names=metrics,
+                              quan_eval_start_time=sequence['start_time_s'], quan_eval_end_time=sequence['end_time_s'],
+                              quan_eval_ts_tol_ms=eval_config['ts_tol_ms'],
+                              has_reference_frames=sequence['dataset'].has_images,
+                              color=eval_config.get('color', False))
+
+
+def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
+    """eval.py:189-246."""
+    ds = open_sequence(sequence)
+    if eval_config.get('color', False):
+        raise NotImplementedError("color evaluation (ColorNet) is not built yet (SURVEY 8f-3)")
+    tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
+    model.reset_states()
+    infer_all = eval_config.get('eval_infer_all', False)
+    post_norm = method_config.get('post_process_norm', "none")
+    norm_in = method_config.get('event_tensor_normalization', False)
+    tb = ds.table()
+    H, W = ds.sensor_resolution
+
+    # which items run (eval.py:212-216); an item the reference's loader raises on stops the loop there
+    todo, bad, idx = [], None, 0
+    for idx in range(len(ds)):
+        if not tb['valid'][idx]:
+            bad = idx
+            break
+        ts = tb['voxel_timestamp'][idx]
+        if ts < sequence['start_time_s'] - 10 and not infer_all:
+            continue
+        if ts > sequence['end_time_s'] and not infer_all:
+            idx -= 1
+            break
+        todo.append(idx)
+
+    imgs = torch.empty((CHUNK, 1, H, W), dtype=torch.float32, device=ds.device)
+    for c0 in range(0, len(todo), CHUNK):
+        items = todo[c0:c0 + CHUNK]
+        n = len(items)
+        grid, stats = ds.voxel_batch(items)
+        for j in range(n):
+            model(grid[j:j + 1], stats=stats[j:j + 1] if norm_in else None, out=imgs[j:j + 1])
+        im = imgs[:n, 0]
+        post_process_normalization(im, post_norm)
+        if ds.has_images:
+            refs = ds.frames(tb['frame_index'][items])[:, 0]
+            ref_ts = [float(v) for v in tb['frame_timestamp'][items]]
+        else:
+            refs, ref_ts = None, None
+        tracker.update_batch(items, im, refs, [float(v) for v in tb['voxel_timestamp'][items]], ref_ts)
+        for i in items:
+            cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
+            tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
+    tracker.finalize(idx)
+    if bad is not None:
+        raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
+            int(tb['idx0'][bad]), int(tb['idx1'][bad]), ds.num_events))
+    return tracker.get_num_quan_evaluations(), tracker.get_mean_scores()
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def eval_method_with_config(eval_config, method_name, datasets, metrics):
+    """eval.py:333-377, with the sequences of each dataset sharded across ranks."""
+    method_config = get_method_config(method_name)
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+    method_metrics = []
+    try:
+        model = get_model_from_checkpoint_path(method_config['model_name'], method_config['model_path'])
+    except Exception as e:
+        print(f"Exception while getting method {method_name} from checkpoint path {method_config['model_path']}")
+        print(e); print(traceback.format_exc())
+        return method_metrics
+    for dataset in datasets:
+        dataset_metrics = MetricTracker()
+        seqs = dataset['sequences']
+        try:
+            costs = [max(os.path.getsize(os.path.join(s['sequence_path'], 'events_ts.npy')), 1)
+                     if os.path.isdir(s['sequence_path']) else 1 for s in seqs]
+            for i in assign_sequences(costs, world)[rank]:
+                sequence = seqs[i]
+                open_sequence(sequence)
+                print(f"[rank {rank}] Evaluating {method_name} with {eval_config['name']} config on "
+                      f"{sequence['name']} from {dataset['name']}")
+                num_evaluated, mean_scores = eval_method_on_sequence(dataset['name'], eval_config, method_name, model,
+                                                                     method_config, sequence, metrics)
+                for metric_name, score in mean_scores.items():
+                    dataset_metrics.update(metric_name, score, num_evaluated)
+        except Exception as e:
+            print(f"Exception while evaluating method {method_name} on {dataset['name']} dataset:")
+            print(e); print(traceback.format_exc())
+        finally:
+            if world > 1:      # fold [sum(mean*n) per metric ..., n] over ranks: MetricTracker.update (eval.py:259-266)
+                names = [m for m in metrics if m in ('mse', 'ssim')]
+                sums = torch.zeros((1, len(names) + 1), dtype=torch.float64, device='cuda')
+                for k, nm in enumerate(names):
+                    if nm in dataset_metrics.data_dict:
+                        sums[0, k] = dataset_metrics.data_dict[nm]['total']
+                        sums[0, -1] = dataset_metrics.data_dict[nm]['count']
+                tot = reduce_metric_sums(sums, dist)
+                dataset_metrics = MetricTracker()
+                if tot[0, -1] > 0:
+                    for k, nm in enumerate(names):
+                        dataset_metrics.data_dict[nm] = {'total': float(tot[0, k]), 'count': int(tot[0, -1]),
+                                                         'average': float(tot[0, k] / tot[0, -1])}
+            method_metrics.append(dataset_metrics)
+    return method_metrics
+
+
+def print_scores(all_metrics, method_names, dataset_names, config_name):
+    """eval.py:279-303."""
+    scores_table, headers = [], ["\nMethod"]
+    for method_name, method_metrics in zip(method_names, all_metrics):
+        row = []
+        for dataset_name, dm in zip(dataset_names, method_metrics):
+            for i, metric in enumerate(dm.data_dict):
+                if len(scores_table) == 0:
+                    headers.append((dataset_name + f' ({dm.get_count(metric)})' + "\n" if i == 0 else "\n") + metric.upper())
+                row.append(dm.get_average(metric))
+        scores_table.append([method_name] + row)
+    print('')
+    print(f'Image Quality Scores (for {config_name} config)')
+    print(tabulate(scores_table, headers=headers, floatfmt=".3f"))
+    print('')
+
+
+def evaluate(method_names, eval_config_names=None, dataset_names=None, metrics=None):
+    """eval.py:413-445."""
+    if method_names is None:
+        method_names = ['E2VID', 'E2VID+', 'FireNet', 'FireNet+', 'SPADE-E2VID', 'SSL-E2VID', 'ET-Net', 'HyperE2VID']
+    eval_config_names = eval_config_names or ['std']
+    dataset_names = dataset_names or ['ECD', 'MVSEC', 'HQF']
+    metrics = metrics or ['mse', 'ssim', 'lpips']
+    results = {}
+    dataset_configs = get_dataset_configs(dataset_names)
+    for eval_config in get_eval_configs(eval_config_names):
+        datasets = get_datasets(dataset_configs, eval_config.get('dataset_kwargs', {}))
+        all_metrics = [eval_method_with_config(eval_config, m, datasets, metrics) for m in method_names]
+        dist = _dist()
+        if dist is None or dist.get_rank() == 0:
+            print_scores(all_metrics, method_names, [d['name'] for d in datasets], eval_config['name'])
+        results[eval_config['name']] = all_metrics
+    return results
+
+
+def main():
+    parser = argparse.ArgumentParser(description='event2im evaluation script (MI355X hot path)')
+    parser.add_argument('-c', '--config', nargs='+', type=str, help='evaluation configs')
+    parser.add_argument('-m', '--method', nargs='+', type=str, help='methods')
+    parser.add_argument('-d', '--dataset', nargs='+', type=str, help='datasets')
+    parser.add_argument('-qm', '--metrics', nargs='+', type=str,
+                        help='quantitative evaluation metrics that will be used calculate scores')
+    args = parser.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    evaluate(args.method, args.config, args.dataset, args.metrics)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

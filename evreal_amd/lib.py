@@ -40,6 +40,8 @@ SYMBOLS = {
     'evr_voxelize_dropped': (c_int, [c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'evr_voxelize_raw': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    'evr_voxelize_raw_windows': (c_int, [c_void_p] * 6 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     'evr_event_tensor_normalize': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                            c_void_p]),
     'evr_model_create': (c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(Tensor), c_int,

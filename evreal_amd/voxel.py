@@ -52,6 +52,21 @@ class Voxelizer:
         _lib.check(rc, 'evr_voxelize_raw')
         return out
 
+    def voxelize_raw_windows(self, xy, ts, pol, win_begin, win_end, rec_base, n_window_events, num_bins,
+                             sensor_size, out=None, stats=None, stream=None):
+        """Arbitrary (overlapping / empty) windows of one resident raw stream; all index tensors int64 cuda."""
+        H, W = sensor_size
+        nw = int(win_begin.numel())
+        if out is None:
+            out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=ts.device)
+        ws = self._workspace(int(n_window_events), nw, num_bins, H, W)
+        rc = self.lib.evr_voxelize_raw_windows(_lib.ptr(xy), _lib.ptr(ts), _lib.ptr(pol), _lib.ptr(win_begin),
+                                               _lib.ptr(win_end), _lib.ptr(rec_base), nw, int(n_window_events),
+                                               num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream_ptr(stream))
+        _lib.check(rc, 'evr_voxelize_raw_windows')
+        return out
+
     def dropped(self):
         import ctypes
         v = ctypes.c_int64(0)

@@ -74,6 +74,15 @@ int evr_voxelize_raw(const int16_t* xy, const double* ts, const uint8_t* pol,
                      int B, int H, int W, float* out, double* stats,
                      void* workspace, size_t workspace_bytes, evr_stream_t stream);
 
+/* General window form for a whole resident sequence: window w = events [win_begin[w], win_end[w]) of the
+ * stream; windows may overlap (k_events / t_seconds with a sliding window, dataset.py:104-130) or be empty.
+ * rec_base[w] = exclusive prefix sum of the window lengths (where the window's records go in the
+ * workspace); n_window_events = total of the window lengths (sizes the workspace). */
+int evr_voxelize_raw_windows(const int16_t* xy, const double* ts, const uint8_t* pol,
+                             const int64_t* win_begin, const int64_t* win_end, const int64_t* rec_base,
+                             int n_windows, int64_t n_window_events, int B, int H, int W, float* out,
+                             double* stats, void* workspace, size_t workspace_bytes, evr_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Event-tensor normalization.  Replaces eval.py:398-410 (normalize_event_tensor), applied per
  * window: over non-zeros mean = sum/nnz, std = sqrt(sumsq/nnz - mean^2) clamped to 1e-6,

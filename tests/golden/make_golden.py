@@ -307,8 +307,76 @@ def make_e2vid():
                  **{'tap.' + k: (v[:, ::4].copy() if v.shape[1] >= 32 else v) for k, v in taps.items()}, **extra)
 
 
+# ---------------------------------------------------------------- 9. the evaluation loop itself
+EVAL_SEQS = {   # name: (seed, n_events, rate_hz, W, H, fps, start_time_s, end_time_s)
+    'seqA': (71, 40000, 2.0e5, 64, 48, 50.0, None, None),
+    'seqB': (72, 30000, 2.0e5, 64, 48, 50.0, 0.03, 0.12),
+}
+EVAL_CFGS = {
+    'std': {"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "between_frames"}, "keep_ratio": 1.0},
+            "save_images": False, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 1.0, "create_video": False},
+    'k3k': {"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "k_events", "k": 3000, "sliding_window_w": 0},
+                               "keep_ratio": 1.0},
+            "save_images": False, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 3.0, "create_video": False},
+    't13ms': {"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "t_seconds", "t": 0.013, "sliding_window_t": 0},
+                                 "keep_ratio": 1.0},
+              "save_images": False, "histeq": "none", "eval_infer_all": True, "ts_tol_ms": 4.0, "create_video": False},
+}
+
+
+def write_eval_tree(root, model_path):
+    """config/ + data/ tree used by both the reference run (here) and the GPU test."""
+    for sub in ('eval', 'method', 'dataset'):
+        os.makedirs(os.path.join(root, 'config', sub), exist_ok=True)
+    for name, cfg in EVAL_CFGS.items():
+        json.dump(cfg, open(os.path.join(root, 'config', 'eval', name + '.json'), 'w'))
+    json.dump({"model_name": "FireNet", "model_path": model_path, "event_tensor_normalization": True,
+               "post_process_norm": "none"}, open(os.path.join(root, 'config', 'method', 'FireNet.json'), 'w'))
+    seqs = {}
+    for name, (seed, n, rate, W, H, fps, st, en) in EVAL_SEQS.items():
+        synth.write_sequence(os.path.join(root, 'data', 'SYN', name), seed, n, rate, W, H, fps)
+        seqs[name] = {} if st is None else {"start_time_s": st, "end_time_s": en}
+    json.dump({"root_path": os.path.join(root, 'data', 'SYN'), "sequences": seqs},
+              open(os.path.join(root, 'config', 'dataset', 'SYN.json'), 'w'))
+
+
+def make_eval():
+    import contextlib
+    import utils.eval_metrics as em
+    from oracle import metrics as omet
+    # stand-ins for the absent scikit-image (parity unpinned, DESIGN.md section 3): the oracle restatement
+    em.mse = lambda ref, img: omet.mse(img, ref)
+    em.ssim = lambda ref, img, **kw: omet.ssim(img, ref, sigma=kw.get('sigma', 1.5), data_range=kw.get('data_range', 1.0))
+    sys.modules['cv2'].imwrite = lambda path, img: True
+
+    class NoTimer(contextlib.ContextDecorator):
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    ref_eval.CudaTimer = NoTimer
+    captured = {}
+    ref_eval.print_scores = lambda all_metrics, methods, dsets, cfg: captured.__setitem__(
+        cfg, [[dm.data_dict for dm in mm] for mm in all_metrics])
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        write_eval_tree(d, f'{REF}/pretrained/FireNet/model.pth')
+        os.chdir(d)
+        sys.path.insert(0, REF)
+        try:
+            ref_eval.evaluate(['FireNet'], list(EVAL_CFGS), ['SYN'], ['mse', 'ssim'])
+        finally:
+            os.chdir(cwd)
+        files = {}
+        for base, _, fs in os.walk(os.path.join(d, 'outputs')):
+            for f in fs:
+                if f.endswith('.txt'):
+                    rel = os.path.relpath(os.path.join(base, f), d)
+                    files[rel] = open(os.path.join(base, f)).read()
+    save_json('eval_loop.json', dict(seqs=EVAL_SEQS, cfgs=EVAL_CFGS, files=files, scores=captured))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval}[w]()

@@ -1,0 +1,99 @@
+"""GPU parity of the evaluation loop (dataset reader + window planner + frame loop + trackers + output files)
+against the reference's own evaluate() run (tests/golden/eval_loop.json: FireNet real weights, synthetic
+sequences, between_frames / k_events / t_seconds configs incl. start/end-time gating and eval_infer_all)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_tree(root, g, model_path):
+    from evreal_amd import synth
+    for sub in ('eval', 'method', 'dataset'):
+        os.makedirs(os.path.join(root, 'config', sub), exist_ok=True)
+    for name, cfg in g['cfgs'].items():
+        json.dump(cfg, open(os.path.join(root, 'config', 'eval', name + '.json'), 'w'))
+    json.dump({"model_name": "FireNet", "model_path": model_path, "event_tensor_normalization": True,
+               "post_process_norm": "none"}, open(os.path.join(root, 'config', 'method', 'FireNet.json'), 'w'))
+    seqs = {}
+    for name, (seed, n, rate, W, H, fps, st, en) in g['seqs'].items():
+        synth.write_sequence(os.path.join(root, 'data', 'SYN', name), seed, n, rate, W, H, fps)
+        seqs[name] = {} if st is None else {"start_time_s": st, "end_time_s": en}
+    json.dump({"root_path": os.path.join(root, 'data', 'SYN'), "sequences": seqs},
+              open(os.path.join(root, 'config', 'dataset', 'SYN.json'), 'w'))
+
+
+def _parse(txt):
+    return [(int(a), float(b)) for a, b in (l.split() for l in txt.strip().splitlines())] if txt.strip() else []
+
+
+def test_evaluate_matches_reference_run(tmp_path, monkeypatch):
+    from evreal_amd import eval as ev
+    g = load_json('eval_loop.json')
+    w = load_npz('firenet_weights.npz')
+    ckpt = {'state_dict': {k: torch.from_numpy(w[k]) for k in w.files},
+            'config': {'model': {'num_bins': 5, 'skip_type': 'no_skip', 'recurrent_block_type': 'convgru',
+                                 'base_num_channels': 16, 'num_residual_blocks': 2,
+                                 'recurrent_blocks': {'resblock': [0]}, 'kernel_size': 3,
+                                 'final_activation': 'none', 'norm': 'none', 'BN_momentum': 0.01}}}
+    model_path = str(tmp_path / 'firenet.pth')
+    torch.save(ckpt, model_path)
+    _write_tree(str(tmp_path), g, model_path)
+    monkeypatch.chdir(tmp_path)
+    res = ev.evaluate(['FireNet'], list(g['cfgs']), ['SYN'], ['mse', 'ssim'])
+    for rel, want in g['files'].items():
+        got = open(tmp_path / rel).read()
+        name = os.path.basename(rel)
+        if name in ('timestamps.txt', 'event_rate.txt'):
+            assert got == want, rel                      # byte-identical
+        else:
+            a, b = _parse(got), _parse(want)
+            assert [i for i, _ in a] == [i for i, _ in b], rel
+            np.testing.assert_allclose([s for _, s in a], [s for _, s in b], rtol=0, atol=2e-5, err_msg=rel)
+    for cfg, want in g['scores'].items():
+        dm = res[cfg][0][0].data_dict
+        for metric, d in want[0][0].items():
+            assert dm[metric]['count'] == d['count'], (cfg, metric)
+            assert abs(dm[metric]['average'] - d['average']) < 1e-5, (cfg, metric, dm[metric]['average'], d['average'])
+
+
+def test_dataset_reader_matches_reference_tables(tmp_path):
+    """MemMapDataset mirror: per-item indices/timestamps/dt and voxel grids vs the reference (dataset_windows.json)."""
+    from evreal_amd import synth
+    from evreal_amd.dataset import MemMapDataset
+    from golden_inputs import sha
+    g = load_json('dataset_windows.json')
+    s = g['seq']
+    synth.write_sequence(str(tmp_path), s['seed'], s['n_events'], s['rate_hz'], s['width'], s['height'], s['fps'])
+    for name in ['between_frames', 'k_events', 'k_events_slide', 't_seconds', 't_seconds_slide']:
+        c = g[name]
+        ds = MemMapDataset(str(tmp_path), num_bins=5, voxel_method=dict(c['voxel_method']))
+        assert len(ds) == c['length'], name
+        mn, mx = ds.get_min_max_t()
+        assert (float(mn), float(mx)) == (c['min_t'], c['max_t'])
+        assert list(ds.sensor_resolution) == c['sensor_resolution']
+        tb = ds.table()
+        ok = [i for i, it in enumerate(c['items']) if 'raises' not in it]
+        for i, it in enumerate(c['items']):
+            if 'raises' in it:
+                assert not tb['valid'][i]
+                with pytest.raises(ValueError):
+                    ds[i]
+                continue
+            assert (int(tb['idx0'][i]), int(tb['idx1'][i]), int(tb['event_count'][i])) == (it['idx0'], it['idx1'], it['event_count']), (name, i)
+            assert tb['dt'][i] == it['dt'] and tb['voxel_timestamp'][i] == it['voxel_timestamp'], (name, i)
+            assert tb['frame_timestamp'][i] == it['frame_timestamp'], (name, i)
+        grid, _ = ds.voxel_batch(ok)                       # every window of the sequence in ONE launch
+        frames = ds.frames(tb['frame_index'][ok]).cpu().numpy()
+        grid = grid.cpu().numpy()
+        for j, i in enumerate(ok):
+            assert sha(grid[j]) == c['items'][i]['voxel_sha'], (name, i)       # bit-exact vs the reference
+            assert sha(frames[j]) == c['items'][i]['frame_sha'], (name, i)
+        item = ds[ok[-1]]
+        assert item['event_count'] == c['items'][ok[-1]]['event_count'] and item['events'].shape == (5, s['height'], s['width'])
