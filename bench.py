@@ -48,9 +48,11 @@ def build_inputs(rank, n_seq, n_steps, device):
     return d(xy.reshape(-1, 2)), d(ts.reshape(-1)), d(pol.reshape(-1)), d(offs), d(refs), (xy, ts, pol, refs)
 
 
-def cpu_baseline(host_inputs, sd, kw, n_frames):
-    """Oracle ("port") timed on the host cores: C voxelizer (1 thread) + numpy normalization + torch-CPU
-    E2VID forward (all cores) + numpy percentile + MSE + scipy SSIM, batch 1 like the reference."""
+def cpu_baseline(host_inputs, sd, kw, n_frames, budget_s=25.0):
+    """Oracle ("port") timed on the host cores, batch 1 like the reference: C voxelizer (1 thread) + numpy
+    normalization + torch-CPU E2VID forward + numpy percentile + MSE + scipy SSIM.  BOUNDED: the torch thread
+    count is the faster of {8, 32} (capped by the core count; all 256 threads of the GPU box's host run this
+    batch-1 network ~100x slower), then frames run until `n_frames` or ~`budget_s` seconds are used."""
     import ctypes
     from oracle import model as omod, prepost as op, metrics as omet
     from evreal_amd import synth
@@ -60,14 +62,11 @@ def cpu_baseline(host_inputs, sd, kw, n_frames):
                               'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
     o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
     crop = op.CropParams(W_, H_, kw['num_encoders'])
-    torch.set_num_threads(os.cpu_count())
     offs = np.array([0, K_EVENTS], dtype=np.int64)
     out = np.empty((1, BINS, H_, W_), np.float32)
     f = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    times = {'voxel': 0.0, 'norm': 0.0, 'forward': 0.0, 'post': 0.0, 'metrics': 0.0}
-    n_warm = 2
-    for i in range(n_frames + n_warm):
-        w = i % xy.shape[0]
+
+    def frame(w):
         t0 = time.perf_counter()
         xs, ys, tf, ps = synth.window_events_f32(ts[w, 0], xy[w, 0], pol[w, 0], 0, K_EVENTS)
         lib.oracle_voxelize(f(xs), f(ys), f(tf), f(ps), f(offs), 1, BINS, H_, W_, f(out))
@@ -82,15 +81,29 @@ def cpu_baseline(host_inputs, sd, kw, n_frames):
         a, b = omet.clip01(img), omet.clip01(refs[0])
         omet.mse(a, b); omet.ssim(a, b)
         t5 = time.perf_counter()
-        if i >= n_warm:
-            for k, dt in zip(times, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-                times[k] += dt
+        return (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)
+
+    t_start = time.perf_counter()
+    best, best_t = None, None
+    for nt in sorted({min(8, os.cpu_count()), min(32, os.cpu_count())}):
+        torch.set_num_threads(nt)
+        frame(0)                                   # warm-up at this thread count
+        dt = sum(frame(1 % xy.shape[0]))
+        if best_t is None or dt < best_t:
+            best, best_t = nt, dt
+    torch.set_num_threads(best)
+    times = {'voxel': 0.0, 'norm': 0.0, 'forward': 0.0, 'post': 0.0, 'metrics': 0.0}
+    done = 0
+    while done < n_frames and (time.perf_counter() - t_start) < budget_s:
+        for k, dt in zip(times, frame((done + 2) % xy.shape[0])):
+            times[k] += dt
+        done += 1
     total = sum(times.values())
-    return {"value": round(n_frames / total, 3), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_frames} frames of one 346x260 sequence, batch 1 (C voxelizer 1 thread; torch-CPU forward "
-                      f"{torch.get_num_threads()} threads, torch {torch.__version__})",
-            "ms_per_frame": {k: round(1e3 * v / n_frames, 3) for k, v in times.items()},
-            "mevents_per_s_voxelizer": round(K_EVENTS * n_frames / times['voxel'] / 1e6, 2)}
+    return {"value": round(done / total, 3), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"{done} frames of one 346x260 sequence, batch 1, E2VID forward on {best} torch threads of the "
+                      f"{os.cpu_count()}-core host (C voxelizer and numpy/scipy stages 1 thread), torch {torch.__version__}",
+            "ms_per_frame": {k: round(1e3 * v / max(done, 1), 3) for k, v in times.items()},
+            "mevents_per_s_voxelizer": round(K_EVENTS * done / max(times['voxel'], 1e-9) / 1e6, 2)}
 
 
 def main():
@@ -99,7 +112,7 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--n-seq', type=int, default=16, help='independent sequences advanced together per GPU')
-    ap.add_argument('--cpu-frames', type=int, default=40, help='frames of the CPU baseline (0 disables)')
+    ap.add_argument('--cpu-frames', type=int, default=200, help='frames of the CPU baseline (0 disables)')
     ap.add_argument('--profile-filter', default='rec', help='layers bracketed with HIP events (roofline block)')
     args = ap.parse_args()
 
