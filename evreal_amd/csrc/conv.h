@@ -14,7 +14,8 @@ enum Epilogue {
     EPI_RESIDUAL_RELU = 2,  // out = relu(acc + bias + residual)       (ResidualBlock, submodules.py:169-184)
     EPI_LSTM = 3,           // ConvLSTM gates (submodules.py:227-245); needs NB == 4 and permuted rows
     EPI_GRU_ZR = 4,         // ConvGRU update/reset (submodules.py:281-282): z -> aux0, h*r -> out
-    EPI_GRU_OUT = 5         // ConvGRU candidate + blend (submodules.py:283-285): h' in place in `state`
+    EPI_GRU_OUT = 5,        // ConvGRU candidate + blend (submodules.py:283-285): h' in place in `state`
+    EPI_BIAS_TANH = 6       // out = tanh(acc + bias)   (HyperE2VID bases_net, hyper_dynamic.py:41-48)
 };
 
 struct ConvPhase {
@@ -50,6 +51,7 @@ struct ConvArgs {
     // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
     const float* pred_w; float pred_b; int pred_sigmoid;
     int crop_h, crop_w, crop_y0, crop_x0;
+    float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };
 
 // kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
@@ -80,8 +82,22 @@ struct PredArgs {
     int sigmoid;
     int H, W, iy0, ix0;                  // crop window
     float* img;
+    float* prev_rec;                     // optional un-cropped copy [n,1,hp,wp]
 };
 int launch_pred(const PredArgs& a, hipStream_t stream);
+
+// HyperE2VID context (hyper_dynamic.py:19-23): cat(padded [normalized] event tensor, prev_rec) -> bilinear x1/4
+// (align_corners=False: the mean of the 2x2 block at rows/cols 4o+1..4o+2) -> planar [n, B+1, hp/4, wp/4].
+struct CtxArgs {
+    const float* vox; const double* stats; const float* prev_rec;
+    int n, B, H, W, hp, wp, pad_top, pad_left;
+    float* out;
+};
+int launch_ctx_down(const CtxArgs& a, hipStream_t stream);
+// HyperE2VID per-pixel dynamic filtering (hyper_dynamic.py:50-57,83-88): atoms = coeff[6,12] x bases[12,25];
+// out[pix][c*6+m] = sum_l atoms[m][l] * x[pix + offset(l)][c] over the 5x5 neighbourhood (zero padded).
+int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w,
+                          int c, hipStream_t stream);
 
 // Bilinear x2 (align_corners=False) of (x + skip): NHWC [n,h,w,c] -> [n,2h,2w,c]  (submodules.py:88)
 int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, hipStream_t stream);

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             } else if (n < a.n_valid) {
                 const int64_t o = opix * a.cout_total + n;
                 if (epi == EPI_RESIDUAL_RELU) v += a.residual[o];
-                if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
+                if (epi == EPI_BIAS_TANH) v = tanhf(v);
+                else if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
                 if (a.pred_w && a.out) a.out[o] = v;          // debug copy of the layer's own output
                 if (a.post_add) v += a.post_add[o];   // skip_sum fused into the producer (model_util.py:4-5)
                 if (!a.pred_w && a.out) a.out[o] = v;
@@ -251,9 +252,10 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                 const int hwo = a.hout * a.wout;
                 const int im = (int)(opix / hwo), rem = (int)(opix - (int64_t)im * hwo);
                 const int y = rem / a.wout - a.crop_y0, x = rem % a.wout - a.crop_x0;
+                float sres = pred_part + a.pred_b;
+                if (a.pred_sigmoid) sres = sigmoidf_(sres);
+                if (a.prev_rec) a.prev_rec[opix] = sres;
                 if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w) {
-                    float sres = pred_part + a.pred_b;
-                    if (a.pred_sigmoid) sres = sigmoidf_(sres);
                     img_out[((int64_t)im * a.crop_h + y) * a.crop_w + x] = sres;
                 }
             }
@@ -310,25 +312,32 @@ void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb) {
 // ---------------------------------------------------------------------------------------------------
 // Head convolution: tiny Cin (num_bins), so K = B*k*k is too ragged for the MFMA tiles; a direct
 // VALU kernel with the input tile in LDS and wave-uniform weights is HBM-bound on its NHWC output.
+// eval.py:398-410 from the tensorizer's {sum, sumsq, nnz}: returns false when the tensor stays as is
+__device__ __forceinline__ bool norm_params(const double* stats, int n, float& mean, float& sd) {
+    mean = 0.f; sd = 1.f;
+    if (!stats) return false;
+    const double s1 = stats[n * 3], s2 = stats[n * 3 + 1], nz = stats[n * 3 + 2];
+    if (!(nz > 0.0)) return false;
+    const float nf = (float)nz;
+    mean = (float)s1 / nf;
+    const float ex2 = (float)s2 / nf;
+    sd = sqrtf(__fsub_rn(ex2, __fmul_rn(mean, mean)));
+    if (sd == sd) sd = fmaxf(sd, 1e-6f);
+    return true;
+}
+__device__ __forceinline__ float norm_apply(float v, float mean, float sd) {
+    const float mask = (v != 0.f) ? 1.f : 0.f;
+    return __fmul_rn(mask, __fsub_rn(v, mean)) / sd;
+}
+
 template <int K, int COUT>
 __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
     constexpr int TS = 16, IS = TS + K - 1;
     extern __shared__ float tile[];   // [B][IS][IS]
     const int n = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
 
-    bool norm = false;
-    float mean = 0.f, sd = 1.f;
-    if (a.stats) {   // eval.py:398-410 fused into the load (statistics from evr_voxelize)
-        const double s1 = a.stats[n * 3], s2 = a.stats[n * 3 + 1], nz = a.stats[n * 3 + 2];
-        if (nz > 0.0) {
-            const float nf = (float)nz;
-            mean = (float)s1 / nf;
-            const float ex2 = (float)s2 / nf;
-            sd = sqrtf(__fsub_rn(ex2, __fmul_rn(mean, mean)));
-            if (sd == sd) sd = fmaxf(sd, 1e-6f);
-            norm = true;
-        }
-    }
+    float mean, sd;
+    const bool norm = norm_params(a.stats, n, mean, sd);   // eval.py:398-410 fused into the load
     const float* vin = a.vox + (int64_t)n * a.B * a.H * a.W;
     for (int i = tid; i < a.B * IS * IS; i += 256) {
         const int b = i / (IS * IS), rr = (i / IS) % IS, cc = i % IS;
@@ -336,10 +345,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
         float v = 0.f;
         if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
             v = vin[((int64_t)b * a.H + y) * a.W + x];
-            if (norm) {
-                const float mask = (v != 0.f) ? 1.f : 0.f;
-                v = __fmul_rn(mask, __fsub_rn(v, mean)) / sd;
-            }
+            if (norm) v = norm_apply(v, mean, sd);
         }
         tile[i] = v;
     }
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
     if (live && sub == 0) {
         acc += a.bias;
         if (a.sigmoid) acc = sigmoidf_(acc);
-        a.img[i] = acc;
+        a.img[i] = acc;   // (prev_rec needs the un-cropped frame: models that use it keep crop == full, see model.cpp)
     }
 }
 
@@ -418,6 +424,96 @@ int launch_pred(const PredArgs& a, hipStream_t stream) {
     EVR_REQUIRE(a.c % 4 == 0, "pred: channels %d not a multiple of 4", a.c);
     const int64_t total = (int64_t)a.n * a.H * a.W * 8;
     hipLaunchKernelGGL(pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// HyperE2VID context downsample (ConvolutionalContextFusion, hyper_dynamic.py:19-23, before its conv)
+__global__ __launch_bounds__(256) void ctx_down_kernel(const CtxArgs a) {
+    const int ho = a.hp / 4, wo = a.wp / 4, C = a.B + 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)a.n * C * ho * wo;
+    if (i >= total) return;
+    const int ox = (int)(i % wo); int64_t p = i / wo;
+    const int oy = (int)(p % ho); p /= ho;
+    const int ch = (int)(p % C);
+    const int n = (int)(p / C);
+    float mean, sd;
+    const bool norm = (ch < a.B) && norm_params(a.stats, n, mean, sd);
+    auto ld = [&](int py, int px) -> float {      // padded coordinates
+        if (ch == a.B) return a.prev_rec[((int64_t)n * a.hp + py) * a.wp + px];
+        const int y = py - a.pad_top, x = px - a.pad_left;
+        if ((unsigned)y >= (unsigned)a.H || (unsigned)x >= (unsigned)a.W) return 0.f;
+        float v = a.vox[(((int64_t)n * a.B + ch) * a.H + y) * a.W + x];
+        return norm ? norm_apply(v, mean, sd) : v;
+    };
+    // aten upsample_bilinear2d with scale 4: src = 4*o + 1.5 -> rows 4o+1, 4o+2 with lambdas 0.5/0.5
+    const int y0 = 4 * oy + 1, x0 = 4 * ox + 1;
+    const float v00 = ld(y0, x0), v01 = ld(y0, x0 + 1), v10 = ld(y0 + 1, x0), v11 = ld(y0 + 1, x0 + 1);
+    a.out[i] = 0.5f * (0.5f * v00 + 0.5f * v01) + 0.5f * (0.5f * v10 + 0.5f * v11);
+}
+
+int launch_ctx_down(const CtxArgs& a, hipStream_t stream) {
+    EVR_REQUIRE(a.hp % 4 == 0 && a.wp % 4 == 0, "ctx_down: padded size %dx%d not a multiple of 4", a.wp, a.hp);
+    const int64_t total = (int64_t)a.n * (a.B + 1) * (a.hp / 4) * (a.wp / 4);
+    hipLaunchKernelGGL(ctx_down_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// Per-pixel dynamic 5x5 filtering.  One block = 8 consecutive pixels of a row; thread = channel (c <= 256,
+// coalesced NHWC reads).  The pixel's 6x25 atoms are built in LDS from its 72 coefficients and the 12x25 bases.
+__global__ __launch_bounds__(256) void dynamic_filter_kernel(const float* __restrict__ x, const float* __restrict__ coeff,
+                                                              const float* __restrict__ bases, float* __restrict__ out,
+                                                              int n, int h, int w, int c) {
+    constexpr int PX = 8, NA = 6, NBAS = 12, KK = 25;
+    __shared__ float sb[NBAS * KK];
+    __shared__ float atoms[PX][NA * KK];
+    const int tid = threadIdx.x;
+    const int wblk = (w + PX - 1) / PX;
+    const int bx = blockIdx.x % wblk, row = blockIdx.x / wblk;   // row over n*h
+    const int img = row / h, py = row % h, px0 = bx * PX;
+    for (int i = tid; i < NBAS * KK; i += 256) sb[i] = bases[i];
+    __syncthreads();
+    for (int i = tid; i < PX * NA * KK; i += 256) {
+        const int p = i / (NA * KK), r = i % (NA * KK), m = r / KK, l = r % KK;
+        float s = 0.f;
+        if (px0 + p < w) {
+            const float* cf = coeff + (((int64_t)img * h + py) * w + px0 + p) * (NA * NBAS) + m * NBAS;
+            for (int k = 0; k < NBAS; ++k) s = fmaf(cf[k], sb[k * KK + l], s);      // einsum 'bmkhw,kl->bmlhw'
+        }
+        atoms[p][r] = s;
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        for (int p = 0; p < PX && px0 + p < w; ++p) {
+            float acc[NA] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int px = px0 + p;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int yy = py + ky - 2;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int xx = px + kx - 2;
+                    float v = 0.f;
+                    if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) v = x[(((int64_t)img * h + yy) * w + xx) * c + ch];
+                    const int l = ky * 5 + kx;
+#pragma unroll
+                    for (int m = 0; m < NA; ++m) acc[m] = fmaf(atoms[p][m * KK + l], v, acc[m]);   // 'bmlhw,bclhw->bcmhw'
+                }
+            }
+            float* o = out + (((int64_t)img * h + py) * w + px) * (int64_t)(c * NA) + ch * NA;
+#pragma unroll
+            for (int m = 0; m < NA; ++m) o[m] = acc[m];
+        }
+    }
+}
+
+int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w, int c,
+                          hipStream_t stream) {
+    const int wblk = (w + 7) / 8;
+    hipLaunchKernelGGL(dynamic_filter_kernel, dim3((unsigned)(wblk * n * h)), dim3(256), 0, stream, x, coeff, bases, out, n, h, w, c);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

@@ -57,7 +57,7 @@ struct Conv {   // one prepared implicit-GEMM convolution
     double flops = 0.0;
 };
 
-enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED };
+enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN };
 struct Step {
     StepKind kind;
     int conv = -1;
@@ -89,7 +89,14 @@ struct evr_model {
     const float* pred_x[2] = {nullptr, nullptr};
     const float* pred_skip[2] = {nullptr, nullptr};
     int pred_c = 0;
-    int pred_fused_conv = -1;   // conv whose epilogue carries the prediction layer (-1: standalone pred kernel)
+    int pred_fused_conv = -1;
+    // HyperE2VID dynamic decoder (submodules.py:100-127)
+    bool dynamic = false;
+    std::vector<float> ctx_w, ctx_b, fb_bases;
+    float* d_ctx_w = nullptr; float* d_ctx_b = nullptr; float* d_bases = nullptr;
+    float* prev_rec = nullptr;
+    HeadArgs ctxconv;
+    CtxArgs ctx;   // conv whose epilogue carries the prediction layer (-1: standalone pred kernel)
     // per-layer event timing (evr_model_profile_*)
     bool prof_on = false;
     std::string prof_filter;
@@ -99,13 +106,14 @@ struct evr_model {
     std::vector<int64_t> prof_n;
 
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
+                   if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
         allocs.clear();
         if (d_args) { (void)hipFree(d_args); d_args = nullptr; }
         steps.clear(); named[0].clear(); named[1].clear();
-        n_seq = 0;
+        n_seq = 0; prev_rec = nullptr;
     }
 };
 
@@ -229,14 +237,15 @@ int finish_conv(evr_model* m, Conv& c) {
 
 int pick_kc(int c0, int c1) { return (c0 % 32 == 0 && (c1 == 0 || c1 % 32 == 0)) ? 32 : 16; }
 
-// plain conv: prefix.{weight,bias}; bn under bn_prefix
+// plain conv: prefix.{weight,bias}; bn under bn_prefix.  The reference's ConvLayer/ResidualBlock drop the conv bias
+// when they use BN (submodules.py:13,155); keep_bias_with_bn covers nn.Sequential(Conv2d(bias), BatchNorm2d).
 int add_conv(evr_model* m, const std::string& name, const std::string& wname, const std::string& bname, const std::string& bn_prefix,
-             bool bn, int cin, int cout, int k, int stride, int epi) {
+             bool bn, int cin, int cout, int k, int stride, int epi, bool keep_bias_with_bn = false) {
     Conv c; c.name = name;
     const HostTensor* w; int rc;
     if ((rc = find(m, wname, &w))) return rc;
     Affine af;
-    if ((rc = make_affine(m, bn ? std::string() : bname, bn_prefix, bn, cout, &af))) return rc;
+    if ((rc = make_affine(m, (bn && !keep_bias_with_bn) ? std::string() : bname, bn_prefix, bn, cout, &af))) return rc;
     EVR_REQUIRE(cin % 16 == 0, "'%s': %d input channels (need a multiple of 16)", name.c_str(), cin);
     c.kc = pick_kc(cin, 0);
     c.cin0 = cin; c.cin1 = 0; c.stride = stride; c.epi = epi; c.n_valid = cout;
@@ -356,9 +365,35 @@ int build_unet(evr_model* m) {
         if ((rc = add_conv(m, n + ".conv1", p + ".conv1.weight", p + ".conv1.bias", p + ".bn1", bn, cm, cm, 3, 1, EPI_BIAS_RELU))) return rc;
         if ((rc = add_conv(m, n + ".conv2", p + ".conv2.weight", p + ".conv2.bias", p + ".bn2", bn, cm, cm, 3, 1, EPI_RESIDUAL_RELU))) return rc;
     }
+    m->dynamic = (d.reserved[1] & 1) != 0;
     for (int i = 0; i < E; ++i) {
         const int cin = base << (E - i), cout = base << (E - i - 1);
         const std::string p = pre + "decoders." + std::to_string(i), n = "dec" + std::to_string(i);
+        if (i == 0 && m->dynamic) {
+            // DynamicUpsampleLayer: context fusion conv (direct, 6 -> 32), bases_net (2 convs + BN + tanh), FB bases,
+            // compositional 1x1 conv over in_channels * num_atoms
+            EVR_REQUIRE(E == 3, "the dynamic decoder needs num_encoders == 3 (context is fused at 1/4 resolution)");
+            const HostTensor *cw, *cb, *bs;
+            const int B1 = d.num_bins + 1;
+            if ((rc = find(m, p + ".context_fusion.conv.weight", &cw))) return rc;
+            if ((rc = find(m, p + ".context_fusion.conv.bias", &cb))) return rc;
+            if ((rc = find(m, p + ".dynamic_atom_generation.bases", &bs))) return rc;
+            EVR_REQUIRE(cw->ndim == 4 && cw->shape[0] == 32 && cw->shape[1] == B1 && cw->shape[2] == 3 && cb->numel() == 32, "context_fusion conv shape mismatch");
+            EVR_REQUIRE(bs->ndim == 2 && bs->shape[0] == 12 && bs->shape[1] == 25, "Fourier-Bessel bases must be [12,25]");
+            m->ctx_w.assign((size_t)B1 * 9 * 32, 0.f); m->ctx_b.assign(cb->data, cb->data + 32);
+            for (int co = 0; co < 32; ++co)
+                for (int b = 0; b < B1; ++b)
+                    for (int t = 0; t < 9; ++t) m->ctx_w[((size_t)b * 9 + t) * 32 + co] = cw->data[((size_t)co * B1 + b) * 9 + t];
+            m->fb_bases.assign(bs->data, bs->data + 300);
+            if ((rc = upload(m->ctx_w, &m->d_ctx_w))) return rc;
+            if ((rc = upload(m->ctx_b, &m->d_ctx_b))) return rc;
+            if ((rc = upload(m->fb_bases, &m->d_bases))) return rc;
+            const std::string bnet = p + ".dynamic_atom_generation.bases_net";
+            if ((rc = add_conv(m, n + ".bn1", bnet + ".0.weight", bnet + ".0.bias", bnet + ".1", true, 32, 64, 3, 1, EPI_BIAS_TANH, true))) return rc;
+            if ((rc = add_conv(m, n + ".bn2", bnet + ".3.weight", bnet + ".3.bias", bnet + ".4", true, 64, 72, 3, 1, EPI_BIAS_TANH, true))) return rc;
+            if ((rc = add_conv(m, n, p + ".dynamic_conv.compositional_coefficients", p + ".dynamic_conv.bias", "", false, cin * 6, cout, 1, 1, EPI_BIAS_RELU))) return rc;
+            continue;
+        }
         if (d.use_upsample_conv) rc = add_conv(m, n, p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", bn, cin, cout, k, 1, EPI_BIAS_RELU);
         else rc = add_tconv(m, n, p, bn, cin, cout, k);
         if (rc) return rc;
@@ -447,6 +482,7 @@ void try_fuse_pred(evr_model* m, int ci, const float* skip) {
         a.post_add = skip;
         a.pred_w = m->d_pred_w; a.pred_b = m->pred_b; a.pred_sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
         a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
+        a.prev_rec = m->prev_rec;
         if (!(m->desc.reserved[0] & 1)) a.out = nullptr;
     }
     m->pred_fused_conv = ci;
@@ -537,7 +573,42 @@ int plan_unet(evr_model* m, hipStream_t stream) {
         const std::string dn = "dec" + std::to_string(i);
         const int di = conv_index(m, dn);
         DevTensor o;
-        if (d.use_upsample_conv) {
+        if (i == 0 && m->dynamic) {
+            DevTensor up, ctxp, ctxf, t1, coef, inter, prev;
+            if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
+            if ((rc = alloc(m, &ctxp, n, 1, (d.num_bins + 1) * (m->hp / 4), m->wp / 4, stream))) return rc;   // planar [n,B+1,hp/4,wp/4]
+            if ((rc = alloc(m, &ctxf, n, m->hp / 4, m->wp / 4, 32, stream))) return rc;
+            if ((rc = alloc(m, &t1, n, 2 * h, 2 * w, 64, stream))) return rc;
+            if ((rc = alloc(m, &coef, n, 2 * h, 2 * w, 72, stream))) return rc;
+            if ((rc = alloc(m, &inter, n, 2 * h, 2 * w, cin * 6, stream))) return rc;
+            if ((rc = alloc(m, &prev, n, m->hp, m->wp, 1, stream))) return rc;
+            m->prev_rec = prev.p;
+            { Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin;
+              for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
+              m->steps.push_back(s); }
+            h *= 2; w *= 2;
+            EVR_REQUIRE(h == m->hp / 4 && w == m->wp / 4, "dynamic decoder: context resolution mismatch");
+            memset(&m->ctx, 0, sizeof(m->ctx));
+            m->ctx.prev_rec = prev.p; m->ctx.n = n; m->ctx.B = d.num_bins; m->ctx.H = m->H; m->ctx.W = m->W; m->ctx.hp = m->hp; m->ctx.wp = m->wp;
+            m->ctx.pad_top = m->pad_top; m->ctx.pad_left = m->pad_left; m->ctx.out = ctxp.p;
+            { Step s; s.kind = ST_CTX; m->steps.push_back(s); }
+            memset(&m->ctxconv, 0, sizeof(m->ctxconv));
+            m->ctxconv.vox = ctxp.p; m->ctxconv.n = n; m->ctxconv.B = d.num_bins + 1; m->ctxconv.H = h; m->ctxconv.W = w; m->ctxconv.hp = h; m->ctxconv.wp = w;
+            m->ctxconv.k = 3; m->ctxconv.cout = 32; m->ctxconv.wgt = m->d_ctx_w; m->ctxconv.bias = m->d_ctx_b; m->ctxconv.out = ctxf.p; m->ctxconv.relu = 0;
+            { Step s; s.kind = ST_CTXCONV; m->steps.push_back(s); }
+            const int b1 = conv_index(m, dn + ".bn1"), b2 = conv_index(m, dn + ".bn2");
+            ConvIO a1{}, a2{}, a3{};
+            for (int p = 0; p < 2; ++p) { a1.in0[p] = ctxf.p; a1.out[p] = t1.p; a2.in0[p] = t1.p; a2.out[p] = coef.p; a3.in0[p] = inter.p; }
+            plan_conv(m, b1, n, h, w, a1, 64); push_conv(m, b1);
+            plan_conv(m, b2, n, h, w, a2, 72); push_conv(m, b2);
+            { Step s; s.kind = ST_DYN; s.a[0] = s.a[1] = up.p; s.b[0] = s.b[1] = coef.p; s.out = inter.p; s.h = h; s.w = w; s.c = cin; m->steps.push_back(s); }
+            if ((rc = alloc(m, &o, n, h, w, cout, stream))) return rc;
+            for (int p = 0; p < 2; ++p) a3.out[p] = o.p;
+            plan_conv(m, di, n, h, w, a3, cout); push_conv(m, di);
+            m->flops += 2.0 * n * h * w * (double)cin * 25 * 6 + 2.0 * n * h * w * 72.0 * 25 + 2.0 * n * h * w * 9.0 * (d.num_bins + 1) * 32;
+            name2(m, "ctx", ctxf, ctxf); name2(m, "coeff", coef, coef);
+            last_plain = -1;   // the next decoder adds its skip itself
+        } else if (d.use_upsample_conv) {
             DevTensor up;
             if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
             Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin;
@@ -575,6 +646,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     m->pred_skip[0] = m->pred_skip[1] = head.p;
     m->pred_c = base;
     try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p);
+    EVR_REQUIRE(!m->dynamic || m->pred_fused_conv >= 0, "dynamic decoder: the prediction layer could not be fused (prev_recs needs it)");
     return EVR_OK;
 }
 
@@ -718,6 +790,18 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             case ST_ADD:
                 if ((rc = launch_add(s.a[p], s.b[p], s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream))) return rc;
+                break;
+            case ST_CTX: {
+                CtxArgs ca = m->ctx;
+                ca.vox = vox; ca.stats = (flags & 1u) ? stats : nullptr;
+                if ((rc = launch_ctx_down(ca, stream))) return rc;
+                break;
+            }
+            case ST_CTXCONV:
+                if ((rc = launch_head_conv(m->ctxconv, stream))) return rc;
+                break;
+            case ST_DYN:
+                if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
                 break;
             default: break;
         }

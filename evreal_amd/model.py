@@ -60,6 +60,7 @@ class _HipModel:
         h = ctypes.c_void_p()
         desc = self._desc()
         desc.reserved[0] = 1 if self.debug_taps else 0
+        desc.reserved[1] = 1 if getattr(self, 'kwargs', {}).get('use_dynamic_decoder', False) else 0
         _lib.check(self.lib.evr_model_create(ctypes.byref(desc), tensors, len(sd), ctypes.byref(h)),
                    'evr_model_create')
         self.handle = h
@@ -159,8 +160,6 @@ class E2VIDRecurrent(_HipModel):
         self.num_encoders = kw['num_encoders']
         if kw.get('skip_type', 'sum') != 'sum':
             raise _lib.EvrError("only skip_type='sum' exists in the reference (model/unet.py:4,31)")
-        if kw.get('use_dynamic_decoder', False):
-            raise _lib.EvrError("HyperE2VID's dynamic decoder is not built yet (SURVEY 8a a21)")
         if kw.get('norm') not in (None, 'none', 'BN'):
             raise _lib.EvrError(f"norm={kw.get('norm')!r} is not supported (BN or none)")
         if kw.get('num_output_channels', 1) != 1:

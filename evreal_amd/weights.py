@@ -44,7 +44,7 @@ def _gru(shapes, name, c):
 
 def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
                           kernel_size=5, norm=None, use_upsample_conv=False,
-                          recurrent_block_type='convlstm', prefix='unetrecurrent.', **_):
+                          recurrent_block_type='convlstm', prefix='unetrecurrent.', use_dynamic_decoder=False, **_):
     """Ordered {name: shape} of E2VIDRecurrent.state_dict() (registration order of
     UNetRecurrent.__init__, model/unet.py:99-106)."""
     s = OrderedDict()
@@ -71,6 +71,15 @@ def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_
         _conv(s, p + '.conv2', cm, cm, 3, bias=not bn)
     for i, (ci, co) in enumerate(zip(reversed(cout), reversed(cin))):
         p = f'{prefix}decoders.{i}'
+        if i == 0 and use_dynamic_decoder:      # DynamicUpsampleLayer (model/submodules.py:100-127, model/hyper/)
+            _conv(s, p + '.context_fusion.conv', 32, num_bins + 1, 3)
+            s[p + '.dynamic_atom_generation.bases'] = (12, 25)          # Fourier-Bessel table: data, not random
+            bn_ = p + '.dynamic_atom_generation.bases_net'
+            _conv(s, bn_ + '.0', 64, 32, 3); _bn(s, bn_ + '.1', 64)
+            _conv(s, bn_ + '.3', 72, 64, 3); _bn(s, bn_ + '.4', 72)
+            s[p + '.dynamic_conv.compositional_coefficients'] = (co, ci * 6, 1, 1)
+            s[p + '.dynamic_conv.bias'] = (co,)
+            continue
         if use_upsample_conv:
             _conv(s, p + '.conv2d', co, ci, k, bias=not bn)
         else:
@@ -109,13 +118,17 @@ def firenet_schema(num_bins=5, base_num_channels=16, kernel_size=3, **_):
     return s
 
 
-def synth_state_dict(schema, seed=0, gain=1.0):
+def synth_state_dict(schema, seed=0, gain=1.0, fixed=None):
     """Deterministic fp32 numpy weights for a schema.  Each tensor is drawn from its own
     PCG64 stream keyed by (seed, crc32(name)) so adding/removing tensors never shifts the
     others.  Conv weights ~ U(-a, a), a = gain*sqrt(3/fan_in) (unit-variance preserving);
     biases small; BN gamma in [0.8,1.2], beta/mean in [-0.1,0.1], var in [0.5,1.5]."""
     out = OrderedDict()
+    fixed = fixed or {}
     for name, shape in schema.items():
+        if name in fixed:                 # e.g. the Fourier-Bessel bases buffer of HyperE2VID
+            out[name] = np.asarray(fixed[name], dtype=np.float32).reshape(shape)
+            continue
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         leaf = name.rsplit('.', 1)[-1]
         if leaf == 'num_batches_tracked':

@@ -121,7 +121,8 @@ typedef struct evr_model_desc {
     int recurrent_block;     /* evr_recurrent */
     int final_activation;    /* evr_activation */
     int pad_multiple_log2;   /* cropper's num_encoders (FireNet legacy: 4, FireNet+: 0) */
-    int reserved[5];         /* reserved[0] bit 0: debug -- keep every intermediate readable by
+    int reserved[5];         /* reserved[1] bit 0: use_dynamic_decoder (HyperE2VID, model/submodules.py:100-127);
+                              * reserved[0] bit 0: debug -- keep every intermediate readable by
                               * evr_model_read_tensor (otherwise the last decoder's NHWC output is never
                               * stored: the prediction layer is fused into its epilogue) */
 } evr_model_desc;

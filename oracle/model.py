@@ -77,6 +77,30 @@ def conv_gru(sd, p, x, h):
     return h * (1 - update) + out * update
 
 
+def dynamic_upsample_layer(sd, p, x, ev_tensor, prev_recs):
+    """DynamicUpsampleLayer (model/submodules.py:100-127) over model/hyper/hyper_dynamic.py:7-92:
+    bilinear x2; context = conv3(bilinear x1/4 of cat(events, prev_rec)); bases_net (conv-BN-tanh x2) ->
+    per-pixel coefficients [6,12] x Fourier-Bessel bases [12,25] -> 6 atoms of 5x5; every input channel is
+    filtered by the 6 atoms (unfold + einsum) and a 1x1 conv mixes the C*6 maps; relu."""
+    x_up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    ctx = torch.cat((ev_tensor, prev_recs), dim=1)
+    ctx = F.interpolate(ctx, scale_factor=0.25, mode='bilinear', align_corners=False)
+    ctx = F.conv2d(ctx, sd[p + '.context_fusion.conv.weight'], sd[p + '.context_fusion.conv.bias'], padding=1)
+    bn = p + '.dynamic_atom_generation.bases_net'
+    c = F.conv2d(ctx, sd[bn + '.0.weight'], sd[bn + '.0.bias'], padding=1)
+    c = torch.tanh(_bn(sd, bn + '.1', c))
+    c = F.conv2d(c, sd[bn + '.3.weight'], sd[bn + '.3.bias'], padding=1)
+    c = torch.tanh(_bn(sd, bn + '.4', c))
+    N, _, H, W = c.shape
+    bases = sd[p + '.dynamic_atom_generation.bases']
+    atoms = torch.einsum('bmkhw,kl->bmlhw', c.view(N, 6, 12, H, W), bases)
+    C = x_up.shape[1]
+    u = F.unfold(x_up, kernel_size=5, padding=2).view(N, C, 25, H, W)
+    inter = torch.einsum('bmlhw,bclhw->bcmhw', atoms, u).reshape(N, C * 6, H, W)
+    out = F.conv2d(inter, sd[p + '.dynamic_conv.compositional_coefficients'], sd[p + '.dynamic_conv.bias'])
+    return torch.relu(out)
+
+
 def residual_block(sd, p, x, norm=None):
     out = F.conv2d(x, sd[p + '.conv1.weight'], sd.get(p + '.conv1.bias'), padding=1)
     if norm == 'BN':
@@ -93,19 +117,24 @@ class UNetRecurrentOracle:
 
     def __init__(self, sd, num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
                  kernel_size=5, norm=None, use_upsample_conv=False, recurrent_block_type='convlstm',
-                 final_activation='none', prefix='unetrecurrent.'):
+                 final_activation='none', prefix='unetrecurrent.', use_dynamic_decoder=False):
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         self.pre, self.k, self.norm = prefix, kernel_size, norm
         self.num_encoders, self.num_res = num_encoders, num_residual_blocks
         self.up, self.rec = use_upsample_conv, recurrent_block_type
         self.final = getattr(torch, final_activation, None)
+        self.dynamic = use_dynamic_decoder
         self.reset_states()
 
     def reset_states(self):
         self.states = [None] * self.num_encoders
+        self.prev_recs = None                      # model/model.py:129-131
 
     def __call__(self, x, taps=None):
         sd, pre, k = self.sd, self.pre, self.k
+        ev_tensor = x
+        if self.prev_recs is None:                 # model/model.py:139-141
+            self.prev_recs = torch.zeros(x.shape[0], 1, x.shape[2], x.shape[3])
         x = conv_layer(sd, pre + 'head', x, 1, k // 2, 'relu', None)   # head has norm=None (unet.py:77-82)
         head = x
         if taps is not None: taps['head'] = x
@@ -126,7 +155,9 @@ class UNetRecurrentOracle:
         for i in range(self.num_encoders):
             x = x + blocks[self.num_encoders - i - 1]
             p = f'{pre}decoders.{i}'
-            if self.up:
+            if i == 0 and self.dynamic:
+                x = dynamic_upsample_layer(sd, p, x, ev_tensor, self.prev_recs)
+            elif self.up:
                 x = upsample_conv_layer(sd, p, x, k // 2, 'relu', self.norm)
             else:
                 x = transposed_conv_layer(sd, p, x, k // 2, 'relu', self.norm)
@@ -134,6 +165,7 @@ class UNetRecurrentOracle:
         img = conv_layer(sd, pre + 'pred', x + head, 1, 0, None, self.norm)
         if self.final is not None:
             img = self.final(img)
+        self.prev_recs = img.detach()              # model/model.py:143
         return img
 
 

@@ -256,14 +256,18 @@ def make_firenet():
 # ---------------------------------------------------------------- 6. E2VID layouts (synthetic weights)
 def make_e2vid():
     for tag, kw in [('e2vid_bn', weights.E2VID_KWARGS), ('e2vid_plus', weights.E2VID_PLUS_KWARGS),
+                    ('e2vid_hyper', dict(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                                         kernel_size=5, norm=None, use_upsample_conv=True, recurrent_block_type='convlstm',
+                                         skip_type='sum', final_activation='none', use_dynamic_decoder=True)),
                     ('e2vid_gru_tiny', dict(num_bins=5, base_num_channels=32, num_encoders=2, num_residual_blocks=1,
                                             kernel_size=5, norm=None, use_upsample_conv=False,
                                             recurrent_block_type='convgru', skip_type='sum',
                                             final_activation='sigmoid'))]:
         schema = weights.unet_recurrent_schema(**kw)
-        sd = weights.synth_state_dict(schema, seed=7)
         m = ref_model.E2VIDRecurrent(dict(kw))
         ref_sd = m.state_dict()
+        fixed = {k: v.numpy() for k, v in ref_sd.items() if k.endswith('.bases')}   # Fourier-Bessel table (data)
+        sd = weights.synth_state_dict(schema, seed=7, fixed=fixed)
         assert list(ref_sd.keys()) == list(sd.keys()), (set(ref_sd) ^ set(sd))
         for k in ref_sd:
             assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
@@ -273,7 +277,7 @@ def make_e2vid():
         vox = voxel_sequence(61, 4, 5, H, W)
         outs, taps = [], {}
         hooks = []
-        if tag != 'e2vid_gru_tiny':
+        if tag not in ('e2vid_gru_tiny',):
             u = m.unetrecurrent
             def tap(name):
                 def hook(mod, inp, out):
@@ -304,6 +308,7 @@ def make_e2vid():
                  images=np.concatenate(outs),
                  kwargs=np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8), seed=np.array(7),
                  weights_sha=np.array(weights.state_dict_digest(sd)),
+                 **{'fixed.' + k: v for k, v in fixed.items()},
                  **{'tap.' + k: (v[:, ::4].copy() if v.shape[1] >= 32 else v) for k, v in taps.items()}, **extra)
 
 

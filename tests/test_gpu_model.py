@@ -54,7 +54,8 @@ def _e2vid(tag, n_seq=1):
     from evreal_amd import model, synth, weights
     z = load_npz(f'{tag}_seq.npz')
     kw = json.loads(bytes(z['kwargs']).decode())
-    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']))
+    fixed = {k[6:]: z[k] for k in z.files if k.startswith('fixed.')}
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']), fixed=fixed)
     assert weights.state_dict_digest(sd) == str(z['weights_sha'])
     m = model.E2VIDRecurrent(kw)
     m.debug_taps = (n_seq == 1)      # taps of the last decoder need its (otherwise never stored) output
@@ -100,6 +101,14 @@ def test_e2vid_plus_layout():
 
 def test_e2vid_gru_tiny():
     _e2vid('e2vid_gru_tiny')
+
+
+def test_e2vid_hyper_dynamic_decoder():
+    _e2vid('e2vid_hyper')
+
+
+def test_e2vid_hyper_batched_sequences():
+    _e2vid('e2vid_hyper', n_seq=2)
 
 
 def test_e2vid_bn_batched_sequences():

@@ -48,10 +48,12 @@ def test_firenet_plus_real_weights():
 def _run_e2vid(tag):
     z = load_npz(f'{tag}_seq.npz')
     kw = json.loads(bytes(z['kwargs']).decode())
-    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']))
+    fixed = {k[6:]: z[k] for k in z.files if k.startswith('fixed.')}
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=int(z['seed']), fixed=fixed)
     assert weights.state_dict_digest(sd) == str(z['weights_sha'])
     okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
                               'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    okw['use_dynamic_decoder'] = kw.get('use_dynamic_decoder', False)
     m = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
     seed, F, B, H, W = [int(v) for v in z['voxel_args']]
     vox = synth.sparse_voxels(seed, F, B, H, W)
@@ -89,3 +91,7 @@ def test_e2vid_plus_layout():
 
 def test_e2vid_gru_tiny():
     _run_e2vid('e2vid_gru_tiny')
+
+
+def test_e2vid_hyper_dynamic_decoder():
+    _run_e2vid('e2vid_hyper')
