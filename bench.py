@@ -109,9 +109,9 @@ def cpu_baseline(host_inputs, sd, kw, n_frames, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--n-seq', type=int, default=16, help='independent sequences advanced together per GPU')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--n-seq', type=int, default=64, help='independent sequences advanced together per GPU')
     ap.add_argument('--cpu-frames', type=int, default=200, help='frames of the CPU baseline (0 disables)')
     ap.add_argument('--profile-filter', default='rec', help='layers bracketed with HIP events (roofline block)')
     args = ap.parse_args()

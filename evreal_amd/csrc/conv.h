@@ -18,12 +18,16 @@ enum Epilogue {
     EPI_BIAS_TANH = 6       // out = tanh(acc + bias)   (HyperE2VID bases_net, hyper_dynamic.py:41-48)
 };
 
-struct ConvPhase {
+// Tap list of one convolution.  For ConvTranspose2d(k, stride 2) the four sub-pixel phases are column GROUPS of
+// one GEMM (N = 4*Cout, phase-major): they share the input taps, and tap_groups[t] says which groups use tap t
+// (the kernel skips the MFMA blocks of the others and whole K steps no group of its N tile needs).
+struct ConvTaps {
     int ntaps;
-    int w_off;        // float offset of this phase's [Cout][ntaps*Cin] weight block
-    int ofy, ofx;     // output pixel = (my*os + ofy, mx*os + ofx)
-    int tap[MAX_TAPS];   // (dy & 0xffff) | (dx << 16): dwords so the kernel fetches them with s_load
-    void set_tap(int i, int dy, int dx) { tap[i] = (dy & 0xffff) | (dx * 65536); }
+    int tap[MAX_TAPS];          // (dy & 0xffff) | (dx << 16): dwords so the kernel fetches them with s_load
+    int tap_groups[MAX_TAPS];   // bitmask over column groups
+    int ngroups, grp_cols;      // columns per group (multiple of 32); ngroups*grp_cols == cout
+    int grp_ofy[MAX_PHASES], grp_ofx[MAX_PHASES];   // output pixel = (my*os + ofy[g], mx*os + ofx[g])
+    void set_tap(int i, int dy, int dx, int groups) { tap[i] = (dy & 0xffff) | (dx * 65536); tap_groups[i] = groups; }
 };
 
 struct ConvArgs {
@@ -33,9 +37,8 @@ struct ConvArgs {
     int n, hin, win;          // input tensor [n, hin, win, c]
     int hm, wm;               // M-grid per image; GEMM M = n*hm*wm
     int stride;               // input pixel = m*stride + tap offset
-    int nphases;
-    ConvPhase ph[MAX_PHASES];
-    const float* wgt;         // per phase [cout][ntaps*(cin_total)], K contiguous
+    ConvTaps tp;
+    const float* wgt;         // [cout][ntaps*(cin_total)], K contiguous (zero blocks for unused (tap, group) pairs)
     const float* bias;        // [cout]
     int cout;                 // GEMM N (multiple of 32*NB; rows >= n_valid are zero padding)
     int n_valid;              // real output channels

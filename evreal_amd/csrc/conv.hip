@@ -21,12 +21,15 @@
 //   im2col      on the fly: per K step one tap (dy,dx) and one channel chunk go HBM/L2 -> LDS by
 //               `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR staging); zero padding and ragged M
 //               come from the buffer descriptor's range check (out-of-range offset reads 0); channel
-//               concat (x|h) switches descriptors per chunk; ConvTranspose2d(k,s=2) runs as 4
-//               sub-pixel phases (blockIdx-selected tap lists); skip-sum is fused into the producer
+//               concat (x|h) switches descriptors per chunk; ConvTranspose2d(k,s=2) is ONE GEMM whose N
+//               is phase-major (4 sub-pixel phases x Cout): the phases share the 3x3 input taps (A tile
+//               loaded once), and (tap, phase) pairs the transposed kernel does not connect are skipped;
+//               skip-sum is fused into the producer
 //   epilogues   bias/ReLU, residual+ReLU, ConvLSTM cell, ConvGRU (update/reset, candidate+blend)
 //   grid        1-D, remapped so every XCD (private L2) walks a contiguous range of tiles with the N
 //               tile fastest: an A tile is reused from L2 across its N tiles and neighbouring M tiles
 #include "conv.h"
+#include <cstdlib>
 
 namespace evr {
 
@@ -52,7 +55,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
-template <int KC, int WM, int NB, bool LSTM>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
@@ -67,7 +70,6 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = a.hm * a.wm;
     const int M = a.n * hw;
-    const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
 
     // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
@@ -78,24 +80,34 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ntile = lin % ntiles;
-    const int rest = lin / ntiles;
-    const int mtile = rest % mtiles;
-    const int phase = rest / mtiles;
-    const ConvPhase& ph = a.ph[phase];
+    const int mtile = lin / ntiles;
+    const ConvTaps& tp = a.tp;
     const int m0 = mtile * 32 * WM, n0 = ntile * 32 * NB;
+
+    // column groups (sub-pixel phases of a transposed conv) covered by this N tile -> taps this block needs
+    const int grp_cols = tp.grp_cols;
+    int tile_groups = 0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0 + nb * 32) / grp_cols);
+    unsigned act_taps = (1u << tp.ntaps) - 1u;     // ntaps <= 25
+    if constexpr (GROUPED) {
+        act_taps = 0;
+        for (int t = 0; t < tp.ntaps; ++t) act_taps |= (tp.tap_groups[t] & tile_groups) ? (1u << t) : 0u;
+    }
+    const int n_act = __builtin_popcount(act_taps);
 
     const int c0 = a.c0, c1 = a.c1;
     const int cin_total = c0 + (a.in_mode == IN_CAT ? c1 : 0);
     const int nchunks = cin_total / KC;
-    const int nsteps = ph.ntaps * nchunks;
-    const int ktot = nsteps * KC;
+    const int nsteps = n_act * nchunks;          // K steps this block runs (active taps only)
+    const int ktot = tp.ntaps * nchunks * KC;    // row length of the weight matrix
     const int hin = a.hin, win = a.win;
 
     // buffer descriptors: out-of-range offsets read as 0.0f -> zero padding and ragged M for free
     const unsigned in_pix = (unsigned)a.n * hin * win;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
-    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt + ph.w_off, (unsigned)a.cout * ktot * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
 
     // LDS image is lane-linear per DMA piece (64 lanes x 16 B): float4 index idx = piece*64 + lane holds
     // row idx/SP, slot idx%SP; the XOR swizzle is applied to the SOURCE quad (and again on the fragment read)
@@ -123,14 +135,18 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         b_off[j] = (unsigned)((n0 + row) * ktot + ((idx % SP) ^ swz<KC>(row)) * 4);
     }
 
-    auto issue = [&](int s, int buf) {
-        const int t = s / nchunks, cc = s - t * nchunks;
+    // (tap, chunk) of the step being issued / computed: walked incrementally over the set bits of act_taps
+    unsigned bits_i = act_taps, bits_c = act_taps;
+    int cc_i = 0, cc_c = 0;
+    auto issue = [&](int buf) {
+        const int t = __builtin_ctz(bits_i), cc = cc_i;
+        if (++cc_i == nchunks) { cc_i = 0; bits_i &= bits_i - 1; }
         int coff = cc * KC;
         const bool second = coff >= c0;
         const int csrc = second ? c1 : c0;
         if (second) coff -= c0;
-        const int tp = ph.tap[t];
-        const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+        const int tpv = tp.tap[t];
+        const int dy = (int)(short)(tpv & 0xffff), dx = tpv >> 16;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             const int iy = r_iy[j] + dy, ix = r_ix[j] + dx;
@@ -145,7 +161,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         for (int j = 0; j < B_PER; ++j) {
             if (B_F4 % NT == 0 || (wmi + j * WM) * 64 < B_F4) {   // wave-uniform
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf][A_F4 + (wmi + j * WM) * 64];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[j] + (unsigned)(s * KC)) * 4u, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[j] + (unsigned)((t * nchunks + cc) * KC)) * 4u, 0, 0, 0);
             }
         }
     };
@@ -159,11 +175,16 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     const int r = lane & 31, h = lane >> 5;
     const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
 
-    issue(0, 0);
+    issue(0);
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         __syncthreads();                       // (waits vmcnt(0)) tile s landed; everyone left tile s-1
-        if (s + 1 < nsteps) issue(s + 1, buf ^ 1);   // DMA of the next tile flies under the MFMAs
+        if (s + 1 < nsteps) issue(buf ^ 1);   // DMA of the next tile flies under the MFMAs
+        int groups_now = 0;
+        if constexpr (GROUPED) {
+            groups_now = tp.tap_groups[__builtin_ctz(bits_c)];
+            if (++cc_c == nchunks) { cc_c = 0; bits_c &= bits_c - 1; }
+        }
         const float4* la = &lds[buf][(wmi * 32 + r) * SP];
         const float4* lb = &lds[buf][A_F4 + r * SP];
 #pragma unroll
@@ -172,6 +193,9 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             const float4 av = la[q];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (GROUPED) {
+                    if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
+                }
                 const float4 bv = lb[nb * 32 * SP + q];
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nb], 0, 0, 0);
@@ -182,40 +206,76 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     }
 
     // ------------------------------------------------------------------ epilogue
-    // C layout of 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // C layout of 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Pass A issues ALL of the wave's epilogue operand loads (c_prev / residual / skip) at once, so their HBM/L2
+    // latency is paid once instead of once per element; pass B does the arithmetic and the stores.
     const int epi = a.epi;
+    const bool direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
+    const bool need_yx = !direct || (a.pred_w != nullptr);
+    const int rbase = m0 + wmi * 32 + 4 * h;
+    auto row = [&](int reg, int& e_img, int& e_my, int& e_mx) -> int {
+        const int m = rbase + (reg & 3) + 8 * (reg >> 2);
+        e_img = 0; e_my = 0; e_mx = 0;
+        if (need_yx && m < M) {
+            e_img = m / hw;
+            const int rem = m - e_img * hw;
+            e_my = rem / a.wm; e_mx = rem - e_my * a.wm;
+        }
+        return m;
+    };
+    auto pixel = [&](int m, int e_img, int e_my, int e_mx, int g, int& o_y, int& o_x) -> int64_t {
+        o_y = e_my * a.os + tp.grp_ofy[g]; o_x = e_mx * a.os + tp.grp_ofx[g];
+        return direct ? (int64_t)m : ((int64_t)e_img * a.hout + o_y) * a.wout + o_x;
+    };
+    constexpr int PN = LSTM ? 1 : NB;
+    f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
+    const float* pre_ptr = LSTM ? a.state : (epi == EPI_RESIDUAL_RELU ? a.residual : a.post_add);
+    if (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT) pre_ptr = nullptr;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wmi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (m >= M) continue;
-        int64_t opix;   // output pixel index in [n, hout, wout]
-        if (a.os == 1 && a.hout == a.hm && a.wout == a.wm) {
-            opix = m;
-        } else {
-            const int img = m / hw, rem = m - img * hw;
-            const int my = rem / a.wm, mx = rem - my * a.wm;
-            opix = ((int64_t)img * a.hout + (my * a.os + ph.ofy)) * a.wout + (mx * a.os + ph.ofx);
+        int e_img, e_my, e_mx, o_y, o_x;
+        const int m = row(reg, e_img, e_my, e_mx);
+#pragma unroll
+        for (int nb = 0; nb < PN; ++nb) {
+            float v = 0.f;
+            if (pre_ptr && m < M) {
+                if constexpr (LSTM) {
+                    v = pre_ptr[(int64_t)m * a.hidden + (n0 >> 2) + r];
+                } else {
+                    const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
+                    const int cg = n0 + nb * 32 + r - g * grp_cols;
+                    if (cg < a.n_valid) v = pre_ptr[pixel(m, e_img, e_my, e_mx, g, o_y, o_x) * a.cout_total + cg];
+                }
+            }
+            pre[nb][reg] = v;
         }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        int e_img, e_my, e_mx, o_y, o_x;
+        const int m = row(reg, e_img, e_my, e_mx);
+        if (m >= M) continue;
+        int64_t opix = pixel(m, e_img, e_my, e_mx, 0, o_y, o_x);
         if constexpr (LSTM) {
             static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
-            {
-                const int c = (n0 >> 2) + r;   // hidden channel: N tile of 128 = 4 gates x 32 channels
-                const float gi = sigmoidf_(acc[0][reg] + a.bias[n0 + r]);
-                const float gf = sigmoidf_(acc[1][reg] + a.bias[n0 + 32 + r]);
-                const float go = sigmoidf_(acc[2][reg] + a.bias[n0 + 64 + r]);
-                const float gc = tanhf(acc[3][reg] + a.bias[n0 + 96 + r]);
-                const int64_t o = opix * a.hidden + c;
-                const float cprev = a.state[o];
-                const float cn = __fadd_rn(__fmul_rn(gf, cprev), __fmul_rn(gi, gc));   // submodules.py:242
-                a.state[o] = cn;
-                a.out[o] = go * tanhf(cn);                                            // submodules.py:243
-            }
+            const int c = (n0 >> 2) + r;   // hidden channel: N tile of 128 = 4 gates x 32 channels
+            const float gi = sigmoidf_(acc[0][reg] + a.bias[n0 + r]);
+            const float gf = sigmoidf_(acc[1][reg] + a.bias[n0 + 32 + r]);
+            const float go = sigmoidf_(acc[2][reg] + a.bias[n0 + 64 + r]);
+            const float gc = tanhf(acc[3][reg] + a.bias[n0 + 96 + r]);
+            const int64_t o = opix * a.hidden + c;
+            const float cn = __fadd_rn(__fmul_rn(gf, pre[0][reg]), __fmul_rn(gi, gc));   // submodules.py:242
+            a.state[o] = cn;
+            a.out[o] = go * tanhf(cn);                                                    // submodules.py:243
             continue;
         }
         float pred_part = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = n0 + nb * 32 + r;
+            const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
+            const int cg = n - g * grp_cols;          // channel inside the group
+            if constexpr (GROUPED) opix = pixel(m, e_img, e_my, e_mx, g, o_y, o_x);
             float v = acc[nb][reg] + a.bias[n];
             if (epi == EPI_GRU_ZR) {
                 const int C = a.hidden;
@@ -234,60 +294,71 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                     // submodules.py:285: prev*(1-update) + out*update
                     a.state[o] = __fadd_rn(__fmul_rn(hp, 1.0f - z), __fmul_rn(cand, z));
                 }
-            } else if (n < a.n_valid) {
-                const int64_t o = opix * a.cout_total + n;
-                if (epi == EPI_RESIDUAL_RELU) v += a.residual[o];
+            } else if (cg < a.n_valid) {
+                const int64_t o = opix * a.cout_total + cg;
+                const int pn = LSTM ? 0 : nb;
+                if (epi == EPI_RESIDUAL_RELU) v += pre[pn][reg];
                 if (epi == EPI_BIAS_TANH) v = tanhf(v);
                 else if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
                 if (a.pred_w && a.out) a.out[o] = v;          // debug copy of the layer's own output
-                if (a.post_add) v += a.post_add[o];   // skip_sum fused into the producer (model_util.py:4-5)
+                // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
+                if (a.post_add) v += (epi == EPI_RESIDUAL_RELU) ? a.post_add[o] : pre[pn][reg];
                 if (!a.pred_w && a.out) a.out[o] = v;
-                if (a.pred_w) pred_part = fmaf(v, a.pred_w[n], pred_part);
+                if (a.pred_w) pred_part = fmaf(v, a.pred_w[cg], pred_part);
             }
-        }
-        if (a.pred_w) {   // fused 1x1 prediction conv: reduce over the 32 channel lanes of this half-wave
+            // fused 1x1 prediction conv: the group's last 32-column block closes one output pixel
+            if (a.pred_w && ((n0 + nb * 32 + 32) % grp_cols) == 0) {
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) pred_part += __shfl_xor(pred_part, o, 64);
-            if (r == 0) {
-                const int hwo = a.hout * a.wout;
-                const int im = (int)(opix / hwo), rem = (int)(opix - (int64_t)im * hwo);
-                const int y = rem / a.wout - a.crop_y0, x = rem % a.wout - a.crop_x0;
-                float sres = pred_part + a.pred_b;
-                if (a.pred_sigmoid) sres = sigmoidf_(sres);
-                if (a.prev_rec) a.prev_rec[opix] = sres;
-                if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w) {
-                    img_out[((int64_t)im * a.crop_h + y) * a.crop_w + x] = sres;
+                for (int o = 16; o > 0; o >>= 1) pred_part += __shfl_xor(pred_part, o, 64);
+                if (r == 0) {
+                    const int y = o_y - a.crop_y0, x = o_x - a.crop_x0;
+                    float sres = pred_part + a.pred_b;
+                    if (a.pred_sigmoid) sres = sigmoidf_(sres);
+                    if (a.prev_rec) a.prev_rec[opix] = sres;
+                    if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
+                        img_out[((int64_t)e_img * a.crop_h + y) * a.crop_w + x] = sres;
                 }
+                pred_part = 0.f;
             }
         }
     }
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KC, int WM, int NB, bool LSTM>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
-    const int total = mtiles * ntiles * a.nphases;
-    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    const int total = mtiles * ntiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM, GROUPED>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
     EVR_REQUIRE(!a.pred_w || (a.cout == 32 * nb && img), "conv_igemm: fused prediction needs a single N tile and an image pointer");
+    EVR_REQUIRE(a.tp.grp_cols % 32 == 0 && a.tp.ngroups * a.tp.grp_cols == a.cout && a.tp.ngroups <= MAX_PHASES, "conv_igemm: bad column groups");
     EVR_REQUIRE(a.cout % (32 * nb) == 0, "conv_igemm: cout %d not a multiple of %d", a.cout, 32 * nb);
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
-        if (wm == 4) return launch_t<32, 4, 4, true>(a, d_args, stream, img);
-        if (wm == 2) return launch_t<32, 2, 4, true>(a, d_args, stream, img);
-        return launch_t<32, 1, 4, true>(a, d_args, stream, img);
+        if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
+        if (wm == 4) return launch_t<32, 4, 4, true, false>(a, d_args, stream, img);
+        if (wm == 2) return launch_t<32, 2, 4, true, false>(a, d_args, stream, img);
+        return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
     }
-#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false>(a, d_args, stream, img);
+    if (a.tp.ngroups > 1) {   // transposed conv: column groups = sub-pixel phases
+#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img);
+        EVR_CASEG(4, 4) EVR_CASEG(2, 4) EVR_CASEG(1, 4) EVR_CASEG(4, 2) EVR_CASEG(2, 2) EVR_CASEG(1, 2)
+        EVR_CASEG(4, 1) EVR_CASEG(2, 1) EVR_CASEG(1, 1)
+#undef EVR_CASEG
+        set_error("conv_igemm: no grouped kernel for kc=%d wm=%d nb=%d", kc, wm, nb);
+        return EVR_ERR_UNSUPPORTED;
+    }
+#define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false, false>(a, d_args, stream, img);
     EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
     EVR_CASE(32, 4, 2) EVR_CASE(32, 2, 2) EVR_CASE(32, 1, 2)
     EVR_CASE(32, 4, 1) EVR_CASE(32, 2, 1) EVR_CASE(32, 1, 1)
@@ -304,8 +375,9 @@ void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb) {
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
     const int ntiles = a.cout / (32 * n_b);
     int w = 4;
+    if (a.epi == EPI_LSTM && getenv("EVR_LSTM_WM8")) w = 8;   // experiment: 256x128 block tile
     // shrink the M tile until the launch has >= 2 workgroups per CU (256 CUs) or the tile is one wave
-    while (w > 1 && ((M + 32 * w - 1) / (32 * w)) * ntiles * a.nphases < 512) w >>= 1;
+    while (w > 1 && ((M + 32 * w - 1) / (32 * w)) * ntiles < 512) w >>= 1;
     *wm = w; *nb = n_b;
 }
 

@@ -46,8 +46,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
     int k = 3, stride = 1;
     bool transposed = false;
     int epi = EPI_BIAS, hidden = 0;
-    int nphases = 1;
-    ConvPhase ph[MAX_PHASES];
+    ConvTaps tp;
+    double useful_taps = 0;   // (tap, group) pairs that carry weights (direct-conv FLOP accounting)
     std::vector<float> w, b;    // host, prepared layout
     float* d_w = nullptr; float* d_b = nullptr;
     // per shape
@@ -185,44 +185,61 @@ int prep_conv2d(Conv& c, const HostTensor* w, const Affine& af, int cout, int ci
             for (int t = 0; t < taps; ++t)
                 c.w[((size_t)row * taps + t) * cin + ci] = (float)((double)w->data[((size_t)co * cin + ci) * taps + t] * af.scale[co]);
     }
-    c.nphases = 1;
-    c.ph[0].ntaps = taps; c.ph[0].w_off = 0; c.ph[0].ofy = 0; c.ph[0].ofx = 0;
+    memset(&c.tp, 0, sizeof(c.tp));
+    c.tp.ntaps = taps; c.tp.ngroups = 1; c.tp.grp_cols = n_gemm;
     for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx) c.ph[0].set_tap(ky * k + kx, ky - pad, kx - pad);
+        for (int kx = 0; kx < k; ++kx) c.tp.set_tap(ky * k + kx, ky - pad, kx - pad, 1);
+    c.useful_taps = taps;
     c.n_gemm = n_gemm; c.k = k;
     return EVR_OK;
 }
 
-// ConvTranspose2d(k, stride 2, padding pad, output_padding 1) weight [cin, cout, k, k] -> four sub-pixel phases.
-// out[2my+py] takes ky with (py + pad - ky) even, from input row my + (py + pad - ky)/2.
-int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout, int k, int pad, int n_gemm) {
+// ConvTranspose2d(k, stride 2, padding pad, output_padding 1) weight [cin, cout, k, k] -> ONE GEMM whose columns are
+// phase-major: group g = py*2+px holds the Cout channels of output pixels (2my+py, 2mx+px).
+// out[2my+py] takes ky with (py + pad - ky) even, from input row my + (py + pad - ky)/2; the union of those input
+// offsets over the four phases is the shared tap list (3x3 for k = 5), tap_groups marks which phases use a tap.
+int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout, int k, int pad, int grp_cols) {
     EVR_REQUIRE(w->ndim == 4 && w->shape[0] == cin && w->shape[1] == cout && w->shape[2] == k && w->shape[3] == k,
                 "'%s': transposed weight shape mismatch", c.name.c_str());
-    c.w.clear();
-    c.b.assign(n_gemm, 0.f);
-    for (int co = 0; co < cout; ++co) c.b[co] = (float)af.shift[co];
-    c.nphases = 4;
+    memset(&c.tp, 0, sizeof(c.tp));
+    c.tp.ngroups = 4; c.tp.grp_cols = grp_cols;
+    // shared taps
+    std::vector<std::pair<int, int>> taps;
+    auto tap_index = [&](int dy, int dx) {
+        for (size_t i = 0; i < taps.size(); ++i) if (taps[i].first == dy && taps[i].second == dx) return (int)i;
+        taps.push_back({dy, dx});
+        return (int)taps.size() - 1;
+    };
+    struct Use { int g, t, ky, kx; };
+    std::vector<Use> uses;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            ConvPhase& ph = c.ph[py * 2 + px];
-            ph.ntaps = 0; ph.ofy = py; ph.ofx = px; ph.w_off = (int)c.w.size();
-            std::vector<std::pair<int, int>> kk;
+            c.tp.grp_ofy[py * 2 + px] = py; c.tp.grp_ofx[py * 2 + px] = px;
             for (int ky = 0; ky < k; ++ky) {
                 if (((py + pad - ky) & 1) != 0) continue;
                 for (int kx = 0; kx < k; ++kx) {
                     if (((px + pad - kx) & 1) != 0) continue;
-                    ph.set_tap(ph.ntaps++, (py + pad - ky) / 2, (px + pad - kx) / 2);
-                    kk.push_back({ky, kx});
+                    uses.push_back({py * 2 + px, tap_index((py + pad - ky) / 2, (px + pad - kx) / 2), ky, kx});
                 }
             }
-            const size_t base = c.w.size();
-            c.w.resize(base + (size_t)n_gemm * ph.ntaps * cin, 0.f);
-            for (int co = 0; co < cout; ++co)
-                for (int t = 0; t < ph.ntaps; ++t)
-                    for (int ci = 0; ci < cin; ++ci)
-                        c.w[base + ((size_t)co * ph.ntaps + t) * cin + ci] =
-                            (float)((double)w->data[(((size_t)ci * cout + co) * k + kk[t].first) * k + kk[t].second] * af.scale[co]);
         }
+    EVR_REQUIRE((int)taps.size() <= MAX_TAPS, "transposed conv: too many taps");
+    const int nt = (int)taps.size();
+    c.tp.ntaps = nt;
+    for (int t = 0; t < nt; ++t) c.tp.set_tap(t, taps[t].first, taps[t].second, 0);
+    const int n_gemm = 4 * grp_cols;
+    c.w.assign((size_t)n_gemm * nt * cin, 0.f);
+    c.b.assign(n_gemm, 0.f);
+    for (int g = 0; g < 4; ++g)
+        for (int co = 0; co < cout; ++co) c.b[g * grp_cols + co] = (float)af.shift[co];
+    for (const Use& u : uses) {
+        c.tp.tap_groups[u.t] |= 1 << u.g;
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                c.w[((size_t)(u.g * grp_cols + co) * nt + u.t) * cin + ci] =
+                    (float)((double)w->data[(((size_t)ci * cout + co) * k + u.ky) * k + u.kx] * af.scale[co]);
+    }
+    c.useful_taps = (double)uses.size() / 4.0;   // per output pixel of one phase on average: k*k/4
     c.n_gemm = n_gemm; c.k = k; c.transposed = true;
     return EVR_OK;
 }
@@ -451,16 +468,15 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.n = n; a.hin = hin; a.win = win;
         if (c.transposed) { a.hm = hin; a.wm = win; a.stride = 1; a.os = 2; a.hout = 2 * hin; a.wout = 2 * win; }
         else { a.hm = hin / c.stride; a.wm = win / c.stride; a.stride = c.stride; a.os = 1; a.hout = a.hm; a.wout = a.wm; }
-        a.nphases = c.nphases;
-        for (int i = 0; i < c.nphases; ++i) a.ph[i] = c.ph[i];
+        a.tp = c.tp;
         a.wgt = c.d_w; a.bias = c.d_b; a.cout = c.n_gemm; a.n_valid = c.n_valid;
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden;
     }
     pick_conv_tile(c.args[0], c.kc, &c.wm, &c.nb);
-    double taps = 0;
-    for (int i = 0; i < c.nphases; ++i) taps += c.ph[i].ntaps;
+    // direct-conv FLOPs: a transposed conv counts its k*k taps once per INPUT pixel (= k*k/4 per output pixel x 4 phases)
+    const double taps = c.transposed ? c.useful_taps * 4.0 : c.useful_taps;
     c.flops = 2.0 * (double)n * c.args[0].hm * c.args[0].wm * taps * (c.cin0 + c.cin1) * c.n_valid;
     m->flops += c.flops;
 }
