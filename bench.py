@@ -8,8 +8,8 @@
 
 A step = one frame for each of S independent synthetic sequences per GPU (sequences shard across GPUs,
 SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
-forward (fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM against the
-reference frame.  LPIPS is not built yet and is NOT part of the step (stated in config.workload).
+forward (fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM + LPIPS against the
+reference frame (LPIPS = AlexNet v0.1 structure on synthetic weights: the real ones cannot be downloaded here).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -48,13 +48,13 @@ def build_inputs(rank, n_seq, n_steps, device):
     return d(xy.reshape(-1, 2)), d(ts.reshape(-1)), d(pol.reshape(-1)), d(offs), d(refs), (xy, ts, pol, refs)
 
 
-def cpu_baseline(host_inputs, sd, kw, n_frames, budget_s=25.0):
+def cpu_baseline(host_inputs, sd, kw, n_frames, budget_s=25.0, lpips_sd=None):
     """Oracle ("port") timed on the host cores, batch 1 like the reference: C voxelizer (1 thread) + numpy
-    normalization + torch-CPU E2VID forward + numpy percentile + MSE + scipy SSIM.  BOUNDED: the torch thread
+    normalization + torch-CPU E2VID forward + numpy percentile + MSE + scipy SSIM + torch-CPU LPIPS.  BOUNDED: the torch thread
     count is the faster of {8, 32} (capped by the core count; all 256 threads of the GPU box's host run this
     batch-1 network ~100x slower), then frames run until `n_frames` or ~`budget_s` seconds are used."""
     import ctypes
-    from oracle import model as omod, prepost as op, metrics as omet
+    from oracle import model as omod, prepost as op, metrics as omet, lpips as olp
     from evreal_amd import synth
     xy, ts, pol, refs = host_inputs
     lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
@@ -80,6 +80,9 @@ def cpu_baseline(host_inputs, sd, kw, n_frames, budget_s=25.0):
         t4 = time.perf_counter()
         a, b = omet.clip01(img), omet.clip01(refs[0])
         omet.mse(a, b); omet.ssim(a, b)
+        if lpips_sd is not None:
+            with torch.no_grad():
+                olp.lpips(lpips_sd, a[None], b[None])
         t5 = time.perf_counter()
         return (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)
 
@@ -132,6 +135,7 @@ def main():
     from evreal_amd import model, weights
     from evreal_amd.pipeline import HotPath
     from evreal_amd.dist import reduce_metric_sums
+    from evreal_amd.lpips import LPIPS
 
     kw = dict(weights.E2VID_KWARGS)
     sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
@@ -139,9 +143,10 @@ def main():
     net.load_state_dict(sd)
     n_seq, K, Wm = args.n_seq, args.steps, args.warmup
     xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, K + Wm, device)
+    lp = LPIPS(weights.synth_lpips_state_dict(seed=0))
     hp = HotPath(net, BINS, (H_, W_), n_seq, event_tensor_normalization=True, post_process_norm='robust',
-                 metrics=('mse', 'ssim'), device=str(device))
-    scores = torch.zeros((K + Wm, n_seq, 2), dtype=torch.float64, device=device)
+                 metrics=('mse', 'ssim', 'lpips'), device=str(device), lpips=lp)
+    scores = torch.zeros((K + Wm, n_seq, 3), dtype=torch.float64, device=device)
 
     def barrier():
         if dist is not None:
@@ -161,9 +166,10 @@ def main():
     net.profile(None)
 
     # metric aggregation exactly as MetricTracker.update (eval.py:259-266): sum(mean*count), count
-    sc = scores[Wm:].cpu().numpy()                       # [K, n_seq, 2]
+    sc = scores[Wm:].cpu().numpy()                       # [K, n_seq, 3]
     seq_mean = sc.mean(axis=0)                           # per sequence
-    sums = np.array([[seq_mean[:, 0].sum() * K, seq_mean[:, 1].sum() * K, n_seq * K]], dtype=np.float64)
+    sums = np.array([[seq_mean[:, 0].sum() * K, seq_mean[:, 1].sum() * K, seq_mean[:, 2].sum() * K, n_seq * K]],
+                    dtype=np.float64)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -192,11 +198,13 @@ def main():
             "model_tflops": round(flops_step * K * world / elapsed / 1e12, 2),
             "config": {"workload": "E2VID (synthetic weights, BN folded) on synthetic 346x260 Poisson events, 5 bins, "
                                    "15k events/window (k_events), %d sequences per GPU advanced together; per frame: "
-                                   "voxelize(raw)+event-tensor norm+pad+forward+crop+robust norm+clip+MSE+SSIM "
-                                   "(LPIPS not built yet, not in the step)" % n_seq,
+                                   "voxelize(raw)+event-tensor norm+pad+forward+crop+robust norm+clip+MSE+SSIM+LPIPS "
+                                   "(LPIPS: AlexNet-v0.1 structure, synthetic weights)" % n_seq,
                        "sequences_per_gpu": n_seq, "events_per_window": K_EVENTS, "sensor": [W_, H_], "bins": BINS,
-                       "gflop_per_frame": round(flops_step / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
-                       "scores": {"mse": tot[0, 0] / tot[0, 2], "ssim": tot[0, 1] / tot[0, 2], "count": int(tot[0, 2])}},
+                       "gflop_per_frame": round(flops_step / n_seq / 1e9, 3),
+                       "lpips_gflop_per_frame": round(lp.flops() / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
+                       "scores": {"mse": tot[0, 0] / tot[0, 3], "ssim": tot[0, 1] / tot[0, 3], "lpips": tot[0, 2] / tot[0, 3],
+                                  "count": int(tot[0, 3])}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc,
                          "kernel": "conv_igemm_kernel<32,WM,4,LSTM=true> (ConvLSTM gate convolutions)",
@@ -207,7 +215,8 @@ def main():
                                     for p in prof}},
         }
         if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(host_inputs, sd, kw, args.cpu_frames)
+            out["cpu_baseline"] = cpu_baseline(host_inputs, sd, kw, args.cpu_frames,
+                                               lpips_sd=weights.synth_lpips_state_dict(seed=0))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -1,0 +1,320 @@
+// LPIPS (AlexNet, v0.1) on gfx950 -- the 'lpips' metric of the reference (utils/eval_metrics.py:100-156:
+// pyiqa.create_metric('lpips') on [n,3,H,W] batches built by cv2torch(img, num_ch=3), eval_utils.py:46-54).
+//
+// PARITY UNPINNED: pyiqa is neither in the reference tree nor installed, and its AlexNet + linear-head weights are
+// downloaded at run time (unobtainable offline).  The arithmetic below follows the published algorithm (Zhang et
+// al. 2018; richzhang/PerceptualSimilarity v0.1 as wrapped by pyiqa): x <- 2x-1; (x-shift)/scale per channel;
+// AlexNet features after relu1..relu5; unit-normalise every pixel's feature vector (eps 1e-10); squared
+// difference; non-negative 1x1 "lin" weights; spatial mean; sum over the five layers.  Scores therefore agree with
+// the oracle restatement (oracle/lpips.py) on any weights, and with pyiqa only once its weights are supplied.
+//
+// Layers: conv1 (3->64, k11 s4 p2) is a direct VALU kernel on the gray input (the three input channels are affine
+// in the same gray value); conv2..conv5 run on the fp32-MFMA implicit-GEMM kernel of conv.hip; 3x3/2 max pools and
+// the per-layer score are NHWC streaming kernels (one wave per pixel for the channel norms).
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+using namespace evr;
+
+namespace {
+
+// ---- conv1: gray [n2,H,W] -> NHWC [n2,h1,w1,64], relu ------------------------------------------------------------
+struct Conv1Args {
+    const float* img; const float* ref;   // [n,H,W] each; batch index >= n reads ref
+    int n, H, W, h1, w1, clip;
+    const float* wgt;                      // [3*121][64]
+    const float* bias;
+    float shift[3], scale[3];
+    float* out;
+};
+
+__global__ __launch_bounds__(256) void lpips_conv1_kernel(const Conv1Args a) {
+    constexpr int TS = 16, K = 11, S = 4, P = 2, IS = (TS - 1) * S + K;   // 71
+    extern __shared__ float tile[];   // [3][IS][IS] scaled input, zero where the conv pads
+    const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
+    const float* src = (b < a.n ? a.img + (int64_t)b * a.H * a.W : a.ref + (int64_t)(b - a.n) * a.H * a.W);
+    for (int i = tid; i < IS * IS; i += 256) {
+        const int rr = i / IS, cc = i % IS;
+        const int y = ty0 * S + rr - P, x = tx0 * S + cc - P;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
+            float g = src[(int64_t)y * a.W + x];
+            if (a.clip) g = fminf(fmaxf(g, 0.f), 1.f);
+            const float t = 2.f * g - 1.f;
+            v0 = (t - a.shift[0]) / a.scale[0]; v1 = (t - a.shift[1]) / a.scale[1]; v2 = (t - a.shift[2]) / a.scale[2];
+        }
+        tile[i] = v0; tile[IS * IS + i] = v1; tile[2 * IS * IS + i] = v2;
+    }
+    __syncthreads();
+    const int ly = tid / TS, lx = tid % TS, oy = ty0 + ly, ox = tx0 + lx;
+    float acc[64];
+#pragma unroll
+    for (int co = 0; co < 64; ++co) acc[co] = a.bias[co];
+    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                const float v = tile[(c * IS + ly * S + ky) * IS + lx * S + kx];
+                const float* w = a.wgt + ((c * K + ky) * K + kx) * 64;     // wave-uniform -> scalar loads
+#pragma unroll
+                for (int co = 0; co < 64; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+            }
+    if (oy < a.h1 && ox < a.w1) {
+        float* o = a.out + (((int64_t)b * a.h1 + oy) * a.w1 + ox) * 64;
+#pragma unroll
+        for (int co = 0; co < 64; co += 4)
+            *(float4*)(o + co) = make_float4(fmaxf(acc[co], 0.f), fmaxf(acc[co + 1], 0.f), fmaxf(acc[co + 2], 0.f), fmaxf(acc[co + 3], 0.f));
+    }
+}
+
+// ---- max pool 3x3 stride 2 (no padding), NHWC --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w,
+                                                          int c, int ho, int wo) {
+    const int c4n = c / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * ho * wo * c4n) return;
+    const int c4 = (int)(i % c4n); int64_t p = i / c4n;
+    const int ox = (int)(p % wo); p /= wo;
+    const int oy = (int)(p % ho);
+    const int b = (int)(p / ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            const float4 v = *(const float4*)(in + (((int64_t)b * h + 2 * oy + ky) * w + 2 * ox + kx) * c + c4 * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    *(float4*)(out + (((int64_t)b * ho + oy) * wo + ox) * c + c4 * 4) = m;
+}
+
+// ---- per-layer score: one wave per pixel -------------------------------------------------------------------------
+// feat: NHWC [2n, h, w, C] (first n = img, last n = ref); out partial[n][blocks] of sum over pixels
+__global__ __launch_bounds__(256) void lpips_score_kernel(const float* __restrict__ feat, const float* __restrict__ lin, int n, int hw,
+                                                           int C, double* __restrict__ partials, int blocks_per_img) {
+    __shared__ double red[4];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* f0 = feat + (int64_t)b * hw * C;
+    const float* f1 = feat + (int64_t)(b + n) * hw * C;
+    double acc = 0.0;
+    for (int p = blockIdx.x * 4 + wave; p < hw; p += blocks_per_img * 4) {
+        float a[6], c[6];                      // C <= 384
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int ch = lane + 64 * k;
+            a[k] = (ch < C) ? f0[(int64_t)p * C + ch] : 0.f;
+            c[k] = (ch < C) ? f1[(int64_t)p * C + ch] : 0.f;
+            s0 = fmaf(a[k], a[k], s0); s1 = fmaf(c[k], c[k], s1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        const float n0 = sqrtf(s0) + 1e-10f, n1 = sqrtf(s1) + 1e-10f;
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < C) { const float e = a[k] / n0 - c[k] / n1; d = fmaf(lin[ch], e * e, d); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        acc += (double)d;
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(int64_t)b * blocks_per_img + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ void lpips_final_kernel(const double* __restrict__ partials, double* __restrict__ out, int blocks_per_img, int nlayers,
+                                   int n, const int* __restrict__ hw) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    double total = 0.0;
+    for (int l = 0; l < nlayers; ++l) {
+        double s = 0.0;
+        for (int k = 0; k < blocks_per_img; ++k) s += partials[((int64_t)l * n + b) * blocks_per_img + k];
+        total += s / (double)hw[l];
+    }
+    out[b] = total;
+}
+
+constexpr int SCORE_BLOCKS = 32;
+
+struct Layer { int cin, cout, k, pad; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
+
+}  // namespace
+
+struct evr_lpips {
+    // conv1 (direct) + 4 igemm layers
+    std::vector<float> w1, b1;
+    float* d_w1 = nullptr; float* d_b1 = nullptr;
+    float* d_lin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    Layer L[4];
+    // shape-dependent
+    int n = 0, H = 0, W = 0;
+    int h[5], w[5];              // feature map sizes of relu1..relu5
+    std::vector<void*> allocs;
+    float* feat[5] = {}; float* pool1 = nullptr; float* pool2 = nullptr;
+    ConvArgs args[4]; ConvArgs* d_args = nullptr; int wm[4], nb[4];
+    double* partials = nullptr; int* d_hw = nullptr;
+    void release() { for (void* p : allocs) (void)hipFree(p); allocs.clear(); n = 0; d_args = nullptr; }
+    ~evr_lpips() {
+        release();
+        if (d_w1) (void)hipFree(d_w1); if (d_b1) (void)hipFree(d_b1);
+        for (auto& p : d_lin) if (p) (void)hipFree(p);
+        for (auto& l : L) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+    }
+};
+
+namespace {
+int up(const std::vector<float>& h, float** d) {
+    EVR_HIP(hipMalloc((void**)d, h.size() * sizeof(float) + 64));
+    EVR_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return EVR_OK;
+}
+template <typename T>
+int dalloc(evr_lpips* m, T** p, size_t count) {
+    EVR_HIP(hipMalloc((void**)p, count * sizeof(T) + 256));
+    m->allocs.push_back((void*)*p);
+    return EVR_OK;
+}
+}  // namespace
+
+extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lpips** out) {
+    EVR_REQUIRE(tensors && out, "evr_lpips_create: null argument");
+    std::map<std::string, const evr_tensor*> sd;
+    for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) sd[tensors[i].name] = &tensors[i];
+    auto get = [&](const std::string& k, int64_t numel, const evr_tensor** t) -> int {
+        auto it = sd.find(k);
+        if (it == sd.end()) { set_error("LPIPS state_dict is missing '%s'", k.c_str()); return EVR_ERR_MISSING_TENSOR; }
+        int64_t ne = 1; for (int d = 0; d < it->second->ndim; ++d) ne *= it->second->shape[d];
+        if (ne != numel) { set_error("LPIPS tensor '%s' has %lld elements, expected %lld", k.c_str(), (long long)ne, (long long)numel); return EVR_ERR_INVALID; }
+        *t = it->second; return EVR_OK;
+    };
+    evr_lpips* m = new evr_lpips();
+    int rc = EVR_OK;
+    const evr_tensor *w, *b;
+    // torchvision alexnet.features indices 0,3,6,8,10 inside pyiqa's slices
+    const char* names[5] = {"net.slice1.0", "net.slice2.3", "net.slice3.6", "net.slice4.8", "net.slice5.10"};
+    const int cin[5] = {3, 64, 192, 384, 256}, cout[5] = {64, 192, 384, 256, 256}, ks[5] = {11, 5, 3, 3, 3};
+    do {
+        if ((rc = get(std::string(names[0]) + ".weight", 64 * 3 * 121, &w))) break;
+        if ((rc = get(std::string(names[0]) + ".bias", 64, &b))) break;
+        m->w1.assign((size_t)3 * 121 * 64, 0.f); m->b1.assign(b->data_host, b->data_host + 64);
+        for (int co = 0; co < 64; ++co) for (int c = 0; c < 3; ++c) for (int t = 0; t < 121; ++t)
+            m->w1[((size_t)c * 121 + t) * 64 + co] = w->data_host[((size_t)co * 3 + c) * 121 + t];
+        if ((rc = up(m->w1, &m->d_w1))) break;
+        if ((rc = up(m->b1, &m->d_b1))) break;
+        for (int l = 1; l < 5 && !rc; ++l) {
+            Layer& L = m->L[l - 1];
+            L.cin = cin[l]; L.cout = cout[l]; L.k = ks[l]; L.pad = ks[l] / 2;
+            const int taps = L.k * L.k;
+            if ((rc = get(std::string(names[l]) + ".weight", (int64_t)cout[l] * cin[l] * taps, &w))) break;
+            if ((rc = get(std::string(names[l]) + ".bias", cout[l], &b))) break;
+            L.w.assign((size_t)cout[l] * taps * cin[l], 0.f); L.b.assign(b->data_host, b->data_host + cout[l]);
+            for (int co = 0; co < cout[l]; ++co) for (int ci = 0; ci < cin[l]; ++ci) for (int t = 0; t < taps; ++t)
+                L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
+            if ((rc = up(L.w, &L.d_w))) break;
+            if ((rc = up(L.b, &L.d_b))) break;
+        }
+        if (rc) break;
+        for (int l = 0; l < 5 && !rc; ++l) {
+            if ((rc = get("lin" + std::to_string(l) + ".model.1.weight", cout[l], &w))) break;
+            std::vector<float> lw(w->data_host, w->data_host + cout[l]);
+            rc = up(lw, &m->d_lin[l]);
+        }
+    } while (0);
+    if (rc) { delete m; return rc; }
+    *out = m;
+    return EVR_OK;
+}
+
+extern "C" int evr_lpips_destroy(evr_lpips* m) { delete m; return EVR_OK; }
+
+static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
+    EVR_HIP(hipStreamSynchronize(stream));
+    m->release();
+    m->n = n; m->H = H; m->W = W;
+    const int n2 = 2 * n;
+    m->h[0] = (H + 4 - 11) / 4 + 1; m->w[0] = (W + 4 - 11) / 4 + 1;
+    const int hp1 = (m->h[0] - 3) / 2 + 1, wp1 = (m->w[0] - 3) / 2 + 1;
+    m->h[1] = hp1; m->w[1] = wp1;
+    const int hp2 = (hp1 - 3) / 2 + 1, wp2 = (wp1 - 3) / 2 + 1;
+    for (int l = 2; l < 5; ++l) { m->h[l] = hp2; m->w[l] = wp2; }
+    EVR_REQUIRE(hp2 >= 1 && wp2 >= 1, "evr_lpips: image %dx%d too small for AlexNet", W, H);
+    const int C[5] = {64, 192, 384, 256, 256};
+    int rc;
+    for (int l = 0; l < 5; ++l) if ((rc = dalloc(m, &m->feat[l], (size_t)n2 * m->h[l] * m->w[l] * C[l]))) return rc;
+    if ((rc = dalloc(m, &m->pool1, (size_t)n2 * hp1 * wp1 * 64))) return rc;
+    if ((rc = dalloc(m, &m->pool2, (size_t)n2 * hp2 * wp2 * 192))) return rc;
+    if ((rc = dalloc(m, &m->partials, (size_t)5 * n * SCORE_BLOCKS))) return rc;
+    if ((rc = dalloc(m, &m->d_hw, 8))) return rc;
+    int hw[5]; for (int l = 0; l < 5; ++l) hw[l] = m->h[l] * m->w[l];
+    EVR_HIP(hipMemcpy(m->d_hw, hw, sizeof(hw), hipMemcpyHostToDevice));
+    const float* ins[4] = {m->pool1, m->pool2, m->feat[2], m->feat[3]};
+    const int hin[4] = {hp1, hp2, hp2, hp2}, win[4] = {wp1, wp2, wp2, wp2};
+    for (int i = 0; i < 4; ++i) {
+        Layer& L = m->L[i];
+        ConvArgs& a = m->args[i];
+        memset(&a, 0, sizeof(a));
+        a.in0 = ins[i]; a.c0 = L.cin; a.in_mode = IN_SINGLE; a.n = n2; a.hin = hin[i]; a.win = win[i];
+        a.hm = hin[i]; a.wm = win[i]; a.stride = 1; a.os = 1; a.hout = hin[i]; a.wout = win[i];
+        a.tp.ntaps = L.k * L.k; a.tp.ngroups = 1; a.tp.grp_cols = L.cout;
+        for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
+        a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
+        a.epi = EPI_BIAS_RELU;
+        pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
+    }
+    EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));
+    m->allocs.push_back((void*)m->d_args);
+    EVR_HIP(hipMemcpy(m->d_args, m->args, 4 * sizeof(ConvArgs), hipMemcpyHostToDevice));
+    return EVR_OK;
+}
+
+extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* ref, int n, int H, int W, int clip, double* out,
+                                 evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    EVR_REQUIRE(m && img && ref && out && n >= 1 && H >= 1 && W >= 1, "evr_lpips_forward: bad argument");
+    int rc;
+    if (m->n != n || m->H != H || m->W != W) if ((rc = lpips_plan(m, n, H, W, stream))) return rc;
+    const int n2 = 2 * n;
+    Conv1Args c1{};
+    c1.img = img; c1.ref = ref; c1.n = n; c1.H = H; c1.W = W; c1.h1 = m->h[0]; c1.w1 = m->w[0]; c1.clip = clip;
+    c1.wgt = m->d_w1; c1.bias = m->d_b1; c1.out = m->feat[0];
+    const float shift[3] = {-.030f, -.088f, -.188f}, scale[3] = {.458f, .448f, .450f};
+    for (int c = 0; c < 3; ++c) { c1.shift[c] = shift[c]; c1.scale[c] = scale[c]; }
+    static bool attr = false;
+    const size_t lds1 = (size_t)3 * 71 * 71 * sizeof(float);
+    if (!attr) { EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
+    EVR_LAUNCH_CHECK();
+    auto pool = [&](const float* in, float* o, int h, int w, int c, int ho, int wo) -> int {
+        const int64_t total = (int64_t)n2 * ho * wo * (c / 4);
+        hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, o, n2, h, w, c, ho, wo);
+        EVR_LAUNCH_CHECK();
+        return EVR_OK;
+    };
+    if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1]))) return rc;
+    if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
+    if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2]))) return rc;
+    for (int i = 1; i < 4; ++i)
+        if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
+    const int C[5] = {64, 192, 384, 256, 256};
+    for (int l = 0; l < 5; ++l) {
+        hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n), dim3(256), 0, stream, m->feat[l], m->d_lin[l], n,
+                           m->h[l] * m->w[l], C[l], m->partials + (size_t)l * n * SCORE_BLOCKS, SCORE_BLOCKS);
+        EVR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(lpips_final_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, m->partials, out, SCORE_BLOCKS, 5, n, m->d_hw);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+extern "C" double evr_lpips_flops(const evr_lpips* m) {
+    if (!m || m->n == 0) return 0.0;
+    const int cin[5] = {3, 64, 192, 384, 256}, cout[5] = {64, 192, 384, 256, 256}, ks[5] = {11, 5, 3, 3, 3};
+    double f = 0.0;
+    for (int l = 0; l < 5; ++l) f += 2.0 * (2.0 * m->n) * m->h[l] * m->w[l] * cin[l] * cout[l] * ks[l] * ks[l];
+    return f;
+}

@@ -15,6 +15,16 @@ import torch
 from .prepost import Metrics
 
 GPU_METRICS = ('mse', 'ssim')
+LPIPS_WEIGHTS_ENV = 'EVREAL_LPIPS_WEIGHTS'      # path to a pyiqa/lpips AlexNet-v0.1 state_dict (torch.save'd)
+
+
+def _load_lpips():
+    """The reference lets pyiqa download the LPIPS weights; offline they must be supplied as a file."""
+    path = os.environ.get(LPIPS_WEIGHTS_ENV, os.path.join('pretrained', 'lpips_alex.pth'))
+    if not os.path.exists(path):
+        return None
+    from .lpips import LPIPS
+    return LPIPS(torch.load(path, map_location='cpu', weights_only=False))
 
 
 class BaseMetric:
@@ -55,6 +65,8 @@ class EvalMetricsTracker:
         for name in quan_eval_metric_names:
             if name in GPU_METRICS:
                 self.metrics.append(BaseMetric(name))
+            elif name == 'lpips' and (self._lpips_model() is not None):
+                self.metrics.append(BaseMetric(name))
             else:
                 print("Unknown metric " + name)     # utils/eval_metrics.py:203 (LPIPS/pyiqa: not built yet)
         if not self.has_reference_frames:
@@ -62,6 +74,17 @@ class EvalMetricsTracker:
         self.only_no_ref = all(m.no_ref for m in self.metrics)
         self._gpu = Metrics()
         self.reset()
+
+    _lpips_cache = [False, None]
+
+    @classmethod
+    def _lpips_model(cls):
+        if not cls._lpips_cache[0]:
+            cls._lpips_cache = [True, _load_lpips()]
+            if cls._lpips_cache[1] is None:
+                print(f"lpips: no weights at ${LPIPS_WEIGHTS_ENV} or pretrained/lpips_alex.pth (pyiqa downloads them; "
+                      "offline they must be provided) -> metric skipped")
+        return cls._lpips_cache[1]
 
     # -- files --------------------------------------------------------------------------------
     def reset(self):
@@ -108,8 +131,11 @@ class EvalMetricsTracker:
                            clip=True).cpu().numpy()
         idxs = [indices[j] for j in sel]
         self.quan_eval_indices.extend(idxs)
+        lp = None
+        if 'lpips' in want:
+            lp = self._lpips_model()(imgs[js].contiguous(), refs[js].contiguous(), clip=True).cpu().numpy()
         for m in self.metrics:
-            col = scores[:, 0] if m.name == 'mse' else scores[:, 1]
+            col = scores[:, 0] if m.name == 'mse' else scores[:, 1] if m.name == 'ssim' else lp
             finite = [(i, float(s)) for i, s in zip(idxs, col) if math.isfinite(s)]
             m.add(col)
             self._append(join(self.output_dir, m.name + '.txt'), finite)

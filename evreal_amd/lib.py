@@ -60,6 +60,10 @@ SYMBOLS = {
     'evr_metrics': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
     'evr_metrics_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'evr_lpips_create': (c_int, [ctypes.POINTER(Tensor), c_int, ctypes.POINTER(c_void_p)]),
+    'evr_lpips_destroy': (c_int, [c_void_p]),
+    'evr_lpips_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'evr_lpips_flops': (c_double, [c_void_p]),
 }
 
 _lib = None

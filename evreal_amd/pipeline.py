@@ -1,7 +1,7 @@
 """The per-frame hot loop of eval.py:203-238 for a batch of independent sequences, fully on the GPU:
 
     events window -> voxel grid (+stats) -> [normalize] -> pad -> network -> crop -> [robust norm]
-                  -> clip -> MSE / SSIM
+                  -> clip -> MSE / SSIM / LPIPS
 
 All launches go to one HIP stream through the C ABI; nothing synchronises with the host inside a
 step (the reference forces a cuda.synchronize() and a D2H copy per frame, eval.py:227-233).
@@ -15,11 +15,13 @@ from .voxel import Voxelizer
 
 class HotPath:
     def __init__(self, model, num_bins, sensor_size, n_seq, event_tensor_normalization=True,
-                 post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0'):
+                 post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0', lpips=None):
         _lib.require_gpu()
         self.model, self.B, (self.H, self.W), self.n = model, num_bins, sensor_size, n_seq
         self.norm_in, self.post = event_tensor_normalization, post_process_norm
         self.want_mse, self.want_ssim = 'mse' in metrics, 'ssim' in metrics
+        self.lpips = lpips if 'lpips' in metrics else None      # evreal_amd.lpips.LPIPS instance
+        self.ncol = 3 if self.lpips is not None else 2
         self.dev = torch.device(device)
         self.vox = Voxelizer(device)
         self.met = Metrics()
@@ -31,7 +33,7 @@ class HotPath:
     def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
         """One frame for every sequence.  xy/ts/pol: resident raw event arrays; win_offsets: int64
         [n_seq+1] device tensor delimiting this step's n_seq windows.  ref: [n_seq,H,W] reference
-        frames (already /255) or None.  Returns (img [n_seq,1,H,W], scores [n_seq,2] or None)."""
+        frames (already /255) or None.  Returns (img [n_seq,1,H,W], scores [n_seq,2|3] = mse, ssim[, lpips] or None)."""
         self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
         return self._rest(ref, scores_out)
 
@@ -45,8 +47,13 @@ class HotPath:
         if self.post != 'none':
             post_process_normalization(im, self.post)
         scores = None
-        if ref is not None and (self.want_mse or self.want_ssim):
+        if ref is not None and (self.want_mse or self.want_ssim or self.lpips is not None):
             scores = self.met(im, ref, mse=self.want_mse, ssim=self.want_ssim, clip=True)
             if scores_out is not None:
-                scores_out.copy_(scores)
+                scores_out[:, :2].copy_(scores)
+            if self.lpips is not None:
+                lp = self.lpips(im, ref, clip=True, out=scores_out[:, 2] if scores_out is not None and scores_out[:, 2].is_contiguous() else None)
+                if scores_out is not None and not scores_out[:, 2].is_contiguous():
+                    scores_out[:, 2].copy_(lp)
+                scores = torch.cat([scores, lp.unsqueeze(1)], dim=1) if scores_out is None else scores_out
         return self.img, scores

@@ -118,6 +118,26 @@ def firenet_schema(num_bins=5, base_num_channels=16, kernel_size=3, **_):
     return s
 
 
+def lpips_alex_schema():
+    """State dict of pyiqa's LPIPS(net='alex', version='0.1'): AlexNet feature convs + the five 1x1 'lin' heads."""
+    s = OrderedDict()
+    for name, co, ci, k in [("net.slice1.0", 64, 3, 11), ("net.slice2.3", 192, 64, 5), ("net.slice3.6", 384, 192, 3),
+                            ("net.slice4.8", 256, 384, 3), ("net.slice5.10", 256, 256, 3)]:
+        _conv(s, name, co, ci, k)
+    for l, c in enumerate([64, 192, 384, 256, 256]):
+        s[f'lin{l}.model.1.weight'] = (1, c, 1, 1)
+    return s
+
+
+def synth_lpips_state_dict(seed=0):
+    """Deterministic stand-in for the (offline-unobtainable) LPIPS weights; the lin heads are non-negative."""
+    sd = synth_state_dict(lpips_alex_schema(), seed=seed)
+    for k in sd:
+        if k.startswith('lin'):
+            sd[k] = np.abs(sd[k]).astype(np.float32)
+    return sd
+
+
 def synth_state_dict(schema, seed=0, gain=1.0, fixed=None):
     """Deterministic fp32 numpy weights for a schema.  Each tensor is drawn from its own
     PCG64 stream keyed by (seed, crc32(name)) so adding/removing tensors never shifts the

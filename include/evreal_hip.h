@@ -181,6 +181,20 @@ int evr_metrics(const float* img, const float* ref, int n, int H, int W, unsigne
                 double* out, void* workspace, size_t workspace_bytes, evr_stream_t stream);
 size_t evr_metrics_workspace_bytes(int n, int H, int W);
 
+/* ----------------------------------------------------------------------------------------------
+ * LPIPS (AlexNet, v0.1).  Replaces PyIqaMetricFactory.get_metric('lpips') (utils/eval_metrics.py:110-156):
+ * gray images are replicated to 3 channels (cv2torch(num_ch=3), eval_utils.py:46-54) and scored in batches.
+ * tensors: the metric's state_dict with pyiqa's names ("net.slice1.0.weight" ... "net.slice5.10.bias",
+ * "lin0.model.1.weight" ... "lin4.model.1.weight").  img, ref: [n,H,W] in [0,1] (clip: clamp first);
+ * out: double [n].  PARITY UNPINNED: pyiqa and its downloaded weights are unavailable offline.
+ */
+typedef struct evr_lpips evr_lpips;
+int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lpips** out);
+int evr_lpips_destroy(evr_lpips* m);
+int evr_lpips_forward(evr_lpips* m, const float* img, const float* ref, int n, int H, int W, int clip,
+                      double* out, evr_stream_t stream);
+double evr_lpips_flops(const evr_lpips* m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,3 +73,24 @@ def test_mse_ssim_vs_oracle(shape):
         assert abs(out[i, 0] - om.mse(a, b)) <= 1e-12 + 1e-9 * om.mse(a, b)
         assert abs(out[i, 1] - om.ssim(a, b)) <= 2e-6, (i, out[i, 1], om.ssim(a, b))
     assert out[0, 0] == 0.0 and abs(out[0, 1] - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(260, 346), (180, 240), (96, 128)])
+def test_lpips_vs_oracle(shape):
+    """LPIPS structure (AlexNet v0.1) with deterministic synthetic weights: HIP vs the torch restatement.
+    Parity vs pyiqa itself is unpinned (weights unobtainable offline)."""
+    from evreal_amd import weights
+    from evreal_amd.lpips import LPIPS
+    from oracle import lpips as ol
+    sd = weights.synth_lpips_state_dict(seed=3)
+    H, W = shape
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ref = np.stack([0.5 + 0.4 * np.sin(xx / (7.0 + i)) * np.cos(yy / (9.0 + i)) for i in range(3)]).astype(np.float32)
+    img = np.clip(ref + 0.1 * rng.standard_normal(ref.shape), 0, 1).astype(np.float32)
+    img[0] = ref[0]
+    m = LPIPS(sd)
+    got = m(torch.from_numpy(img).cuda(), torch.from_numpy(ref).cuda()).cpu().numpy()
+    want = ol.lpips(sd, img, ref)
+    assert got[0] == 0.0
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
