@@ -23,45 +23,68 @@ using namespace evr;
 namespace {
 
 // ---- conv1: gray [n2,H,W] -> NHWC [n2,h1,w1,64], relu ------------------------------------------------------------
+// The three input channels are the same gray value g pushed through per-channel affine maps
+// x_c = ((2g-1) - shift_c)/scale_c = alpha_c*g + beta_c (and 0 where the conv pads), so
+//   sum_c sum_t w[co][c][t] x_c[t] = sum_t inside[t] * (wg[t][co]*g[t] + wb[t][co]),
+// with wg = sum_c w*alpha_c, wb = sum_c w*beta_c folded on the host: a ONE-channel 11x11 conv (121 taps instead of
+// 363) plus, for output tiles whose receptive field leaves the image, the wb term under the inside mask; interior
+// tiles take sum_t wb[t] from the bias.  Weights are wave-uniform (scalar loads); the gray tile and mask sit in LDS.
 struct Conv1Args {
     const float* img; const float* ref;   // [n,H,W] each; batch index >= n reads ref
     int n, H, W, h1, w1, clip;
-    const float* wgt;                      // [3*121][64]
-    const float* bias;
-    float shift[3], scale[3];
+    const float* wg;                       // [121][64]
+    const float* wb;                       // [121][64]
+    const float* bias;                     // [64]
+    const float* bias_in;                  // [64] bias + sum_t wb[t]  (interior tiles)
     float* out;
 };
 
 __global__ __launch_bounds__(256) void lpips_conv1_kernel(const Conv1Args a) {
     constexpr int TS = 16, K = 11, S = 4, P = 2, IS = (TS - 1) * S + K;   // 71
-    extern __shared__ float tile[];   // [3][IS][IS] scaled input, zero where the conv pads
+    extern __shared__ float smem[];
+    float* tile = smem;                 // [IS][IS] gray (0 outside the image)
+    float* mask = smem + IS * IS;       // [IS][IS] 1 inside / 0 outside
     const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
     const float* src = (b < a.n ? a.img + (int64_t)b * a.H * a.W : a.ref + (int64_t)(b - a.n) * a.H * a.W);
+    const int y_lo = ty0 * S - P, x_lo = tx0 * S - P;
+    const bool interior = y_lo >= 0 && x_lo >= 0 && y_lo + IS <= a.H && x_lo + IS <= a.W;   // block-uniform
     for (int i = tid; i < IS * IS; i += 256) {
         const int rr = i / IS, cc = i % IS;
-        const int y = ty0 * S + rr - P, x = tx0 * S + cc - P;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        const int y = y_lo + rr, x = x_lo + cc;
+        float g = 0.f, in = 0.f;
         if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
-            float g = src[(int64_t)y * a.W + x];
+            g = src[(int64_t)y * a.W + x];
             if (a.clip) g = fminf(fmaxf(g, 0.f), 1.f);
-            const float t = 2.f * g - 1.f;
-            v0 = (t - a.shift[0]) / a.scale[0]; v1 = (t - a.shift[1]) / a.scale[1]; v2 = (t - a.shift[2]) / a.scale[2];
+            in = 1.f;
         }
-        tile[i] = v0; tile[IS * IS + i] = v1; tile[2 * IS * IS + i] = v2;
+        tile[i] = g; mask[i] = in;
     }
     __syncthreads();
     const int ly = tid / TS, lx = tid % TS, oy = ty0 + ly, ox = tx0 + lx;
     float acc[64];
+    if (interior) {
 #pragma unroll
-    for (int co = 0; co < 64; ++co) acc[co] = a.bias[co];
-    for (int c = 0; c < 3; ++c)
+        for (int co = 0; co < 64; ++co) acc[co] = a.bias_in[co];
         for (int ky = 0; ky < K; ++ky)
             for (int kx = 0; kx < K; ++kx) {
-                const float v = tile[(c * IS + ly * S + ky) * IS + lx * S + kx];
-                const float* w = a.wgt + ((c * K + ky) * K + kx) * 64;     // wave-uniform -> scalar loads
+                const float v = tile[(ly * S + ky) * IS + lx * S + kx];
+                const float* w = a.wg + (ky * K + kx) * 64;                 // wave-uniform -> scalar loads
 #pragma unroll
                 for (int co = 0; co < 64; ++co) acc[co] = fmaf(v, w[co], acc[co]);
             }
+    } else {
+#pragma unroll
+        for (int co = 0; co < 64; ++co) acc[co] = a.bias[co];
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                const int ti = (ly * S + ky) * IS + lx * S + kx;
+                const float v = tile[ti], mk = mask[ti];
+                const float* w = a.wg + (ky * K + kx) * 64;
+                const float* wbp = a.wb + (ky * K + kx) * 64;
+#pragma unroll
+                for (int co = 0; co < 64; ++co) acc[co] = fmaf(mk, wbp[co], fmaf(v, w[co], acc[co]));
+            }
+    }
     if (oy < a.h1 && ox < a.w1) {
         float* o = a.out + (((int64_t)b * a.h1 + oy) * a.w1 + ox) * 64;
 #pragma unroll
@@ -147,8 +170,8 @@ struct Layer { int cin, cout, k, pad; std::vector<float> w, b; float* d_w = null
 
 struct evr_lpips {
     // conv1 (direct) + 4 igemm layers
-    std::vector<float> w1, b1;
-    float* d_w1 = nullptr; float* d_b1 = nullptr;
+    std::vector<float> wg, wb, b1, b1in;
+    float* d_wg = nullptr; float* d_wb = nullptr; float* d_b1 = nullptr; float* d_b1in = nullptr;
     float* d_lin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Layer L[4];
     // shape-dependent
@@ -161,7 +184,7 @@ struct evr_lpips {
     void release() { for (void* p : allocs) (void)hipFree(p); allocs.clear(); n = 0; d_args = nullptr; }
     ~evr_lpips() {
         release();
-        if (d_w1) (void)hipFree(d_w1); if (d_b1) (void)hipFree(d_b1);
+        if (d_wg) (void)hipFree(d_wg); if (d_wb) (void)hipFree(d_wb); if (d_b1) (void)hipFree(d_b1); if (d_b1in) (void)hipFree(d_b1in);
         for (auto& p : d_lin) if (p) (void)hipFree(p);
         for (auto& l : L) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     }
@@ -201,11 +224,28 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
     do {
         if ((rc = get(std::string(names[0]) + ".weight", 64 * 3 * 121, &w))) break;
         if ((rc = get(std::string(names[0]) + ".bias", 64, &b))) break;
-        m->w1.assign((size_t)3 * 121 * 64, 0.f); m->b1.assign(b->data_host, b->data_host + 64);
-        for (int co = 0; co < 64; ++co) for (int c = 0; c < 3; ++c) for (int t = 0; t < 121; ++t)
-            m->w1[((size_t)c * 121 + t) * 64 + co] = w->data_host[((size_t)co * 3 + c) * 121 + t];
-        if ((rc = up(m->w1, &m->d_w1))) break;
+        m->wg.assign((size_t)121 * 64, 0.f); m->wb.assign((size_t)121 * 64, 0.f);
+        m->b1.assign(b->data_host, b->data_host + 64); m->b1in.assign(64, 0.f);
+        {   // scaling layer of LPIPS folded into conv1: x_c = alpha_c * g + beta_c
+            const double shift[3] = {-.030, -.088, -.188}, scale[3] = {.458, .448, .450};
+            for (int co = 0; co < 64; ++co) {
+                double bsum = 0.0;
+                for (int t = 0; t < 121; ++t) {
+                    double g = 0.0, bb = 0.0;
+                    for (int c = 0; c < 3; ++c) {
+                        const double wv = w->data_host[((size_t)co * 3 + c) * 121 + t];
+                        g += wv * (2.0 / scale[c]); bb += wv * ((-1.0 - shift[c]) / scale[c]);
+                    }
+                    m->wg[(size_t)t * 64 + co] = (float)g; m->wb[(size_t)t * 64 + co] = (float)bb;
+                    bsum += bb;
+                }
+                m->b1in[co] = (float)((double)m->b1[co] + bsum);
+            }
+        }
+        if ((rc = up(m->wg, &m->d_wg))) break;
+        if ((rc = up(m->wb, &m->d_wb))) break;
         if ((rc = up(m->b1, &m->d_b1))) break;
+        if ((rc = up(m->b1in, &m->d_b1in))) break;
         for (int l = 1; l < 5 && !rc; ++l) {
             Layer& L = m->L[l - 1];
             L.cin = cin[l]; L.cout = cout[l]; L.k = ks[l]; L.pad = ks[l] / 2;
@@ -281,11 +321,9 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     const int n2 = 2 * n;
     Conv1Args c1{};
     c1.img = img; c1.ref = ref; c1.n = n; c1.H = H; c1.W = W; c1.h1 = m->h[0]; c1.w1 = m->w[0]; c1.clip = clip;
-    c1.wgt = m->d_w1; c1.bias = m->d_b1; c1.out = m->feat[0];
-    const float shift[3] = {-.030f, -.088f, -.188f}, scale[3] = {.458f, .448f, .450f};
-    for (int c = 0; c < 3; ++c) { c1.shift[c] = shift[c]; c1.scale[c] = scale[c]; }
+    c1.wg = m->d_wg; c1.wb = m->d_wb; c1.bias = m->d_b1; c1.bias_in = m->d_b1in; c1.out = m->feat[0];
     static bool attr = false;
-    const size_t lds1 = (size_t)3 * 71 * 71 * sizeof(float);
+    const size_t lds1 = (size_t)(2 * 71 * 71) * sizeof(float);
     if (!attr) { EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
     EVR_LAUNCH_CHECK();
