@@ -127,9 +127,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('EVR_FORCE_DIST'):      # EVR_FORCE_DIST=1: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from evreal_amd import model, weights
@@ -219,10 +220,15 @@ def main():
                                                lpips_sd=weights.synth_lpips_state_dict(seed=0))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON stays the LAST stdout line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == '__main__':
