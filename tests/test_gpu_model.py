@@ -140,3 +140,57 @@ def test_e2vid_full_size_vs_oracle_with_padding_and_norm():
         v = op.normalize_event_tensor(ov.events_to_voxel(x, y, t, p, 5, (H, W))[None])
         want = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())
         np.testing.assert_allclose(img, want, rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')
+
+
+def test_recurrent_drift_30_frames():
+    """fp32 MFMA vs torch-CPU over a long recurrence: the 1e-4 per-pixel gate must hold on every frame, and the
+    ConvLSTM states must not drift (error compounds through h/c, SURVEY section 7 'hard parts')."""
+    from evreal_amd import model, synth, weights
+    from oracle import model as omod
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=11)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
+                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    F, H, W = 30, 64, 96
+    vox = synth.sparse_voxels(123, F, 5, H, W, density=0.1)
+    m.reset_states()
+    worst = 0.0
+    for f in range(F):
+        got = m(torch.from_numpy(vox[f:f + 1]).cuda())['image'].cpu().numpy()
+        want = o(torch.from_numpy(vox[f:f + 1])).numpy()
+        worst = max(worst, float(np.abs(got - want).max()))
+        assert worst < IMG_ATOL, (f, worst)
+    for i in range(3):
+        h = m.read_tensor(f'h{i}').cpu().numpy().reshape(o.states[i][0].shape)
+        c = m.read_tensor(f'c{i}').cpu().numpy().reshape(o.states[i][1].shape)
+        np.testing.assert_allclose(h, o.states[i][0].numpy(), rtol=2e-4, atol=5e-5)
+        np.testing.assert_allclose(c, o.states[i][1].numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_firenet_real_weights_40_frames_and_reset():
+    """FireNet with the shipped checkpoint over 40 frames, then reset_states() must reproduce frame 0 exactly."""
+    from evreal_amd import model, synth
+    from oracle import model as omod
+    from oracle.prepost import CropParams
+    w = load_npz('firenet_weights.npz')
+    sd = {k: w[k] for k in w.files}
+    m = model.FireNet_legacy(unet_kwargs=dict(num_bins=5, recurrent_block_type='convgru', base_num_channels=16,
+                                              num_residual_blocks=2, kernel_size=3, norm='none'))
+    m.load_state_dict(sd)
+    o = omod.FireNetLegacyOracle({k: torch.from_numpy(v) for k, v in sd.items()})
+    F, H, W = 40, 90, 120
+    crop = CropParams(W, H, 4)
+    vox = synth.sparse_voxels(321, F, 5, H, W, density=0.08)
+    m.reset_states()
+    first = None
+    for f in range(F):
+        got = m(torch.from_numpy(vox[f:f + 1]).cuda())['image'].cpu().numpy()
+        want = crop.crop(o(torch.from_numpy(crop.pad(vox[f:f + 1]))).numpy())
+        assert float(np.abs(got - want).max()) < IMG_ATOL, f
+        if f == 0:
+            first = got
+    m.reset_states()
+    again = m(torch.from_numpy(vox[0:1]).cuda())['image'].cpu().numpy()
+    assert np.array_equal(again, first)          # deterministic kernels + zeroed state
