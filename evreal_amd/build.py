@@ -23,6 +23,7 @@ PER_FILE = {
     'voxelize.hip': ['-ffp-contract=off'],
     'prepost.hip': ['-ffp-contract=off'],
     'metrics.hip': ['-ffp-contract=off'],
+    'color.hip': ['-ffp-contract=off'],
 }
 
 

@@ -28,7 +28,7 @@ from .dataset import MemMapDataset
 from .dist import assign_sequences, reduce_metric_sums
 from .eval_metrics import EvalMetricsTracker, MetricTracker
 from .lib import EvrError
-from .prepost import post_process_normalization
+from .prepost import normalize_event_tensor, post_process_normalization
 
 CHUNK = 16   # windows voxelised / frames scored per launch
 
@@ -142,8 +142,7 @@ def get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, m
 def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
     """eval.py:189-246."""
     ds = open_sequence(sequence)
-    if eval_config.get('color', False):
-        raise NotImplementedError("color evaluation (ColorNet) is not built yet (SURVEY 8f-3)")
+    color = eval_config.get('color', False)
     tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
     model.reset_states()
     infer_all = eval_config.get('eval_infer_all', False)
@@ -171,6 +170,18 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
         items = todo[c0:c0 + CHUNK]
         n = len(items)
         grid, stats = ds.voxel_batch(items)
+        if color:
+            # eval.py:222-232 with color: normalise the full tensor, no outer pad/crop, ColorNet splits the streams
+            if post_norm != 'none':
+                raise NotImplementedError("colour evaluation supports post_process_norm='none' only")
+            if norm_in:
+                normalize_event_tensor(grid, stats)
+            bgr = [model(grid[j:j + 1])['image'][0] for j in range(n)]
+            tracker.update_batch_color(items, torch.stack(bgr), [float(v) for v in tb['voxel_timestamp'][items]])
+            for i in items:
+                cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
+                tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
+            continue
         for j in range(n):
             model(grid[j:j + 1], stats=stats[j:j + 1] if norm_in else None, out=imgs[j:j + 1])
         im = imgs[:n, 0]
@@ -204,6 +215,8 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
     method_metrics = []
     try:
         model = get_model_from_checkpoint_path(method_config['model_name'], method_config['model_path'])
+        if eval_config.get('color', False):
+            model = model_arch.ColorNet(model)          # eval.py:346-347
     except Exception as e:
         print(f"Exception while getting method {method_name} from checkpoint path {method_config['model_path']}")
         print(e); print(traceback.format_exc())

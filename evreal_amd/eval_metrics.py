@@ -140,6 +140,16 @@ class EvalMetricsTracker:
             m.add(col)
             self._append(join(self.output_dir, m.name + '.txt'), finite)
 
+    def update_batch_color(self, indices, bgr_u8, img_ts):
+        """Colour frames (uint8 BGR [n,H,W,3] on the GPU): timestamps + PNGs only -- the reference skips every
+        quantitative metric in colour mode (utils/eval_metrics.py:272)."""
+        self._append(join(self.output_dir, 'timestamps.txt'), zip(indices, img_ts), '{} {:.15f}\n')
+        if self.save_images:
+            from PIL import Image
+            rgb = bgr_u8.flip(-1).cpu().numpy()          # cv2.imwrite stores BGR arrays as RGB files
+            for i, a in zip(indices, rgb):
+                Image.fromarray(a, mode='RGB').save(join(self.output_dir, 'frame_{:010d}.png'.format(i)))
+
     def _save_pngs(self, indices, imgs):
         from PIL import Image
         u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()

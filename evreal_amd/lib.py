@@ -64,6 +64,8 @@ SYMBOLS = {
     'evr_lpips_destroy': (c_int, [c_void_p]),
     'evr_lpips_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'evr_lpips_flops': (c_double, [c_void_p]),
+    'evr_bayer_split': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'evr_color_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

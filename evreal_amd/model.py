@@ -46,6 +46,7 @@ class _HipModel:
 
     def load_state_dict(self, state_dict, strict=True):
         sd = _np_state_dict(state_dict)
+        self._sd = sd                 # kept so ColorNet can build its second (half-resolution) executor
         tensors = (_lib.Tensor * len(sd))()
         keep = []
         for i, (k, v) in enumerate(sd.items()):
@@ -231,3 +232,50 @@ class FireNet(_HipModel):
         d.kernel_size = self.kernel_size
         d.pad_multiple_log2 = self.num_encoders
         return d
+
+
+class ColorNet:
+    """model/model.py:46-105: the event tensor is split into the R,G,B,W Bayer sub-lattices plus the full-resolution
+    grayscale stream; every stream is reconstructed by the SAME recurrent network with its own state; the five uint8
+    reconstructions are merged into one BGR frame (utils/color_utils.py:53-88).
+
+    Here the four half-resolution colour streams of all sequences advance as extra sequences of one batched executor
+    (n_seq = 4N) and the grayscale streams in a second executor that shares the weights; nothing leaves the GPU.
+    The reference converts every stream to uint8 on the CPU (5 D2H copies per frame, model.py:100-101)."""
+
+    def __init__(self, model):
+        self.model = model                       # full-resolution (grayscale) executor
+        if getattr(model, '_sd', None) is None:
+            raise _lib.EvrError("ColorNet needs a model with loaded weights")
+        import copy
+        self.half = copy.copy(model)             # shallow: same kwargs/desc, own handle
+        self.half.handle = None
+        self.half._shape = None
+        self.half.load_state_dict(model._sd)
+        self.lib = _lib.load()
+        self.reset_states()
+
+    @property
+    def num_encoders(self):
+        return self.model.num_encoders
+
+    def reset_states(self):
+        self.model.reset_states()
+        self.half.reset_states()
+
+    def forward(self, event_tensor, stats=None):
+        """event_tensor [N,B,H,W] (H, W even) -> {'image': uint8 BGR [N,H,W,3] on the GPU, 'planes': [N,4,H/2,W/2],
+        'gray': [N,1,H,W]} (planes/gray are the float reconstructions before the uint8 truncation)."""
+        assert event_tensor.is_cuda and event_tensor.dim() == 4
+        ev = event_tensor.contiguous()
+        n, B, H, W = ev.shape
+        split = torch.empty((4 * n, B, H // 2, W // 2), dtype=torch.float32, device=ev.device)
+        _lib.check(self.lib.evr_bayer_split(_lib.ptr(ev), n, B, H, W, _lib.ptr(split), _lib.stream_ptr()), 'evr_bayer_split')
+        planes = self.half(split)['image'].view(n, 4, H // 2, W // 2)
+        gray = self.model(ev)['image']
+        bgr = torch.empty((n, H, W, 3), dtype=torch.uint8, device=ev.device)
+        _lib.check(self.lib.evr_color_merge(_lib.ptr(planes), _lib.ptr(gray), n, H, W, _lib.ptr(bgr), _lib.stream_ptr()),
+                   'evr_color_merge')
+        return {'image': bgr, 'planes': planes, 'gray': gray}
+
+    __call__ = forward

@@ -195,6 +195,19 @@ int evr_lpips_forward(evr_lpips* m, const float* img, const float* ref, int n, i
                       double* out, evr_stream_t stream);
 double evr_lpips_flops(const evr_lpips* m);
 
+/* ----------------------------------------------------------------------------------------------
+ * Colour reconstruction (ColorNet, model/model.py:46-105; merge utils/color_utils.py:53-88).
+ * evr_bayer_split: vox [n,B,H,W] -> out [4n,B,H/2,W/2], the R,G,B,W Bayer sub-lattices of each sequence
+ *   (model.py:54-57), so the four colour streams run as extra sequences of one batched evr_model_step.
+ * evr_color_merge: planes [n,4,H/2,W/2] (R,G,B,W reconstructions, float) + gray [n,H,W] -> bgr_out uint8 [n,H,W,3]:
+ *   uint8 truncation (model.py:101), x2 bilinear, Bayer origin shifts, G/W mean, Lab merge with the gray L.
+ *   The uint8 planes are pinned against the reference; the merge is floating-point (OpenCV's fixed-point tables are
+ *   unavailable offline) -> UNPINNED, may differ by a few LSB.
+ */
+int evr_bayer_split(const float* vox, int n, int B, int H, int W, float* out, evr_stream_t stream);
+int evr_color_merge(const float* planes, const float* gray, int n, int H, int W, unsigned char* bgr_out,
+                    evr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

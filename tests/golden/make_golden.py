@@ -380,8 +380,35 @@ def make_eval():
     save_json('eval_loop.json', dict(seqs=EVAL_SEQS, cfgs=EVAL_CFGS, files=files, scores=captured))
 
 
+# ---------------------------------------------------------------- 10. ColorNet streams
+def make_color():
+    import model.model as mm
+    kw = dict(weights.E2VID_PLUS_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=9)
+    base = ref_model.E2VIDRecurrent(dict(kw))
+    base.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    base.eval()
+    captured = []
+    mm.merge_channels_into_color_image = lambda ch: (captured.append({k: v.copy() for k, v in ch.items()}),
+                                                     np.zeros(ch['grayscale'].shape + (3,), np.uint8))[1]
+    mm.transforms.functional = types.SimpleNamespace(to_tensor=lambda a: torch.zeros(3, *a.shape[:2]))
+    net = mm.ColorNet(base)
+    H, W, F = 96, 128, 3
+    vox = synth.sparse_voxels(91, F, 5, H, W)
+    with torch.no_grad():
+        for f in range(F):
+            net(torch.from_numpy(vox[f:f + 1]))
+    out = {}
+    for f, ch in enumerate(captured):
+        for k, v in ch.items():
+            out[f'f{f}.{k}'] = v
+    save_npz('colornet_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([91, F, 5, H, W]), seed=np.array(9),
+             kwargs=np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8),
+             weights_sha=np.array(weights.state_dict_digest(sd)), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color}[w]()
