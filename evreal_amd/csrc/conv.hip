@@ -175,11 +175,12 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     const int r = lane & 31, h = lane >> 5;
     const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
 
+    const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     issue(0);
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        __syncthreads();                       // (waits vmcnt(0)) tile s landed; everyone left tile s-1
-        if (s + 1 < nsteps) issue(buf ^ 1);   // DMA of the next tile flies under the MFMAs
+        if (!(ablate & 1)) __syncthreads();    // (waits vmcnt(0)) tile s landed; everyone left tile s-1
+        if (s + 1 < nsteps && !(ablate & 2)) issue(buf ^ 1);   // DMA of the next tile flies under the MFMAs
         int groups_now = 0;
         if constexpr (GROUPED) {
             groups_now = tp.tap_groups[__builtin_ctz(bits_c)];

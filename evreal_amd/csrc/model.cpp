@@ -14,6 +14,7 @@
 // kernargs, no host arithmetic and no synchronisation.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -473,6 +474,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden;
+        if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM) ? atoi(e) : 0;
     }
     pick_conv_tile(c.args[0], c.kc, &c.wm, &c.nb);
     // direct-conv FLOPs: a transposed conv counts its k*k taps once per INPUT pixel (= k*k/4 per output pixel x 4 phases)
