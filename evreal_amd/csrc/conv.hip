@@ -55,7 +55,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
@@ -138,6 +138,8 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     // (tap, chunk) of the step being issued / computed: walked incrementally over the set bits of act_taps
     unsigned bits_i = act_taps, bits_c = act_taps;
     int cc_i = 0, cc_c = 0;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[A_PER], rb[B_PER];     // REGSTAGE: tile s+1 waits in registers while tile s is multiplied
     auto issue = [&](int buf) {
         const int t = __builtin_ctz(bits_i), cc = cc_i;
         if (++cc_i == nchunks) { cc_i = 0; bits_i &= bits_i - 1; }
@@ -153,17 +155,36 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             unsigned voff = OOB_OFFSET;
             if ((unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win)
                 voff = ((unsigned)((r_pix[j] + iy) * win + ix) * (unsigned)csrc + (unsigned)coff + a_q4[j]) * 4u;
-            lds_ptr_t dst = (lds_ptr_t)&lds[buf][(wmi + j * WM) * 64];
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            if constexpr (REGSTAGE) {
+                ra[j] = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0);
+            } else {
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf][(wmi + j * WM) * 64];
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             if (B_F4 % NT == 0 || (wmi + j * WM) * 64 < B_F4) {   // wave-uniform
-                lds_ptr_t dst = (lds_ptr_t)&lds[buf][A_F4 + (wmi + j * WM) * 64];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[j] + (unsigned)((t * nchunks + cc) * KC)) * 4u, 0, 0, 0);
+                const unsigned woff = (b_off[j] + (unsigned)((t * nchunks + cc) * KC)) * 4u;
+                if constexpr (REGSTAGE) {
+                    rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, woff, 0, 0);
+                } else {
+                    lds_ptr_t dst = (lds_ptr_t)&lds[buf][A_F4 + (wmi + j * WM) * 64];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, woff, 0, 0, 0);
+                }
             }
         }
+    };
+
+    // REGSTAGE: the staged registers land in the same lane-linear LDS image the DMA would have produced
+    auto store_staged = [&](int buf) {
+        u32x4* l = (u32x4*)&lds[buf][0];
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) l[tid + j * NT] = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j)
+            if (B_F4 % NT == 0 || tid + j * NT < B_F4) l[A_F4 + tid + j * NT] = rb[j];
     };
 
     f32x16 acc[NB];
@@ -177,10 +198,11 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     issue(0);
+    if constexpr (REGSTAGE) { store_staged(0); }
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (!(ablate & 1)) __syncthreads();    // (waits vmcnt(0)) tile s landed; everyone left tile s-1
-        if (s + 1 < nsteps && !(ablate & 2)) issue(buf ^ 1);   // DMA of the next tile flies under the MFMAs
+        if (!(ablate & 1)) __syncthreads();    // tile s is in LDS for every wave; everyone left tile s-1
+        if (s + 1 < nsteps && !(ablate & 2)) issue(buf ^ 1);   // next tile: LDS-DMA, or plain loads into registers
         int groups_now = 0;
         if constexpr (GROUPED) {
             groups_now = tp.tap_groups[__builtin_ctz(bits_c)];
@@ -204,6 +226,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nb], 0, 0, 0);
             }
         }
+        if constexpr (REGSTAGE) { if (s + 1 < nsteps) store_staged(buf ^ 1); }   // waits for the loads, ds_write_b128
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -232,9 +255,22 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
     const float* pre_ptr = LSTM ? a.state : (epi == EPI_RESIDUAL_RELU ? a.residual : a.post_add);
     if (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT) pre_ptr = nullptr;
+    // the common case -- plain conv, output pixel == GEMM row, every column real -- takes a lean path: all the
+    // epilogue-kind decisions are made once here instead of once per output element (64 per thread at NB = 4)
+    const bool lean = !LSTM && !GROUPED && direct && a.pred_w == nullptr && a.n_valid == a.cout &&
+                      (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_RESIDUAL_RELU);
+    const unsigned ct = (unsigned)a.cout_total;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         int e_img, e_my, e_mx, o_y, o_x;
+        if (lean) {
+            const int m = rbase + (reg & 3) + 8 * (reg >> 2);
+#pragma unroll
+            for (int nb = 0; nb < PN; ++nb)
+                pre[nb][reg] = (pre_ptr && m < M) ? pre_ptr[(unsigned)m * ct + (unsigned)(n0 + nb * 32 + r)] : 0.f;
+            continue;
+        }
+        if (GROUPED && (epi == EPI_BIAS_RELU || epi == EPI_BIAS)) continue;   // the grouped lean path prefetches itself
         const int m = row(reg, e_img, e_my, e_mx);
 #pragma unroll
         for (int nb = 0; nb < PN; ++nb) {
@@ -249,6 +285,105 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                 }
             }
             pre[nb][reg] = v;
+        }
+    }
+    if constexpr (!LSTM && !GROUPED) {
+        if (lean) {
+            float bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = a.bias[n0 + nb * 32 + r];
+            const bool relu = epi != EPI_BIAS, res = epi == EPI_RESIDUAL_RELU, pa = a.post_add != nullptr;
+            float* outp = a.out + n0 + r;
+            const float* padd = a.post_add ? a.post_add + n0 + r : nullptr;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = rbase + (reg & 3) + 8 * (reg >> 2);
+                if (m >= M) continue;
+                const unsigned o = (unsigned)m * ct;          // < 2^30 elements (checked at allocation)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float v = acc[nb][reg] + bv[nb];
+                    if (res) v += pre[nb][reg];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (pa) v += res ? padd[o + nb * 32] : pre[nb][reg];
+                    outp[o + nb * 32] = v;
+                }
+            }
+            return;
+        }
+    }
+    if constexpr (GROUPED) {
+        // transposed conv (sub-pixel phases as column groups): lean path.  The wave's 32 GEMM rows are consecutive
+        // input-grid pixels, so ONE division decodes the first and the rest follow by carry; per group only the
+        // (ofy, ofx) offsets differ.  32-bit element offsets (tensors are < 2^30 elements, checked at allocation).
+        if (epi == EPI_BIAS_RELU || epi == EPI_BIAS) {
+            const int b_img = rbase / hw, b_rem = rbase - b_img * hw;
+            const int b_my = b_rem / a.wm, b_mx = b_rem - b_my * a.wm;
+            int g_oy[NB], g_ox[NB], g_c[NB];
+            float bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int g = (n0 + nb * 32) / grp_cols;
+                g_oy[nb] = tp.grp_ofy[g]; g_ox[nb] = tp.grp_ofx[g]; g_c[nb] = n0 + nb * 32 + r - g * grp_cols;
+                bv[nb] = a.bias[n0 + nb * 32 + r];
+            }
+            const bool relu = epi != EPI_BIAS;
+            const float* padd = a.post_add;
+            const float* pw = a.pred_w;
+            // pass A: skip operand prefetch (all loads in flight together)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int d = (reg & 3) + 8 * (reg >> 2);
+                int mx = b_mx + d, my = b_my, img = b_img;
+                while (mx >= a.wm) { mx -= a.wm; ++my; }
+                while (my >= a.hm) { my -= a.hm; ++img; }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float v = 0.f;
+                    if (padd && rbase + d < M && g_c[nb] < a.n_valid) {
+                        const unsigned opx = (unsigned)((img * a.hout + my * a.os + g_oy[nb]) * a.wout + mx * a.os + g_ox[nb]);
+                        v = padd[opx * ct + (unsigned)g_c[nb]];
+                    }
+                    pre[nb][reg] = v;
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int d = (reg & 3) + 8 * (reg >> 2);
+                if (rbase + d >= M) continue;
+                int mx = b_mx + d, my = b_my, img = b_img;
+                while (mx >= a.wm) { mx -= a.wm; ++my; }
+                while (my >= a.hm) { my -= a.hm; ++img; }
+                float pred_part = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int oy = my * a.os + g_oy[nb], ox = mx * a.os + g_ox[nb];
+                    const unsigned opx = (unsigned)((img * a.hout + oy) * a.wout + ox);
+                    if (g_c[nb] < a.n_valid) {
+                        const unsigned o = opx * ct + (unsigned)g_c[nb];
+                        float v = acc[nb][reg] + bv[nb];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (pw && a.out) a.out[o] = v;               // debug copy of the layer's own output
+                        if (padd) v += pre[nb][reg];                 // fused skip_sum
+                        if (!pw && a.out) a.out[o] = v;
+                        if (pw) pred_part = fmaf(v, pw[g_c[nb]], pred_part);
+                    }
+                    if (pw && ((n0 + nb * 32 + 32) % grp_cols) == 0) {   // the group's last block closes one output pixel
+#pragma unroll
+                        for (int o2 = 16; o2 > 0; o2 >>= 1) pred_part += __shfl_xor(pred_part, o2, 64);
+                        if (r == 0) {
+                            const int y = oy - a.crop_y0, x = ox - a.crop_x0;
+                            float sres = pred_part + a.pred_b;
+                            if (a.pred_sigmoid) sres = sigmoidf_(sres);
+                            if (a.prev_rec) a.prev_rec[opx] = sres;
+                            if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
+                                img_out[(unsigned)((img * a.crop_h + y) * a.crop_w + x)] = sres;
+                        }
+                        pred_part = 0.f;
+                    }
+                }
+            }
+            return;
         }
     }
 #pragma unroll
@@ -326,13 +461,13 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
     const int total = mtiles * ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM, GROUPED>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM, GROUPED, REGSTAGE>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -347,6 +482,7 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
         if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
+        if (wm == 4 && getenv("EVR_REGSTAGE")) return launch_t<32, 4, 4, true, false, true>(a, d_args, stream, img);
         if (wm == 4) return launch_t<32, 4, 4, true, false>(a, d_args, stream, img);
         if (wm == 2) return launch_t<32, 2, 4, true, false>(a, d_args, stream, img);
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
@@ -375,11 +511,29 @@ void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb) {
     if (a.epi == EPI_LSTM) n_b = 4;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
     const int ntiles = a.cout / (32 * n_b);
-    int w = 4;
-    if (a.epi == EPI_LSTM && getenv("EVR_LSTM_WM8")) w = 8;   // experiment: 256x128 block tile
-    // shrink the M tile until the launch has >= 2 workgroups per CU (256 CUs) or the tile is one wave
-    while (w > 1 && ((M + 32 * w - 1) / (32 * w)) * ntiles < 512) w >>= 1;
-    *wm = w; *nb = n_b;
+    // Wave-quantisation model: a CU holds bpc blocks (LDS- and register-limited); every wave does the same work
+    // whatever WM is, and the waves resident on a SIMD share its matrix pipe, so
+    //   time ~ rounds(WM) * waves_per_SIMD(WM),  rounds = ceil(blocks / (256 CUs * bpc)).
+    // Pick the WM that minimises it (ties -> the larger tile: fewer weight re-loads).
+    const int occ = (n_b == 4) ? 2 : (n_b == 2) ? 3 : 4;          // waves/SIMD the kernels' VGPR budgets allow
+    int best = 4; double best_cost = 1e30;
+    for (int w = 4; w >= 1; w >>= 1) {
+        const int lds = 2 * (32 * w + 32 * n_b) * kc * 4;
+        int bpc = (160 * 1024) / lds;
+        if (bpc > (4 * occ) / w) bpc = (4 * occ) / w;
+        if (bpc < 1) bpc = 1;
+        const int64_t blocks = ((M + 32 * w - 1) / (32 * w)) * ntiles;
+        const int64_t rounds = (blocks + 256LL * bpc - 1) / (256LL * bpc);
+        const double eff = (w == 4) ? 1.0 : (w == 2) ? 0.93 : 0.85;   // smaller tiles re-load the weight tile more often
+        const double cost = (double)rounds * (bpc * w / 4.0) / eff;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
+    }
+    if (a.epi == EPI_LSTM) {   // the ConvLSTM kernel is tuned (register staging) at WM = 4; shrink only to fill the chip
+        best = 4;
+        while (best > 1 && ((M + 32 * best - 1) / (32 * best)) * ntiles < 512) best >>= 1;
+    }
+    if (a.epi == EPI_LSTM && getenv("EVR_LSTM_WM8")) best = 8;   // experiment: 256x128 block tile
+    *wm = best; *nb = n_b;
 }
 
 // ---------------------------------------------------------------------------------------------------
