@@ -482,7 +482,8 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
         if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
-        if (wm == 4 && getenv("EVR_REGSTAGE")) return launch_t<32, 4, 4, true, false, true>(a, d_args, stream, img);
+        // register staging measured +1..4 % over LDS-DMA for this kernel (EVR_LSTM_DMA=1 selects the DMA loader)
+        if (wm == 4 && !getenv("EVR_LSTM_DMA")) return launch_t<32, 4, 4, true, false, true>(a, d_args, stream, img);
         if (wm == 4) return launch_t<32, 4, 4, true, false>(a, d_args, stream, img);
         if (wm == 2) return launch_t<32, 2, 4, true, false>(a, d_args, stream, img);
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
