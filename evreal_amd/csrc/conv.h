@@ -54,6 +54,8 @@ struct ConvArgs {
     // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
     const float* pred_w; float pred_b; int pred_sigmoid;
     int crop_h, crop_w, crop_y0, crop_x0;
+    int x3;                   // weights are packed for the split-bf16 path: every 32-float K chunk of a row holds
+                              // 32 bf16 'hi' then 32 bf16 'lo' (same 128 B); the kernel splits activations on the fly
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };

@@ -8,8 +8,15 @@
 //   GEMM view   M = n*hm*wm output pixels, N = output channels, K = taps x input channels
 //   data        activations NHWC fp32 (a K chunk of 16/32 channels of one pixel = one 64/128-B line);
 //               weights pre-laid as [N][K] (K contiguous) at model creation, BatchNorm folded
-//   MFMA        v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 157 TF peak): the 1e-4 parity gate of
-//               the recurrent state rules out a reduced-precision fast path for now
+//   MFMA        two arithmetic modes on the same tiles (template X3):
+//               fp32   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (157 TF peak) -- FireNet (16-channel chunks)
+//                      and the reference mode (EVR_FP32=1);
+//               x3     split-bf16: x = hi + lo, w = hi + lo (bf16 each, RNE), acc += hi*hi + hi*lo + lo*hi on
+//                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 k instead of
+//                      8 x 64 cycles (5.3x fewer matrix-pipe cycles).  Dropped terms are 2^-16 relative; measured
+//                      through a 30-frame recurrence the image error is 2.5e-6 (gate 1e-4, plain bf16: 1.8e-3).
+//                      Weights are pre-split on the host into the same 128-B-per-row tile (32 hi | 32 lo), so the
+//                      loader is unchanged; activations are split in registers after the fragment read
 //   tile        block = WM waves stacked along M; a wave owns 32 pixels x (NB*32) channels, i.e. NB
 //               accumulators of 16 VGPRs; for ConvLSTM NB = 4 and the weight rows are permuted so
 //               the four 32-column blocks are the in/remember/out/cell gates of the SAME 32 hidden
@@ -34,6 +41,8 @@
 namespace evr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -46,6 +55,12 @@ __device__ __forceinline__ int swz(int row) {
 // just needs the kernel's signature to emit the launch stub, so the body is compiled for the device only.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// two fp32 -> packed bf16 (RNE): `lo` lands in bits 15:0, `hi` in bits 31:16 (no builtin on gfx950)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -55,7 +70,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, bool X3 = false>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
@@ -210,6 +225,35 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         }
         const float4* la = &lds[buf][(wmi * 32 + r) * SP];
         const float4* lb = &lds[buf][A_F4 + r * SP];
+        if constexpr (X3) {
+            static_assert(!X3 || KC == 32, "split-bf16 tiles are 32 k wide");
+            const u32x4_t* lbu = (const u32x4_t*)lb;
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {           // two 16-k MFMA slabs per step
+                // this lane's 8 activations k = 16*slab + 8*h .. +7 (two 16-B slots), split x = hi + lo in registers
+                const float4 x0 = la[(4 * slab + 2 * h) ^ sw], x1 = la[(4 * slab + 2 * h + 1) ^ sw];
+                u32x4_t ah, al;
+                ah[0] = cvt_pk_bf16(x0.x, x0.y); ah[1] = cvt_pk_bf16(x0.z, x0.w);
+                ah[2] = cvt_pk_bf16(x1.x, x1.y); ah[3] = cvt_pk_bf16(x1.z, x1.w);
+                al[0] = cvt_pk_bf16(x0.x - __uint_as_float(ah[0] << 16), x0.y - __uint_as_float(ah[0] & 0xffff0000u));
+                al[1] = cvt_pk_bf16(x0.z - __uint_as_float(ah[1] << 16), x0.w - __uint_as_float(ah[1] & 0xffff0000u));
+                al[2] = cvt_pk_bf16(x1.x - __uint_as_float(ah[2] << 16), x1.y - __uint_as_float(ah[2] & 0xffff0000u));
+                al[3] = cvt_pk_bf16(x1.z - __uint_as_float(ah[3] << 16), x1.w - __uint_as_float(ah[3] & 0xffff0000u));
+                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if constexpr (GROUPED) {
+                        if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
+                    }
+                    // weight row: slots 0-3 = hi (8 bf16 each), slots 4-7 = lo
+                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((2 * slab + h) ^ sw)]);
+                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((4 + 2 * slab + h) ^ sw)]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[nb], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < KC / 8; ++i) {
             const int q = (2 * i + h) ^ sw;
@@ -225,6 +269,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nb], 0, 0, 0);
             }
+        }
         }
         if constexpr (REGSTAGE) { if (s + 1 < nsteps) store_staged(buf ^ 1); }   // waits for the loads, ds_write_b128
     }
@@ -461,13 +506,13 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, bool X3 = false>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int ntiles = a.cout / (32 * NB);
     const int total = mtiles * ntiles;
-    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM, GROUPED, REGSTAGE>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv_igemm_kernel<KC, WM, NB, LSTM, GROUPED, REGSTAGE, X3>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -479,8 +524,14 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
+    EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split-bf16 path needs 32-channel chunks");
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
+        if (a.x3) {
+            if (wm == 4) return launch_t<32, 4, 4, true, false, true, true>(a, d_args, stream, img);
+            if (wm == 2) return launch_t<32, 2, 4, true, false, false, true>(a, d_args, stream, img);
+            return launch_t<32, 1, 4, true, false, false, true>(a, d_args, stream, img);
+        }
         if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
         // register staging measured +1..4 % over LDS-DMA for this kernel (EVR_LSTM_DMA=1 selects the DMA loader)
         if (wm == 4 && !getenv("EVR_LSTM_DMA")) return launch_t<32, 4, 4, true, false, true>(a, d_args, stream, img);
@@ -489,12 +540,18 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
     }
     if (a.tp.ngroups > 1) {   // transposed conv: column groups = sub-pixel phases
-#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img);
+#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { if (a.x3) return launch_t<32, WM_, NB_, false, true, false, true>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img); }
         EVR_CASEG(4, 4) EVR_CASEG(2, 4) EVR_CASEG(1, 4) EVR_CASEG(4, 2) EVR_CASEG(2, 2) EVR_CASEG(1, 2)
         EVR_CASEG(4, 1) EVR_CASEG(2, 1) EVR_CASEG(1, 1)
 #undef EVR_CASEG
         set_error("conv_igemm: no grouped kernel for kc=%d wm=%d nb=%d", kc, wm, nb);
         return EVR_ERR_UNSUPPORTED;
+    }
+    if (a.x3) {
+#define EVR_CASEX(WM_, NB_) if (wm == WM_ && nb == NB_) return launch_t<32, WM_, NB_, false, false, false, true>(a, d_args, stream, img);
+        EVR_CASEX(4, 4) EVR_CASEX(2, 4) EVR_CASEX(1, 4) EVR_CASEX(4, 2) EVR_CASEX(2, 2) EVR_CASEX(1, 2)
+        EVR_CASEX(4, 1) EVR_CASEX(2, 1) EVR_CASEX(1, 1)
+#undef EVR_CASEX
     }
 #define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false, false>(a, d_args, stream, img);
     EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
