@@ -8,7 +8,7 @@
 
 A step = one frame for each of S independent synthetic sequences per GPU (sequences shard across GPUs,
 SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
-forward (fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM + LPIPS against the
+forward (split-bf16 x3 MFMA, fp32 accumulate; EVR_FP32=1: exact fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM + LPIPS against the
 reference frame (LPIPS = AlexNet v0.1 structure on synthetic weights: the real ones cannot be downloaded here).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 W_, H_, BINS, K_EVENTS = 346, 260, 5, 15000
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak (micro-benchmark ceiling 2382)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -186,6 +187,12 @@ def main():
         rl_ms = sum(p['ms'] for p in lstm)
         rl_launches = sum(p['launches'] for p in lstm)
         achieved = rl_flops / (rl_ms * 1e-3) / 1e12 if rl_ms > 0 else 0.0
+        # arithmetic mode of the 32-channel-chunk convolutions (model.cpp finish_conv): default split-bf16
+        # (x = hi + lo, three bf16 MFMA products, fp32 accumulate: fp32-equivalent to ~1e-6 relative);
+        # EVR_FP32=1 selects the exact fp32 MFMA.  `achieved` counts ALGORITHMIC (direct convolution) flops in
+        # both modes; in split mode the matrix cores execute 3x that, reported as mfma_issue_*.
+        x3 = not os.environ.get('EVR_FP32')
+        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
         pmc = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc_path):
@@ -194,7 +201,7 @@ def main():
             "metric": "reconstructed frames/sec + Mevents/sec voxelized, E2VID 346x260 B=5",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3" if x3 else "f32", "data": "synthetic",
             "mevents_per_s": round(frames * K_EVENTS / elapsed / 1e6, 2),
             "model_tflops": round(flops_step * K * world / elapsed / 1e12, 2),
             "config": {"workload": "E2VID (synthetic weights, BN folded) on synthetic 346x260 Poisson events, 5 bins, "
@@ -206,9 +213,15 @@ def main():
                        "lpips_gflop_per_frame": round(lp.flops() / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
                        "scores": {"mse": tot[0, 0] / tot[0, 3], "ssim": tot[0, 1] / tot[0, 3], "lpips": tot[0, 2] / tot[0, 3],
                                   "count": int(tot[0, 3])}},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc,
-                         "kernel": "conv_igemm_kernel<32,WM,4,LSTM=true> (ConvLSTM gate convolutions)",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": pmc,
+                         "kernel": "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=%s> (ConvLSTM gate convolutions)"
+                                   % ("true" if x3 else "false"),
+                         "arithmetic": ("split bf16: x=hi+lo, w=hi+lo, acc += lo*hi + hi*lo + hi*hi on "
+                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate" if x3 else
+                                        "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"),
+                         "mfma_issue_tflops": round(achieved * (3 if x3 else 1), 2),
+                         "mfma_issue_frac": round(achieved * (3 if x3 else 1) / peak, 4),
                          "gflop_per_launch": round(rl_flops / max(rl_launches, 1) / 1e9, 3),
                          "avg_launch_us": round(1e3 * rl_ms / max(rl_launches, 1), 2), "launches": rl_launches,
                          "layers": {p['name']: {"us": round(1e3 * p['ms'] / p['launches'], 2),

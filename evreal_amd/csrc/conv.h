@@ -1,6 +1,9 @@
 // Convolution building blocks of the recurrent networks (NHWC fp32 activations on device).
 #pragma once
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
 namespace evr {
 
@@ -59,6 +62,32 @@ struct ConvArgs {
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };
+
+// fp32 -> bf16 bits, round to nearest even
+inline unsigned short bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline float bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// Split-bf16 weight packing (host side, at model creation): every aligned 32-float K chunk of a row becomes
+// 32 bf16 'hi' followed by 32 bf16 'lo' (w ~ hi + lo, both RNE) in the same 128 bytes, so the kernel's tile
+// loader does not change.
+inline void pack_x3(std::vector<float>& w) {
+    for (size_t base = 0; base + 32 <= w.size(); base += 32) {
+        unsigned short hi[32], lo[32];
+        for (int k = 0; k < 32; ++k) {
+            hi[k] = bf16_rne(w[base + k]);
+            lo[k] = bf16_rne(w[base + k] - bf16_to_f32(hi[k]));
+        }
+        memcpy(&w[base], hi, 64);
+        memcpy(&w[base + 16], lo, 64);
+    }
+}
+// arithmetic mode of the 32-channel-chunk convolutions: split-bf16 unless EVR_FP32=1 (exact fp32 MFMA)
+inline bool use_split_bf16() { return getenv("EVR_FP32") == nullptr; }
 
 // kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     // C layout of 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     // Pass A issues ALL of the wave's epilogue operand loads (c_prev / residual / skip) at once, so their HBM/L2
     // latency is paid once instead of once per element; pass B does the arithmetic and the stores.
+    if (ablate & 4) return;   // timing ablation: no epilogue at all
     const int epi = a.epi;
     const bool direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
     const bool need_yx = !direct || (a.pred_w != nullptr);

@@ -164,7 +164,7 @@ __global__ void lpips_final_kernel(const double* __restrict__ partials, double* 
 
 constexpr int SCORE_BLOCKS = 32;
 
-struct Layer { int cin, cout, k, pad; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
+struct Layer { int cin, cout, k, pad; bool x3 = false; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
 
 }  // namespace
 
@@ -255,6 +255,8 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
             L.w.assign((size_t)cout[l] * taps * cin[l], 0.f); L.b.assign(b->data_host, b->data_host + cout[l]);
             for (int co = 0; co < cout[l]; ++co) for (int ci = 0; ci < cin[l]; ++ci) for (int t = 0; t < taps; ++t)
                 L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
+            L.x3 = use_split_bf16();      // conv2..conv5 run on the same implicit-GEMM family as the networks
+            if (L.x3) pack_x3(L.w);
             if ((rc = up(L.w, &L.d_w))) break;
             if ((rc = up(L.b, &L.d_b))) break;
         }
@@ -303,7 +305,7 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.tp.ntaps = L.k * L.k; a.tp.ngroups = 1; a.tp.grp_cols = L.cout;
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
-        a.epi = EPI_BIAS_RELU;
+        a.epi = EPI_BIAS_RELU; a.x3 = L.x3 ? 1 : 0;
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));

@@ -246,33 +246,10 @@ int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout
     return EVR_OK;
 }
 
-// fp32 -> bf16 bits, round to nearest even
-inline unsigned short bf16_rne(float f) {
-    unsigned u; memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-inline float bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
-
-// Split-bf16 weight packing: every aligned 32-float K chunk of a row becomes 32 bf16 'hi' followed by 32 bf16 'lo'
-// (w ~ hi + lo, both RNE) in the same 128 bytes, so the kernel's tile loader does not change.
-void pack_x3(std::vector<float>& w) {
-    for (size_t base = 0; base + 32 <= w.size(); base += 32) {
-        unsigned short hi[32], lo[32];
-        for (int k = 0; k < 32; ++k) {
-            hi[k] = bf16_rne(w[base + k]);
-            lo[k] = bf16_rne(w[base + k] - bf16_to_f32(hi[k]));
-        }
-        memcpy(&w[base], hi, 64);
-        memcpy(&w[base + 16], lo, 64);
-    }
-}
-
 int finish_conv(evr_model* m, Conv& c) {
     int rc;
     // arithmetic mode: split-bf16 (3 MFMA products) for the 32-channel-chunk convolutions unless EVR_FP32=1
-    c.x3 = (c.kc == 32) && !getenv("EVR_FP32");
+    c.x3 = (c.kc == 32) && use_split_bf16();
     if (c.x3) pack_x3(c.w);
     if ((rc = upload(c.w, &c.d_w))) return rc;
     if ((rc = upload(c.b, &c.d_b))) return rc;
@@ -501,7 +478,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
-        if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM) ? atoi(e) : 0;
+        if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM || getenv("EVR_ABLATE_ALL")) ? atoi(e) : 0;
     }
     pick_conv_tile(c.args[0], c.kc, &c.wm, &c.nb);
     // direct-conv FLOPs: a transposed conv counts its k*k taps once per INPUT pixel (= k*k/4 per output pixel x 4 phases)
