@@ -45,6 +45,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate activations.  FAST (split-bf16 mode): v_exp_f32 / v_rcp_f32 forms, absolute error ~2e-7 -- an order below the
+// mode's own 2^-17 input rounding; the exact-fp32 mode keeps the libm-grade functions.
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    else return 1.0f / (1.0f + expf(-x));
+}
+template <bool FAST> __device__ __forceinline__ float tanh_t(float x) {
+    if constexpr (FAST) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+    else return tanhf(x);
+}
 
 template <int KC>
 __device__ __forceinline__ int swz(int row) {
@@ -202,14 +212,83 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             if (B_F4 % NT == 0 || tid + j * NT < B_F4) l[A_F4 + tid + j * NT] = rb[j];
     };
 
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
+
+    // Accumulator layout (the MFMAs run with the WEIGHT fragment as the A operand, so acc holds C^T): lane & 31 =
+    // pixel (GEMM row m0 + wmi*32 + r), register `reg` of block nb = channel n0 + nb*32 + (reg&3) + 8*(reg>>2) + 4*h.
+    // A lane owns ONE pixel and, per 32-column block, four runs of 4 consecutive channels: every epilogue operand
+    // load and result store is a 16-B access, the address arithmetic happens once per lane, and the fused
+    // prediction layer reduces over channels in registers.  The accumulators start at the bias, and the epilogue's
+    // operands (cell state / residual / fused skip) are requested here, a whole main loop before they are needed.
+    typedef float f4 __attribute__((ext_vector_type(4)));
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-
-    const int r = lane & 31, h = lane >> 5;
-    const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
+        for (int q = 0; q < 4; ++q) {
+            const f4 b4 = *(const f4*)(a.bias + n0 + nb * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[nb][4 * q + j] = b4[j];
+        }
+    const int epi = a.epi;
+    const int m = m0 + wmi * 32 + r;
+    const bool mvalid = m < M;
+    const bool direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
+    int e_img = 0, e_my = 0, e_mx = 0;
+    if (!direct || a.pred_w) {
+        const int mm = mvalid ? m : 0;
+        e_img = mm / hw;
+        const int rem = mm - e_img * hw;
+        e_my = rem / a.wm; e_mx = rem - e_my * a.wm;
+    }
+    const unsigned ct = (unsigned)a.cout_total;
+    const int nvalid = a.n_valid;
+    const bool vec = (ct & 3u) == 0;     // 16-B accesses need 4-channel alignment of the pixel rows
+    auto ld4 = [&](const float* p, unsigned off, int nv) -> f4 {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec && nv >= 4) return *(const f4*)(p + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nv) v[j] = p[off + j];
+        return v;
+    };
+    auto st4 = [&](float* p, unsigned off, f4 v, int nv) {
+        if (vec && nv >= 4) { *(f4*)(p + off) = v; return; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nv) p[off + j] = v[j];
+    };
+    // output pixel and first channel (inside its column group) of the lane in 32-column block nb
+    auto out_addr = [&](int nb, unsigned& opx, int& cgb, int& oy, int& ox) {
+        const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
+        cgb = n0 + nb * 32 - g * grp_cols + 4 * h;
+        oy = e_my * a.os + tp.grp_ofy[g]; ox = e_mx * a.os + tp.grp_ofx[g];
+        opx = direct ? (unsigned)m : (unsigned)((e_img * a.hout + oy) * a.wout + ox);
+    };
+    const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
+    const bool res = (epi == EPI_RESIDUAL_RELU);
+    constexpr int PN = LSTM ? 1 : NB;
+    f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
+    const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
+    const unsigned lstm_o = (unsigned)(mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
+    if (pre_ptr) {
+#pragma unroll
+        for (int nb = 0; nb < PN; ++nb) {
+            unsigned opx; int cgb, oy, ox;
+            out_addr(nb, opx, cgb, oy, ox);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LSTM) {
+                    if (mvalid) v = *(const f4*)(pre_ptr + lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
+                } else {
+                    const int c4 = cgb + 8 * q;
+                    if (mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct + (unsigned)c4, nvalid - c4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[nb][4 * q + j] = v[j];
+            }
+        }
+    }
 
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     issue(0);
@@ -248,9 +327,10 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                     // weight row: slots 0-3 = hi (8 bf16 each), slots 4-7 = lo
                     const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((2 * slab + h) ^ sw)]);
                     const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((4 + 2 * slab + h) ^ sw)]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[nb], 0, 0, 0);
+                    // weights are the A operand (rows), activations the B operand (columns): acc = C^T (see epilogue)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
                 }
             }
         } else {
@@ -264,241 +344,120 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                     if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
                 }
                 const float4 bv = lb[nb * 32 * SP + q];
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nb], 0, 0, 0);
+                // weights are the A operand (rows), activations the B operand (columns): acc = C^T (see epilogue)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[nb], 0, 0, 0);
             }
         }
         }
         if constexpr (REGSTAGE) { if (s + 1 < nsteps) store_staged(buf ^ 1); }   // waits for the loads, ds_write_b128
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // C layout of 32x32 MFMA: column (channel) = lane & 31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Pass A issues ALL of the wave's epilogue operand loads (c_prev / residual / skip) at once, so their HBM/L2
-    // latency is paid once instead of once per element; pass B does the arithmetic and the stores.
+    // ------------------------------------------------------------------ epilogue (layout: see the accumulator setup)
     if (ablate & 4) return;   // timing ablation: no epilogue at all
-    const int epi = a.epi;
-    const bool direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
-    const bool need_yx = !direct || (a.pred_w != nullptr);
-    const int rbase = m0 + wmi * 32 + 4 * h;
-    auto row = [&](int reg, int& e_img, int& e_my, int& e_mx) -> int {
-        const int m = rbase + (reg & 3) + 8 * (reg >> 2);
-        e_img = 0; e_my = 0; e_mx = 0;
-        if (need_yx && m < M) {
-            e_img = m / hw;
-            const int rem = m - e_img * hw;
-            e_my = rem / a.wm; e_mx = rem - e_my * a.wm;
-        }
-        return m;
-    };
-    auto pixel = [&](int m, int e_img, int e_my, int e_mx, int g, int& o_y, int& o_x) -> int64_t {
-        o_y = e_my * a.os + tp.grp_ofy[g]; o_x = e_mx * a.os + tp.grp_ofx[g];
-        return direct ? (int64_t)m : ((int64_t)e_img * a.hout + o_y) * a.wout + o_x;
-    };
-    constexpr int PN = LSTM ? 1 : NB;
-    f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
-    const float* pre_ptr = LSTM ? a.state : (epi == EPI_RESIDUAL_RELU ? a.residual : a.post_add);
-    if (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT) pre_ptr = nullptr;
-    // the common case -- plain conv, output pixel == GEMM row, every column real -- takes a lean path: all the
-    // epilogue-kind decisions are made once here instead of once per output element (64 per thread at NB = 4)
-    const bool lean = !LSTM && !GROUPED && direct && a.pred_w == nullptr && a.n_valid == a.cout &&
-                      (epi == EPI_BIAS || epi == EPI_BIAS_RELU || epi == EPI_RESIDUAL_RELU);
-    const unsigned ct = (unsigned)a.cout_total;
+    if constexpr (LSTM) {
+        static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
+        // N tile of 128 = 4 gates x 32 hidden channels (rows permuted at model creation); the conv is stride 1 on
+        // the state's own grid, so the output pixel is the GEMM row.  submodules.py:227-245
+        if (!mvalid) return;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        int e_img, e_my, e_mx, o_y, o_x;
-        if (lean) {
-            const int m = rbase + (reg & 3) + 8 * (reg >> 2);
+        for (int q = 0; q < 4; ++q) {
+            f4 cn, hn;
 #pragma unroll
-            for (int nb = 0; nb < PN; ++nb)
-                pre[nb][reg] = (pre_ptr && m < M) ? pre_ptr[(unsigned)m * ct + (unsigned)(n0 + nb * 32 + r)] : 0.f;
-            continue;
-        }
-        if (GROUPED && (epi == EPI_BIAS_RELU || epi == EPI_BIAS)) continue;   // the grouped lean path prefetches itself
-        const int m = row(reg, e_img, e_my, e_mx);
-#pragma unroll
-        for (int nb = 0; nb < PN; ++nb) {
-            float v = 0.f;
-            if (pre_ptr && m < M) {
-                if constexpr (LSTM) {
-                    v = pre_ptr[(int64_t)m * a.hidden + (n0 >> 2) + r];
-                } else {
-                    const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
-                    const int cg = n0 + nb * 32 + r - g * grp_cols;
-                    if (cg < a.n_valid) v = pre_ptr[pixel(m, e_img, e_my, e_mx, g, o_y, o_x) * a.cout_total + cg];
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float gi = sigmoid_t<X3>(acc[0][4 * q + j]);
+                const float gf = sigmoid_t<X3>(acc[1][4 * q + j]);
+                const float go = sigmoid_t<X3>(acc[2][4 * q + j]);
+                const float gc = tanh_t<X3>(acc[3][4 * q + j]);
+                cn[j] = __fadd_rn(__fmul_rn(gf, pre[0][4 * q + j]), __fmul_rn(gi, gc));   // submodules.py:242
+                hn[j] = go * tanh_t<X3>(cn[j]);                                            // submodules.py:243
             }
-            pre[nb][reg] = v;
+            *(f4*)(a.state + lstm_o + 8 * q) = cn;
+            *(f4*)(a.out + lstm_o + 8 * q) = hn;
         }
-    }
-    if constexpr (!LSTM && !GROUPED) {
-        if (lean) {
-            float bv[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[nb] = a.bias[n0 + nb * 32 + r];
-            const bool relu = epi != EPI_BIAS, res = epi == EPI_RESIDUAL_RELU, pa = a.post_add != nullptr;
-            float* outp = a.out + n0 + r;
-            const float* padd = a.post_add ? a.post_add + n0 + r : nullptr;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = rbase + (reg & 3) + 8 * (reg >> 2);
-                if (m >= M) continue;
-                const unsigned o = (unsigned)m * ct;          // < 2^30 elements (checked at allocation)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float v = acc[nb][reg] + bv[nb];
-                    if (res) v += pre[nb][reg];
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (pa) v += res ? padd[o + nb * 32] : pre[nb][reg];
-                    outp[o + nb * 32] = v;
-                }
-            }
-            return;
-        }
-    }
-    if constexpr (GROUPED) {
-        // transposed conv (sub-pixel phases as column groups): lean path.  The wave's 32 GEMM rows are consecutive
-        // input-grid pixels, so ONE division decodes the first and the rest follow by carry; per group only the
-        // (ofy, ofx) offsets differ.  32-bit element offsets (tensors are < 2^30 elements, checked at allocation).
-        if (epi == EPI_BIAS_RELU || epi == EPI_BIAS) {
-            const int b_img = rbase / hw, b_rem = rbase - b_img * hw;
-            const int b_my = b_rem / a.wm, b_mx = b_rem - b_my * a.wm;
-            int g_oy[NB], g_ox[NB], g_c[NB];
-            float bv[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int g = (n0 + nb * 32) / grp_cols;
-                g_oy[nb] = tp.grp_ofy[g]; g_ox[nb] = tp.grp_ofx[g]; g_c[nb] = n0 + nb * 32 + r - g * grp_cols;
-                bv[nb] = a.bias[n0 + nb * 32 + r];
-            }
-            const bool relu = epi != EPI_BIAS;
-            const float* padd = a.post_add;
-            const float* pw = a.pred_w;
-            // pass A: skip operand prefetch (all loads in flight together)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int d = (reg & 3) + 8 * (reg >> 2);
-                int mx = b_mx + d, my = b_my, img = b_img;
-                while (mx >= a.wm) { mx -= a.wm; ++my; }
-                while (my >= a.hm) { my -= a.hm; ++img; }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float v = 0.f;
-                    if (padd && rbase + d < M && g_c[nb] < a.n_valid) {
-                        const unsigned opx = (unsigned)((img * a.hout + my * a.os + g_oy[nb]) * a.wout + mx * a.os + g_ox[nb]);
-                        v = padd[opx * ct + (unsigned)g_c[nb]];
-                    }
-                    pre[nb][reg] = v;
-                }
-            }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int d = (reg & 3) + 8 * (reg >> 2);
-                if (rbase + d >= M) continue;
-                int mx = b_mx + d, my = b_my, img = b_img;
-                while (mx >= a.wm) { mx -= a.wm; ++my; }
-                while (my >= a.hm) { my -= a.hm; ++img; }
-                float pred_part = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int oy = my * a.os + g_oy[nb], ox = mx * a.os + g_ox[nb];
-                    const unsigned opx = (unsigned)((img * a.hout + oy) * a.wout + ox);
-                    if (g_c[nb] < a.n_valid) {
-                        const unsigned o = opx * ct + (unsigned)g_c[nb];
-                        float v = acc[nb][reg] + bv[nb];
-                        if (relu) v = fmaxf(v, 0.f);
-                        if (pw && a.out) a.out[o] = v;               // debug copy of the layer's own output
-                        if (padd) v += pre[nb][reg];                 // fused skip_sum
-                        if (!pw && a.out) a.out[o] = v;
-                        if (pw) pred_part = fmaf(v, pw[g_c[nb]], pred_part);
-                    }
-                    if (pw && ((n0 + nb * 32 + 32) % grp_cols) == 0) {   // the group's last block closes one output pixel
-#pragma unroll
-                        for (int o2 = 16; o2 > 0; o2 >>= 1) pred_part += __shfl_xor(pred_part, o2, 64);
-                        if (r == 0) {
-                            const int y = oy - a.crop_y0, x = ox - a.crop_x0;
-                            float sres = pred_part + a.pred_b;
-                            if (a.pred_sigmoid) sres = sigmoidf_(sres);
-                            if (a.prev_rec) a.prev_rec[opx] = sres;
-                            if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
-                                img_out[(unsigned)((img * a.crop_h + y) * a.crop_w + x)] = sres;
-                        }
-                        pred_part = 0.f;
-                    }
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        int e_img, e_my, e_mx, o_y, o_x;
-        const int m = row(reg, e_img, e_my, e_mx);
-        if (m >= M) continue;
-        int64_t opix = pixel(m, e_img, e_my, e_mx, 0, o_y, o_x);
-        if constexpr (LSTM) {
-            static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
-            const int c = (n0 >> 2) + r;   // hidden channel: N tile of 128 = 4 gates x 32 channels
-            const float gi = sigmoidf_(acc[0][reg] + a.bias[n0 + r]);
-            const float gf = sigmoidf_(acc[1][reg] + a.bias[n0 + 32 + r]);
-            const float go = sigmoidf_(acc[2][reg] + a.bias[n0 + 64 + r]);
-            const float gc = tanhf(acc[3][reg] + a.bias[n0 + 96 + r]);
-            const int64_t o = opix * a.hidden + c;
-            const float cn = __fadd_rn(__fmul_rn(gf, pre[0][reg]), __fmul_rn(gi, gc));   // submodules.py:242
-            a.state[o] = cn;
-            a.out[o] = go * tanhf(cn);                                                    // submodules.py:243
-            continue;
-        }
+        return;
+    } else {
+        const float* pw = a.pred_w;
         float pred_part = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int n = n0 + nb * 32 + r;
-            const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
-            const int cg = n - g * grp_cols;          // channel inside the group
-            if constexpr (GROUPED) opix = pixel(m, e_img, e_my, e_mx, g, o_y, o_x);
-            float v = acc[nb][reg] + a.bias[n];
-            if (epi == EPI_GRU_ZR) {
-                const int C = a.hidden;
-                if (n < C) {
-                    a.aux0[opix * C + n] = sigmoidf_(v);                 // update gate z
-                } else if (n < 2 * C) {
-                    const int c = n - C;
-                    a.out[opix * C + c] = a.state[opix * C + c] * sigmoidf_(v);   // h * reset
-                }
-            } else if (epi == EPI_GRU_OUT) {
-                const int C = a.hidden;
-                if (n < C) {
-                    const int64_t o = opix * C + n;
-                    const float z = a.aux0[o], hp = a.state[o];
-                    const float cand = tanhf(v);
-                    // submodules.py:285: prev*(1-update) + out*update
-                    a.state[o] = __fadd_rn(__fmul_rn(hp, 1.0f - z), __fmul_rn(cand, z));
-                }
-            } else if (cg < a.n_valid) {
-                const int64_t o = opix * a.cout_total + cg;
-                const int pn = LSTM ? 0 : nb;
-                if (epi == EPI_RESIDUAL_RELU) v += pre[pn][reg];
-                if (epi == EPI_BIAS_TANH) v = tanhf(v);
-                else if (epi != EPI_BIAS) v = fmaxf(v, 0.f);
-                if (a.pred_w && a.out) a.out[o] = v;          // debug copy of the layer's own output
-                // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
-                if (a.post_add) v += (epi == EPI_RESIDUAL_RELU) ? a.post_add[o] : pre[pn][reg];
-                if (!a.pred_w && a.out) a.out[o] = v;
-                if (a.pred_w) pred_part = fmaf(v, a.pred_w[cg], pred_part);
-            }
-            // fused 1x1 prediction conv: the group's last 32-column block closes one output pixel
-            if (a.pred_w && ((n0 + nb * 32 + 32) % grp_cols) == 0) {
+            unsigned opx; int cgb, oy, ox;
+            out_addr(nb, opx, cgb, oy, ox);
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) pred_part += __shfl_xor(pred_part, o, 64);
-                if (r == 0) {
-                    const int y = o_y - a.crop_y0, x = o_x - a.crop_x0;
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = n0 + nb * 32 + 8 * q + 4 * h;   // GEMM column of the run
+                const int c4 = cgb + 8 * q;                    // channel inside the column group
+                f4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
+                if (!mvalid) continue;
+                if (gru) {
+                    // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
+                    const int C = a.hidden;
+                    if (epi == EPI_GRU_ZR) {
+                        if (n4 < C) {
+                            f4 z;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<false>(v[j]);
+                            *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
+                        } else if (n4 < 2 * C) {
+                            const unsigned o = opx * (unsigned)C + (unsigned)(n4 - C);
+                            const f4 hp = *(const f4*)(a.state + o);
+                            f4 hr;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<false>(v[j]);
+                            *(f4*)(a.out + o) = hr;                                           // h * reset
+                        }
+                    } else if (n4 < C) {
+                        const unsigned o = opx * (unsigned)C + (unsigned)n4;
+                        const f4 z = *(const f4*)(a.aux0 + o), hp = *(const f4*)(a.state + o);
+                        f4 hn;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
+                            hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<false>(v[j]), z[j]));
+                        *(f4*)(a.state + o) = hn;
+                    }
+                } else if (c4 < nvalid) {
+                    const int nv = nvalid - c4;
+                    const unsigned o = opx * ct + (unsigned)c4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = v[j];
+                        if (res) t += pre[nb][4 * q + j];
+                        if (epi == EPI_BIAS_TANH) t = tanh_t<false>(t);
+                        else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
+                        v[j] = t;
+                    }
+                    if (pw && a.out) st4(a.out, o, v, nv);        // debug copy of the layer's own output
+                    // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
+                    if (a.post_add) {
+                        if (res) { const f4 s4 = ld4(a.post_add, o, nv); v += s4; }
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += pre[nb][4 * q + j];
+                        }
+                    }
+                    if (!pw && a.out) st4(a.out, o, v, nv);
+                    if (pw) {
+                        const f4 w4 = ld4(pw, (unsigned)c4, nv);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
+                    }
+                }
+            }
+            // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
+            // pixel; the channels of a pixel live in the two lanes r and r+32
+            if (pw && ((n0 + nb * 32 + 32) % grp_cols) == 0) {
+                pred_part += __shfl_xor(pred_part, 32, 64);
+                if (h == 0 && mvalid) {
+                    const int y = oy - a.crop_y0, x = ox - a.crop_x0;
                     float sres = pred_part + a.pred_b;
-                    if (a.pred_sigmoid) sres = sigmoidf_(sres);
-                    if (a.prev_rec) a.prev_rec[opix] = sres;
+                    if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
+                    if (a.prev_rec) a.prev_rec[opx] = sres;
                     if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
-                        img_out[((int64_t)e_img * a.crop_h + y) * a.crop_w + x] = sres;
+                        img_out[(unsigned)((e_img * a.crop_h + y) * a.crop_w + x)] = sres;
                 }
                 pred_part = 0.f;
             }
@@ -526,6 +485,9 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
     EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split-bf16 path needs 32-channel chunks");
+    EVR_REQUIRE(a.epi != EPI_LSTM || (a.os == 1 && a.hout == a.hm && a.wout == a.wm && a.hidden % 32 == 0),
+                "conv_igemm: the ConvLSTM epilogue writes the state grid itself (stride 1, hidden %% 32 == 0)");
+    EVR_REQUIRE((a.epi != EPI_GRU_ZR && a.epi != EPI_GRU_OUT) || a.hidden % 4 == 0, "conv_igemm: ConvGRU hidden %d not a multiple of 4", a.hidden);
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
         if (a.x3) {
