@@ -1,4 +1,11 @@
-// Convolution building blocks of the recurrent networks (NHWC fp32 activations on device).
+// Convolution building blocks of the recurrent networks (NHWC activations on device).
+//
+// Activation formats.  PLAIN: fp32, pixel-major, channels contiguous.  PACKED (split-bf16 mode, tensors that feed
+// the matrix cores): same 4 bytes per channel, but every group of 8 channels (32 B) holds the bf16 'hi' halves of
+// its 8 values (16 B) followed by the 8 bf16 'lo' halves (16 B), value ~ hi + lo (both RNE, 16 significant bits).
+// A 16-B slot of a pixel row is then directly one MFMA operand (8 k-values), so the consumer's main loop has no
+// conversion work; the PRODUCER's epilogue does the split once per element instead of once per (tap, N tile).
+// Weight rows use the same layout per 8 k-values.
 #pragma once
 #include "common.h"
 #include <cstdlib>
@@ -57,8 +64,10 @@ struct ConvArgs {
     // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
     const float* pred_w; float pred_b; int pred_sigmoid;
     int crop_h, crop_w, crop_y0, crop_x0;
-    int x3;                   // weights are packed for the split-bf16 path: every 32-float K chunk of a row holds
-                              // 32 bf16 'hi' then 32 bf16 'lo' (same 128 B); the kernel splits activations on the fly
+    int x3;                   // weights are in the split-bf16 layout (pack_x3); activations are split on the fly unless
+    int in_packed;            //   in0/in1 are PACKED tensors (then the main loop feeds LDS slots straight to the MFMAs)
+    int out_packed;           // write `out` PACKED (n_valid and cout_total multiples of 8)
+    int res_packed, padd_packed, state_packed;   // format of residual / post_add / the ConvGRU hidden state
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };
@@ -72,18 +81,18 @@ inline unsigned short bf16_rne(float f) {
 }
 inline float bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
-// Split-bf16 weight packing (host side, at model creation): every aligned 32-float K chunk of a row becomes
-// 32 bf16 'hi' followed by 32 bf16 'lo' (w ~ hi + lo, both RNE) in the same 128 bytes, so the kernel's tile
-// loader does not change.
+// Split-bf16 weight packing (host side, at model creation): every aligned group of 8 k-values of a row becomes
+// 8 bf16 'hi' followed by 8 bf16 'lo' (w ~ hi + lo, both RNE) in the same 32 bytes -- the PACKED layout above, so
+// the kernel's tile loader does not change.
 inline void pack_x3(std::vector<float>& w) {
-    for (size_t base = 0; base + 32 <= w.size(); base += 32) {
-        unsigned short hi[32], lo[32];
-        for (int k = 0; k < 32; ++k) {
+    for (size_t base = 0; base + 8 <= w.size(); base += 8) {
+        unsigned short hi[8], lo[8];
+        for (int k = 0; k < 8; ++k) {
             hi[k] = bf16_rne(w[base + k]);
             lo[k] = bf16_rne(w[base + k] - bf16_to_f32(hi[k]));
         }
-        memcpy(&w[base], hi, 64);
-        memcpy(&w[base + 16], lo, 64);
+        memcpy(&w[base], hi, 16);
+        memcpy(&w[base + 4], lo, 16);
     }
 }
 // arithmetic mode of the 32-channel-chunk convolutions: split-bf16 unless EVR_FP32=1 (exact fp32 MFMA)
@@ -106,6 +115,7 @@ struct HeadArgs {
     const float* bias;   // [cout]
     float* out;
     int relu;
+    int out_packed;      // write `out` in the PACKED activation format
 };
 int launch_head_conv(const HeadArgs& a, hipStream_t stream);
 
@@ -118,6 +128,7 @@ struct PredArgs {
     int H, W, iy0, ix0;                  // crop window
     float* img;
     float* prev_rec;                     // optional un-cropped copy [n,1,hp,wp]
+    int x_packed, skip_packed;           // activation formats
 };
 int launch_pred(const PredArgs& a, hipStream_t stream);
 
@@ -135,10 +146,12 @@ int launch_dynamic_filter(const float* x, const float* coeff, const float* bases
                           int c, hipStream_t stream);
 
 // Bilinear x2 (align_corners=False) of (x + skip): NHWC [n,h,w,c] -> [n,2h,2w,c]  (submodules.py:88)
-int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, hipStream_t stream);
+// (x_packed / skip_packed: input formats; the output is PLAIN)
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, hipStream_t stream);
 // out = x + y (skip_sum, model_util.py:4-5) when it cannot be fused into a producer epilogue
-int launch_add(const float* x, const float* y, float* out, int64_t n, hipStream_t stream);
+// (packed: all three tensors are PACKED)
+int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream);
 // NHWC -> NCHW copy (debug/parity reads)
-int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, hipStream_t stream);
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream);
 
 }  // namespace evr

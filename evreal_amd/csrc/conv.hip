@@ -71,6 +71,33 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+typedef float f4 __attribute__((ext_vector_type(4)));
+// PACKED activation format (conv.h): 4 consecutive channels c4..c4+3 (c4 % 4 == 0) of a pixel row are an 8-B 'hi'
+// piece and, 16 B further, an 8-B 'lo' piece.  pk_off = float-element offset of the hi piece; lo = +4 floats.
+__device__ __forceinline__ unsigned pk_off(unsigned row_off, int c4) { return row_off + (unsigned)((c4 & ~7) + ((c4 & 4) >> 1)); }
+__device__ __forceinline__ f4 unpack4(uint2 hi, uint2 lo) {
+    f4 v;
+    v[0] = __uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16);
+    v[1] = __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u);
+    v[2] = __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16);
+    v[3] = __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void pack4(f4 v, uint2& hi, uint2& lo) {
+    hi.x = cvt_pk_bf16(v[0], v[1]); hi.y = cvt_pk_bf16(v[2], v[3]);
+    lo.x = cvt_pk_bf16(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = cvt_pk_bf16(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+}
+__device__ __forceinline__ f4 load4_packed(const float* p, unsigned row_off, int c4) {
+    const float* q = p + pk_off(row_off, c4);
+    return unpack4(*(const uint2*)q, *(const uint2*)(q + 4));
+}
+__device__ __forceinline__ void store4_packed(float* p, unsigned row_off, int c4, f4 v) {
+    uint2 hi, lo;
+    pack4(v, hi, lo);
+    float* q = p + pk_off(row_off, c4);
+    *(uint2*)q = hi; *(uint2*)(q + 4) = lo;
+}
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -80,7 +107,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, bool X3 = false>
+// X3: 0 = fp32 MFMA; 1 = split-bf16 MFMA, PLAIN activations split in registers; 2 = split-bf16 MFMA, PACKED activations
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
@@ -221,7 +249,6 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     // load and result store is a 16-B access, the address arithmetic happens once per lane, and the fused
     // prediction layer reduces over channels in registers.  The accumulators start at the bias, and the epilogue's
     // operands (cell state / residual / fused skip) are requested here, a whole main loop before they are needed.
-    typedef float f4 __attribute__((ext_vector_type(4)));
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -244,18 +271,15 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     }
     const unsigned ct = (unsigned)a.cout_total;
     const int nvalid = a.n_valid;
-    const bool vec = (ct & 3u) == 0;     // 16-B accesses need 4-channel alignment of the pixel rows
-    auto ld4 = [&](const float* p, unsigned off, int nv) -> f4 {
-        f4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vec && nv >= 4) return *(const f4*)(p + off);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nv) v[j] = p[off + j];
-        return v;
+    // (row = element offset of the pixel row, c4 = first of the lane's 4 channels; n_valid and cout_total are
+    // multiples of 4 -- checked at launch -- so a run is never ragged)
+    auto ld4 = [&](const float* p, unsigned row, int c4, int packed) -> f4 {
+        if (packed) return load4_packed(p, row, c4);
+        return *(const f4*)(p + row + (unsigned)c4);
     };
-    auto st4 = [&](float* p, unsigned off, f4 v, int nv) {
-        if (vec && nv >= 4) { *(f4*)(p + off) = v; return; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nv) p[off + j] = v[j];
+    auto st4 = [&](float* p, unsigned row, int c4, f4 v, int packed) {
+        if (packed) store4_packed(p, row, c4, v);
+        else *(f4*)(p + row + (unsigned)c4) = v;
     };
     // output pixel and first channel (inside its column group) of the lane in 32-column block nb
     auto out_addr = [&](int nb, unsigned& opx, int& cgb, int& oy, int& ox) {
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                     if (mvalid) v = *(const f4*)(pre_ptr + lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
                 } else {
                     const int c4 = cgb + 8 * q;
-                    if (mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct + (unsigned)c4, nvalid - c4);
+                    if (mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct, c4, res ? a.res_packed : a.padd_packed);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pre[nb][4 * q + j] = v[j];
@@ -295,6 +319,9 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     if constexpr (REGSTAGE) { store_staged(0); }
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
+        // LDS-DMA completion is NOT left to hipcc's automatic waitcnt insertion: with every fragment read bit-cast
+        // to bf16 (PACKED mode) it no longer sees the reads alias the DMA writes and emits no vmcnt wait at all
+        if constexpr (!REGSTAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ablate & 1)) __syncthreads();    // tile s is in LDS for every wave; everyone left tile s-1
         if (s + 1 < nsteps && !(ablate & 2)) issue(buf ^ 1);   // next tile: LDS-DMA, or plain loads into registers
         int groups_now = 0;
@@ -304,29 +331,36 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         }
         const float4* la = &lds[buf][(wmi * 32 + r) * SP];
         const float4* lb = &lds[buf][A_F4 + r * SP];
-        if constexpr (X3) {
-            static_assert(!X3 || KC == 32, "split-bf16 tiles are 32 k wide");
-            const u32x4_t* lbu = (const u32x4_t*)lb;
+        if constexpr (X3 != 0) {
+            static_assert(X3 == 0 || KC == 32, "split-bf16 tiles are 32 k wide");
+            // (every fragment is loaded AS float4, the LDS array's own type, and bit-cast: reads through a punned
+            // pointer carry no alias with the LDS-DMA writes and hipcc then drops the vmcnt wait in front of them)
 #pragma unroll
             for (int slab = 0; slab < 2; ++slab) {           // two 16-k MFMA slabs per step
-                // this lane's 8 activations k = 16*slab + 8*h .. +7 (two 16-B slots), split x = hi + lo in registers
-                const float4 x0 = la[(4 * slab + 2 * h) ^ sw], x1 = la[(4 * slab + 2 * h + 1) ^ sw];
-                u32x4_t ah, al;
-                ah[0] = cvt_pk_bf16(x0.x, x0.y); ah[1] = cvt_pk_bf16(x0.z, x0.w);
-                ah[2] = cvt_pk_bf16(x1.x, x1.y); ah[3] = cvt_pk_bf16(x1.z, x1.w);
-                al[0] = cvt_pk_bf16(x0.x - __uint_as_float(ah[0] << 16), x0.y - __uint_as_float(ah[0] & 0xffff0000u));
-                al[1] = cvt_pk_bf16(x0.z - __uint_as_float(ah[1] << 16), x0.w - __uint_as_float(ah[1] & 0xffff0000u));
-                al[2] = cvt_pk_bf16(x1.x - __uint_as_float(ah[2] << 16), x1.y - __uint_as_float(ah[2] & 0xffff0000u));
-                al[3] = cvt_pk_bf16(x1.z - __uint_as_float(ah[3] << 16), x1.w - __uint_as_float(ah[3] & 0xffff0000u));
-                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+                // this lane's 8 k-values = unit u of the 32-k chunk (slots 2u, 2u+1 of the row)
+                const int u = 2 * slab + h;
+                bf16x8 a_hi, a_lo;
+                if constexpr (X3 == 2) {     // PACKED activations: slot 2u = 8 hi, slot 2u+1 = 8 lo
+                    a_hi = __builtin_bit_cast(bf16x8, la[(2 * u) ^ sw]);
+                    a_lo = __builtin_bit_cast(bf16x8, la[(2 * u + 1) ^ sw]);
+                } else {                     // PLAIN activations: split x = hi + lo in registers
+                    const float4 x0 = la[(2 * u) ^ sw], x1 = la[(2 * u + 1) ^ sw];
+                    u32x4_t ah, al;
+                    ah[0] = cvt_pk_bf16(x0.x, x0.y); ah[1] = cvt_pk_bf16(x0.z, x0.w);
+                    ah[2] = cvt_pk_bf16(x1.x, x1.y); ah[3] = cvt_pk_bf16(x1.z, x1.w);
+                    al[0] = cvt_pk_bf16(x0.x - __uint_as_float(ah[0] << 16), x0.y - __uint_as_float(ah[0] & 0xffff0000u));
+                    al[1] = cvt_pk_bf16(x0.z - __uint_as_float(ah[1] << 16), x0.w - __uint_as_float(ah[1] & 0xffff0000u));
+                    al[2] = cvt_pk_bf16(x1.x - __uint_as_float(ah[2] << 16), x1.y - __uint_as_float(ah[2] & 0xffff0000u));
+                    al[3] = cvt_pk_bf16(x1.z - __uint_as_float(ah[3] << 16), x1.w - __uint_as_float(ah[3] & 0xffff0000u));
+                    a_hi = __builtin_bit_cast(bf16x8, ah); a_lo = __builtin_bit_cast(bf16x8, al);
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if constexpr (GROUPED) {
                         if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
                     }
-                    // weight row: slots 0-3 = hi (8 bf16 each), slots 4-7 = lo
-                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((2 * slab + h) ^ sw)]);
-                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lbu[nb * 32 * SP + ((4 + 2 * slab + h) ^ sw)]);
+                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
+                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
                     // weights are the A operand (rows), activations the B operand (columns): acc = C^T (see epilogue)
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
@@ -367,15 +401,16 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
             f4 cn, hn;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float gi = sigmoid_t<X3>(acc[0][4 * q + j]);
-                const float gf = sigmoid_t<X3>(acc[1][4 * q + j]);
-                const float go = sigmoid_t<X3>(acc[2][4 * q + j]);
-                const float gc = tanh_t<X3>(acc[3][4 * q + j]);
+                const float gi = sigmoid_t<(X3 != 0)>(acc[0][4 * q + j]);
+                const float gf = sigmoid_t<(X3 != 0)>(acc[1][4 * q + j]);
+                const float go = sigmoid_t<(X3 != 0)>(acc[2][4 * q + j]);
+                const float gc = tanh_t<(X3 != 0)>(acc[3][4 * q + j]);
                 cn[j] = __fadd_rn(__fmul_rn(gf, pre[0][4 * q + j]), __fmul_rn(gi, gc));   // submodules.py:242
-                hn[j] = go * tanh_t<X3>(cn[j]);                                            // submodules.py:243
+                hn[j] = go * tanh_t<(X3 != 0)>(cn[j]);                                            // submodules.py:243
             }
-            *(f4*)(a.state + lstm_o + 8 * q) = cn;
-            *(f4*)(a.out + lstm_o + 8 * q) = hn;
+            *(f4*)(a.state + lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
+            if (a.out_packed) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
+            else *(f4*)(a.out + lstm_o + 8 * q) = hn;
         }
         return;
     } else {
@@ -403,25 +438,23 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                             for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<false>(v[j]);
                             *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
                         } else if (n4 < 2 * C) {
-                            const unsigned o = opx * (unsigned)C + (unsigned)(n4 - C);
-                            const f4 hp = *(const f4*)(a.state + o);
+                            const f4 hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
                             f4 hr;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<false>(v[j]);
-                            *(f4*)(a.out + o) = hr;                                           // h * reset
+                            st4(a.out, opx * (unsigned)C, n4 - C, hr, a.out_packed);      // h * reset
                         }
                     } else if (n4 < C) {
                         const unsigned o = opx * (unsigned)C + (unsigned)n4;
-                        const f4 z = *(const f4*)(a.aux0 + o), hp = *(const f4*)(a.state + o);
+                        const f4 z = *(const f4*)(a.aux0 + o), hp = ld4(a.state, opx * (unsigned)C, n4, a.state_packed);
                         f4 hn;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
                             hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<false>(v[j]), z[j]));
-                        *(f4*)(a.state + o) = hn;
+                        st4(a.state, opx * (unsigned)C, n4, hn, a.state_packed);
                     }
                 } else if (c4 < nvalid) {
-                    const int nv = nvalid - c4;
-                    const unsigned o = opx * ct + (unsigned)c4;
+                    const unsigned orow = opx * ct;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = v[j];
@@ -430,18 +463,18 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
                         else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
                         v[j] = t;
                     }
-                    if (pw && a.out) st4(a.out, o, v, nv);        // debug copy of the layer's own output
+                    if (pw && a.out) st4(a.out, orow, c4, v, a.out_packed);        // debug copy of the layer's own output
                     // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
                     if (a.post_add) {
-                        if (res) { const f4 s4 = ld4(a.post_add, o, nv); v += s4; }
+                        if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
                         else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += pre[nb][4 * q + j];
                         }
                     }
-                    if (!pw && a.out) st4(a.out, o, v, nv);
+                    if (!pw && a.out) st4(a.out, orow, c4, v, a.out_packed);
                     if (pw) {
-                        const f4 w4 = ld4(pw, (unsigned)c4, nv);
+                        const f4 w4 = *(const f4*)(pw + c4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
                     }
@@ -466,7 +499,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 #endif   // __HIP_DEVICE_COMPILE__
 }
 
-template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, bool X3 = false>
+template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
@@ -485,15 +518,21 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
     EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split-bf16 path needs 32-channel chunks");
+    EVR_REQUIRE(a.n_valid % 4 == 0 && a.cout_total % 4 == 0, "conv_igemm: output channels %d/%d not multiples of 4 (16-B epilogue accesses)", a.n_valid, a.cout_total);
     EVR_REQUIRE(a.epi != EPI_LSTM || (a.os == 1 && a.hout == a.hm && a.wout == a.wm && a.hidden % 32 == 0),
                 "conv_igemm: the ConvLSTM epilogue writes the state grid itself (stride 1, hidden %% 32 == 0)");
     EVR_REQUIRE((a.epi != EPI_GRU_ZR && a.epi != EPI_GRU_OUT) || a.hidden % 4 == 0, "conv_igemm: ConvGRU hidden %d not a multiple of 4", a.hidden);
+    const bool packed_io = a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed;
+    EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split-bf16 mode");
+    EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
+    const int mode = a.x3 ? (a.in_packed ? 2 : 1) : 0;
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
-        if (a.x3) {
-            if (wm == 4) return launch_t<32, 4, 4, true, false, true, true>(a, d_args, stream, img);
-            if (wm == 2) return launch_t<32, 2, 4, true, false, false, true>(a, d_args, stream, img);
-            return launch_t<32, 1, 4, true, false, false, true>(a, d_args, stream, img);
+        EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 ConvLSTM kernel takes PACKED inputs");
+        if (mode == 2) {
+            if (wm == 4) return launch_t<32, 4, 4, true, false, true, 2>(a, d_args, stream, img);
+            if (wm == 2) return launch_t<32, 2, 4, true, false, false, 2>(a, d_args, stream, img);
+            return launch_t<32, 1, 4, true, false, false, 2>(a, d_args, stream, img);
         }
         if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
         // register staging measured +1..4 % over LDS-DMA for this kernel (EVR_LSTM_DMA=1 selects the DMA loader)
@@ -503,15 +542,16 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
     }
     if (a.tp.ngroups > 1) {   // transposed conv: column groups = sub-pixel phases
-#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { if (a.x3) return launch_t<32, WM_, NB_, false, true, false, true>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img); }
+        EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 transposed-conv kernel takes PACKED inputs");
+#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { if (mode == 2) return launch_t<32, WM_, NB_, false, true, false, 2>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img); }
         EVR_CASEG(4, 4) EVR_CASEG(2, 4) EVR_CASEG(1, 4) EVR_CASEG(4, 2) EVR_CASEG(2, 2) EVR_CASEG(1, 2)
         EVR_CASEG(4, 1) EVR_CASEG(2, 1) EVR_CASEG(1, 1)
 #undef EVR_CASEG
         set_error("conv_igemm: no grouped kernel for kc=%d wm=%d nb=%d", kc, wm, nb);
         return EVR_ERR_UNSUPPORTED;
     }
-    if (a.x3) {
-#define EVR_CASEX(WM_, NB_) if (wm == WM_ && nb == NB_) return launch_t<32, WM_, NB_, false, false, false, true>(a, d_args, stream, img);
+    if (mode != 0) {
+#define EVR_CASEX(WM_, NB_) if (wm == WM_ && nb == NB_) { if (mode == 2) return launch_t<32, WM_, NB_, false, false, false, 2>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, false, false, 1>(a, d_args, stream, img); }
         EVR_CASEX(4, 4) EVR_CASEX(2, 4) EVR_CASEX(1, 4) EVR_CASEX(4, 2) EVR_CASEX(2, 2) EVR_CASEX(1, 2)
         EVR_CASEX(4, 1) EVR_CASEX(2, 1) EVR_CASEX(1, 1)
 #undef EVR_CASEX
@@ -621,6 +661,9 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
         for (int co = 0; co < COUT; co += 4) {
             float4 v = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (a.out_packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(o, 0u, co, t); continue; }
+#endif
             *(float4*)(o + co) = v;
         }
     }
@@ -639,6 +682,20 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 4 consecutive channels (c4 % 4 == 0) of the pixel row at `row`, PLAIN or PACKED
+__device__ __forceinline__ float4 ld4_any(const float* row, int c4, int packed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (packed) { const f4 t = load4_packed(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
+#endif
+    return *(const float4*)(row + c4);
+}
+__device__ __forceinline__ void st4_any(float* row, int c4, float4 v, int packed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(row, 0u, c4, t); return; }
+#endif
+    *(float4*)(row + c4) = v;
+}
+
 __global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
     // 8 lanes per pixel, one float4 (4 channels) each per 32-channel group: a wave reads 8 pixels x 128 B
     // contiguous lines (the thread-per-pixel form over-fetched 3.7x, profiles/r01_pmc_fetch_size_nseq16.md)
@@ -654,8 +711,8 @@ __global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
         const int y = rem / a.W, x = rem - y * a.W;
         const int64_t pix = ((int64_t)n * a.hp + (y + a.iy0)) * a.wp + (x + a.ix0);
         for (int c4 = sub; c4 < a.c / 4; c4 += 8) {
-            float4 v = *(const float4*)(a.x + pix * a.c + c4 * 4);
-            if (a.skip) { const float4 u = *(const float4*)(a.skip + pix * a.c + c4 * 4); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            float4 v = ld4_any(a.x + pix * a.c, c4 * 4, a.x_packed);
+            if (a.skip) { const float4 u = ld4_any(a.skip + pix * a.c, c4 * 4, a.skip_packed); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
             const float* w = a.wgt + c4 * 4;
             acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
         }
@@ -769,7 +826,8 @@ int launch_dynamic_filter(const float* x, const float* coeff, const float* bases
 // ---------------------------------------------------------------------------------------------------
 // F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) of (x + skip), NHWC.
 __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ x, const float* __restrict__ skip,
-                                                              float* __restrict__ out, int n, int h, int w, int c) {
+                                                              float* __restrict__ out, int n, int h, int w, int c,
+                                                              int x_packed, int skip_packed) {
     const int c4n = c / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)n * 2 * h * 2 * w * c4n;
@@ -786,9 +844,9 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
     const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
     const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
     auto ld = [&](int yy, int xx) {
-        const int64_t o = (((int64_t)img * h + yy) * w + xx) * c + c4 * 4;
-        float4 v = *(const float4*)(x + o);
-        if (skip) { const float4 u = *(const float4*)(skip + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        const int64_t o = (((int64_t)img * h + yy) * w + xx) * c;
+        float4 v = ld4_any(x + o, c4 * 4, x_packed);
+        if (skip) { const float4 u = ld4_any(skip + o, c4 * 4, skip_packed); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
         return v;
     };
     const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
@@ -800,31 +858,35 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
     *(float4*)(out + ((((int64_t)img * 2 * h + oy) * 2 * w + ox) * c + c4 * 4)) = o4;
 }
 
-int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, hipStream_t stream) {
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, hipStream_t stream) {
     EVR_REQUIRE(c % 4 == 0, "upsample: channels %d not a multiple of 4", c);
+    EVR_REQUIRE(!(x_packed || skip_packed) || c % 8 == 0, "upsample: PACKED inputs need channels %d to be a multiple of 8", c);
     const int64_t total = (int64_t)n * 4 * h * w * (c / 4);
-    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c);
+    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c, x_packed, skip_packed);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
-__global__ __launch_bounds__(256) void add_kernel(const float4* __restrict__ x, const float4* __restrict__ y, float4* __restrict__ o, int64_t n4) {
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, int64_t n4, int packed) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 a = x[i], b = y[i];
-        o[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        // 4-channel run i: PACKED tensors are addressed per 8-channel unit (the row base is the unit, c4 = 0 or 4)
+        const int64_t base = packed ? (i >> 1) * 8 : i * 4;
+        const int c4 = packed ? (int)(i & 1) * 4 : 0;
+        const float4 a = ld4_any(x + base, c4, packed), b = ld4_any(y + base, c4, packed);
+        st4_any(o + base, c4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w), packed);
     }
 }
 
-int launch_add(const float* x, const float* y, float* out, int64_t n, hipStream_t stream) {
-    EVR_REQUIRE(n % 4 == 0, "add: element count not a multiple of 4");
+int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream) {
+    EVR_REQUIRE(n % 8 == 0, "add: element count not a multiple of 8");
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float4*)x, (const float4*)y, (float4*)out, n / 4);
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, out, n / 4, packed);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, int packed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)n * h * w * c;
     if (i >= total) return;
@@ -832,12 +894,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     const int y = (int)(p % h); p /= h;
     const int ch = (int)(p % c);
     const int img = (int)(p / c);
-    dst[i] = src[(((int64_t)img * h + y) * w + x) * c + ch];
+    const float* row = src + (((int64_t)img * h + y) * w + x) * c;
+    if (packed) {   // value = hi + lo, bf16 halves at 16-bit positions ch%8 of the unit's two 16-B pieces
+        const unsigned short* u16 = (const unsigned short*)(row + (ch & ~7));
+        dst[i] = __uint_as_float((unsigned)u16[ch & 7] << 16) + __uint_as_float((unsigned)u16[8 + (ch & 7)] << 16);
+    } else {
+        dst[i] = row[ch];
+    }
 }
 
-int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, hipStream_t stream) {
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream) {
+    EVR_REQUIRE(!packed || c % 8 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c);
     const int64_t total = (int64_t)n * h * w * c;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c, packed);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

@@ -36,6 +36,7 @@ struct HostTensor {
 struct DevTensor {   // NHWC activation / state
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
+    bool packed = false;   // PACKED activation format (conv.h): bf16 hi|lo halves per 8 channels
     int64_t numel() const { return (int64_t)n * h * w * c; }
 };
 
@@ -67,6 +68,7 @@ struct Step {
     const float* b[2] = {nullptr, nullptr};
     float* out = nullptr;
     int h = 0, w = 0, c = 0;
+    int a_packed = 0, b_packed = 0, out_packed = 0;   // activation formats of the operands
 };
 
 }  // namespace
@@ -81,6 +83,8 @@ struct evr_model {
     float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
+    bool packed = false;   // split-bf16 mode: tensors between matrix-core convolutions use the PACKED format
+    int pred_x_packed = 0, pred_skip_packed = 0;
     std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes)
     std::map<std::string, DevTensor> named[2];   // debug names -> tensor valid after a frame of parity p
     std::vector<Step> steps;
@@ -447,8 +451,9 @@ int build_firenet(evr_model* m) {
 
 // ------------------------------------------------------------------------------------------------
 // shape-dependent planning
-int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream) {
-    t->n = n; t->h = h; t->w = w; t->c = c;
+int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream, bool packed = false) {
+    t->n = n; t->h = h; t->w = w; t->c = c; t->packed = packed;
+    EVR_REQUIRE(!packed || c % 8 == 0, "PACKED activation tensor with %d channels", c);
     EVR_HIP(hipMalloc((void**)&t->p, (size_t)t->numel() * sizeof(float) + 256));
     m->allocs.push_back({t->p, (size_t)t->numel() * sizeof(float)});
     EVR_HIP(hipMemsetAsync(t->p, 0, (size_t)t->numel() * sizeof(float), stream));
@@ -461,6 +466,7 @@ struct ConvIO {
     const float* in0[2]; const float* in1[2]; float* out[2];
     const float* residual[2] = {nullptr, nullptr}; const float* post_add[2] = {nullptr, nullptr};
     float* state[2] = {nullptr, nullptr}; float* aux0[2] = {nullptr, nullptr};
+    bool in_packed = false, out_packed = false, res_packed = false, padd_packed = false, state_packed = false;
 };
 
 void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, int cout_total) {
@@ -478,6 +484,8 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
+        a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
+        a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;
         if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM || getenv("EVR_ABLATE_ALL")) ? atoi(e) : 0;
     }
     pick_conv_tile(c.args[0], c.kc, &c.wm, &c.nb);
@@ -494,14 +502,14 @@ void name2(evr_model* m, const std::string& name, const DevTensor& t0, const Dev
 // Fold the 1x1 prediction conv (+ skip-sum with `skip`, final activation, centre crop) into conv `ci`'s epilogue
 // when its GEMM has a single N tile; otherwise the standalone pred kernel runs.  reserved[0] bit 0 (debug) keeps
 // the conv's own NHWC output for evr_model_read_tensor.
-void try_fuse_pred(evr_model* m, int ci, const float* skip) {
+void try_fuse_pred(evr_model* m, int ci, const float* skip, bool skip_packed) {
     Conv& c = m->convs[ci];
     m->pred_fused_conv = -1;
     if (c.n_gemm != 32 * c.nb || c.n_gemm > 128) return;
     if (c.epi != EPI_BIAS_RELU && c.epi != EPI_RESIDUAL_RELU && c.epi != EPI_BIAS) return;
     for (int p = 0; p < 2; ++p) {
         ConvArgs& a = c.args[p];
-        a.post_add = skip;
+        a.post_add = skip; a.padd_packed = skip_packed ? 1 : 0;
         a.pred_w = m->d_pred_w; a.pred_b = m->pred_b; a.pred_sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
         a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
         a.prev_rec = m->prev_rec;
@@ -515,10 +523,11 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
     const bool lstm = d.recurrent_block == EVR_REC_CONVLSTM;
     int rc;
+    const bool P = m->packed;   // every tensor that feeds a matrix-core convolution is PACKED in split-bf16 mode
     DevTensor head;
-    if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream))) return rc;
+    if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);
-    m->head.out = head.p;
+    m->head.out = head.p; m->head.out_packed = P;
 
     // x[p]: current activation pointer per parity
     const float* x[2] = {head.p, head.p};
@@ -528,8 +537,9 @@ int plan_unet(evr_model* m, hipStream_t stream) {
         const int cout = base << (i + 1);
         const std::string en = "enc" + std::to_string(i);
         DevTensor cv;
-        if ((rc = alloc(m, &cv, n, h / 2, w / 2, cout, stream))) return rc;
+        if ((rc = alloc(m, &cv, n, h / 2, w / 2, cout, stream, P))) return rc;
         ConvIO io{};
+        io.in_packed = P; io.out_packed = P;
         io.in0[0] = x[0]; io.in0[1] = x[1]; io.in1[0] = io.in1[1] = nullptr; io.out[0] = io.out[1] = cv.p;
         const int ci = conv_index(m, en + ".conv");
         plan_conv(m, ci, n, h, w, io, cout);
@@ -538,10 +548,11 @@ int plan_unet(evr_model* m, hipStream_t stream) {
         h /= 2; w /= 2;
         if (lstm) {
             DevTensor hb[2], cb;
-            if ((rc = alloc(m, &hb[0], n, h, w, cout, stream))) return rc;
-            if ((rc = alloc(m, &hb[1], n, h, w, cout, stream))) return rc;
-            if ((rc = alloc(m, &cb, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &hb[0], n, h, w, cout, stream, P))) return rc;
+            if ((rc = alloc(m, &hb[1], n, h, w, cout, stream, P))) return rc;
+            if ((rc = alloc(m, &cb, n, h, w, cout, stream))) return rc;      // cell state: fp32, never a GEMM operand
             ConvIO r{};
+            r.in_packed = P; r.out_packed = P;
             for (int p = 0; p < 2; ++p) { r.in0[p] = cv.p; r.in1[p] = hb[p].p; r.out[p] = hb[1 - p].p; r.state[p] = cb.p; }
             const int ri = conv_index(m, en + ".rec");
             plan_conv(m, ri, n, h, w, r, cout);
@@ -552,10 +563,11 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             name2(m, "c" + std::to_string(i), cb, cb);
         } else {
             DevTensor hs, z, hr;
-            if ((rc = alloc(m, &hs, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &hs, n, h, w, cout, stream, P))) return rc;
             if ((rc = alloc(m, &z, n, h, w, cout, stream))) return rc;
-            if ((rc = alloc(m, &hr, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &hr, n, h, w, cout, stream, P))) return rc;
             ConvIO a{}, b{};
+            a.in_packed = b.in_packed = P; a.out_packed = b.out_packed = P; a.state_packed = b.state_packed = P;
             for (int p = 0; p < 2; ++p) {
                 a.in0[p] = cv.p; a.in1[p] = hs.p; a.out[p] = hr.p; a.state[p] = hs.p; a.aux0[p] = z.p;
                 b.in0[p] = cv.p; b.in1[p] = hr.p; b.out[p] = hs.p; b.state[p] = hs.p; b.aux0[p] = z.p;
@@ -575,9 +587,10 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     for (int i = 0; i < d.num_residual_blocks; ++i) {
         const std::string rn = "res" + std::to_string(i);
         DevTensor t, o;
-        if ((rc = alloc(m, &t, n, h, w, cm, stream))) return rc;
-        if ((rc = alloc(m, &o, n, h, w, cm, stream))) return rc;
+        if ((rc = alloc(m, &t, n, h, w, cm, stream, P))) return rc;
+        if ((rc = alloc(m, &o, n, h, w, cm, stream, P))) return rc;
         ConvIO a{}, b{};
+        a.in_packed = b.in_packed = P; a.out_packed = b.out_packed = P; b.res_packed = P;
         for (int p = 0; p < 2; ++p) {
             a.in0[p] = x[p]; a.out[p] = t.p;
             b.in0[p] = t.p; b.out[p] = o.p; b.residual[p] = x[p];
@@ -599,13 +612,13 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             DevTensor up, ctxp, ctxf, t1, coef, inter, prev;
             if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
             if ((rc = alloc(m, &ctxp, n, 1, (d.num_bins + 1) * (m->hp / 4), m->wp / 4, stream))) return rc;   // planar [n,B+1,hp/4,wp/4]
-            if ((rc = alloc(m, &ctxf, n, m->hp / 4, m->wp / 4, 32, stream))) return rc;
-            if ((rc = alloc(m, &t1, n, 2 * h, 2 * w, 64, stream))) return rc;
+            if ((rc = alloc(m, &ctxf, n, m->hp / 4, m->wp / 4, 32, stream, P))) return rc;
+            if ((rc = alloc(m, &t1, n, 2 * h, 2 * w, 64, stream, P))) return rc;
             if ((rc = alloc(m, &coef, n, 2 * h, 2 * w, 72, stream))) return rc;
             if ((rc = alloc(m, &inter, n, 2 * h, 2 * w, cin * 6, stream))) return rc;
             if ((rc = alloc(m, &prev, n, m->hp, m->wp, 1, stream))) return rc;
             m->prev_rec = prev.p;
-            { Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin;
+            { Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = P; s.b_packed = P;
               for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
               m->steps.push_back(s); }
             h *= 2; w *= 2;
@@ -616,15 +629,17 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             { Step s; s.kind = ST_CTX; m->steps.push_back(s); }
             memset(&m->ctxconv, 0, sizeof(m->ctxconv));
             m->ctxconv.vox = ctxp.p; m->ctxconv.n = n; m->ctxconv.B = d.num_bins + 1; m->ctxconv.H = h; m->ctxconv.W = w; m->ctxconv.hp = h; m->ctxconv.wp = w;
-            m->ctxconv.k = 3; m->ctxconv.cout = 32; m->ctxconv.wgt = m->d_ctx_w; m->ctxconv.bias = m->d_ctx_b; m->ctxconv.out = ctxf.p; m->ctxconv.relu = 0;
+            m->ctxconv.k = 3; m->ctxconv.cout = 32; m->ctxconv.wgt = m->d_ctx_w; m->ctxconv.bias = m->d_ctx_b; m->ctxconv.out = ctxf.p; m->ctxconv.relu = 0; m->ctxconv.out_packed = P;
             { Step s; s.kind = ST_CTXCONV; m->steps.push_back(s); }
             const int b1 = conv_index(m, dn + ".bn1"), b2 = conv_index(m, dn + ".bn2");
             ConvIO a1{}, a2{}, a3{};
+            a1.in_packed = P; a1.out_packed = P; a2.in_packed = P;     // coeff and the filtered tensor stay PLAIN (VALU kernels)
+            a3.out_packed = P;
             for (int p = 0; p < 2; ++p) { a1.in0[p] = ctxf.p; a1.out[p] = t1.p; a2.in0[p] = t1.p; a2.out[p] = coef.p; a3.in0[p] = inter.p; }
             plan_conv(m, b1, n, h, w, a1, 64); push_conv(m, b1);
             plan_conv(m, b2, n, h, w, a2, 72); push_conv(m, b2);
             { Step s; s.kind = ST_DYN; s.a[0] = s.a[1] = up.p; s.b[0] = s.b[1] = coef.p; s.out = inter.p; s.h = h; s.w = w; s.c = cin; m->steps.push_back(s); }
-            if ((rc = alloc(m, &o, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             for (int p = 0; p < 2; ++p) a3.out[p] = o.p;
             plan_conv(m, di, n, h, w, a3, cout); push_conv(m, di);
             m->flops += 2.0 * n * h * w * (double)cin * 25 * 6 + 2.0 * n * h * w * 72.0 * 25 + 2.0 * n * h * w * 9.0 * (d.num_bins + 1) * 32;
@@ -633,29 +648,31 @@ int plan_unet(evr_model* m, hipStream_t stream) {
         } else if (d.use_upsample_conv) {
             DevTensor up;
             if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
-            Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin;
+            Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = P; s.b_packed = P;
             for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
             m->steps.push_back(s);
             h *= 2; w *= 2;
-            if ((rc = alloc(m, &o, n, h, w, cout, stream))) return rc;
+            if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             ConvIO a{};
+            a.out_packed = P;      // the upsampled tensor is PLAIN: this conv splits it on the fly
             for (int p = 0; p < 2; ++p) { a.in0[p] = up.p; a.out[p] = o.p; }
             plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
         } else {
             const float* xin[2] = {x[0], x[1]};
             if (fuse && last_plain >= 0) {
                 // skip_sum (model_util.py:4-5) folded into the producer's epilogue
-                for (int p = 0; p < 2; ++p) m->convs[last_plain].args[p].post_add = sk[p].p;
+                for (int p = 0; p < 2; ++p) { m->convs[last_plain].args[p].post_add = sk[p].p; m->convs[last_plain].args[p].padd_packed = P; }
             } else {
                 DevTensor sum;
-                if ((rc = alloc(m, &sum, n, h, w, cin, stream))) return rc;
-                Step s; s.kind = ST_ADD; s.out = sum.p; s.h = h; s.w = w; s.c = cin;
+                if ((rc = alloc(m, &sum, n, h, w, cin, stream, P))) return rc;
+                Step s; s.kind = ST_ADD; s.out = sum.p; s.h = h; s.w = w; s.c = cin; s.a_packed = s.b_packed = s.out_packed = P;
                 for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
                 m->steps.push_back(s);
                 xin[0] = xin[1] = sum.p;
             }
-            if ((rc = alloc(m, &o, n, 2 * h, 2 * w, cout, stream))) return rc;
+            if ((rc = alloc(m, &o, n, 2 * h, 2 * w, cout, stream, P))) return rc;
             ConvIO a{};
+            a.in_packed = P; a.out_packed = P;
             for (int p = 0; p < 2; ++p) { a.in0[p] = xin[p]; a.out[p] = o.p; }
             plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
             h *= 2; w *= 2;
@@ -666,8 +683,8 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     }
     m->pred_x[0] = x[0]; m->pred_x[1] = x[1];
     m->pred_skip[0] = m->pred_skip[1] = head.p;
-    m->pred_c = base;
-    try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p);
+    m->pred_c = base; m->pred_x_packed = P; m->pred_skip_packed = P;
+    try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p, P);
     EVR_REQUIRE(!m->dynamic || m->pred_fused_conv >= 0, "dynamic decoder: the prediction layer could not be fused (prev_recs needs it)");
     return EVR_OK;
 }
@@ -713,7 +730,8 @@ int plan_firenet(evr_model* m, hipStream_t stream) {
     m->pred_x[0] = m->pred_x[1] = x;
     m->pred_skip[0] = m->pred_skip[1] = nullptr;
     m->pred_c = C;
-    try_fuse_pred(m, conv_index(m, "r2.conv2"), nullptr);
+    m->pred_x_packed = m->pred_skip_packed = 0;
+    try_fuse_pred(m, conv_index(m, "r2.conv2"), nullptr, false);
     return EVR_OK;
 }
 
@@ -758,6 +776,11 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     EVR_HIP(hipStreamSynchronize(stream));
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
+    m->packed = false;
+    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT) {
+        m->packed = true;
+        for (const auto& c : m->convs) if (!c.x3) m->packed = false;
+    }
     // CropParameters (utils/util.py:30-59)
     const int f = 1 << m->desc.pad_multiple_log2;
     m->hp = (H + f - 1) / f * f; m->wp = (W + f - 1) / f * f;
@@ -808,10 +831,10 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             }
             case ST_UPSAMPLE:
-                if ((rc = launch_upsample2x_sum(s.a[p], s.b[p], s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
+                if ((rc = launch_upsample2x_sum(s.a[p], s.b[p], s.out, m->n_seq, s.h, s.w, s.c, s.a_packed, s.b_packed, stream))) return rc;
                 break;
             case ST_ADD:
-                if ((rc = launch_add(s.a[p], s.b[p], s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream))) return rc;
+                if ((rc = launch_add(s.a[p], s.b[p], s.out, (int64_t)m->n_seq * s.h * s.w * s.c, s.out_packed, stream))) return rc;
                 break;
             case ST_CTX: {
                 CtxArgs ca = m->ctx;
@@ -832,6 +855,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
     pa.x = m->pred_x[p]; pa.skip = m->pred_skip[p]; pa.n = m->n_seq; pa.hp = m->hp; pa.wp = m->wp; pa.c = m->pred_c;
     pa.wgt = m->d_pred_w; pa.bias = m->pred_b; pa.sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
     pa.H = m->H; pa.W = m->W; pa.iy0 = m->iy0; pa.ix0 = m->ix0; pa.img = img;
+    pa.x_packed = m->pred_x_packed; pa.skip_packed = m->pred_skip_packed;
     if (m->pred_fused_conv < 0 && (rc = launch_pred(pa, stream))) return rc;
     m->frame++;
     return EVR_OK;
@@ -847,7 +871,7 @@ extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst,
     if (n_out) *n_out = t.numel();
     if (!dst) return EVR_OK;
     EVR_REQUIRE(dst_elems >= t.numel(), "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)t.numel());
-    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, (hipStream_t)stream);
+    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, t.packed ? 1 : 0, (hipStream_t)stream);
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }
