@@ -530,6 +530,7 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
         EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 ConvLSTM kernel takes PACKED inputs");
         if (mode == 2) {
+            if (wm == 8) return launch_t<32, 8, 4, true, false, true, 2>(a, d_args, stream, img);
             if (wm == 4) return launch_t<32, 4, 4, true, false, true, 2>(a, d_args, stream, img);
             if (wm == 2) return launch_t<32, 2, 4, true, false, false, 2>(a, d_args, stream, img);
             return launch_t<32, 1, 4, true, false, false, 2>(a, d_args, stream, img);
