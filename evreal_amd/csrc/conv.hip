@@ -103,7 +103,208 @@ constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descri
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Epilogue shared by the convolution kernels.
+//
+// Accumulator layout (the MFMAs run with the WEIGHT fragment as the A operand, so acc holds C^T): lane & 31 = pixel
+// (GEMM row m), register `reg` of 32-column block nb = channel n0 + nb*32 + (reg&3) + 8*(reg>>2) + 4*h, h = lane>>5.
+// A lane owns ONE pixel and, per block, four runs of 4 consecutive channels: every operand load and result store
+// is a 16-B access, the address arithmetic happens once per lane, and the fused prediction layer reduces over
+// channels in registers.  epi_setup (before the main loop) starts the accumulators at the bias and requests the
+// epilogue's operands (cell state / residual / fused skip) a whole main loop before they are needed.
+struct EpiCtx {
+    int m; bool mvalid, direct;
+    int e_img, e_my, e_mx;      // decoded GEMM row (only when the output pixel is not the row itself)
+    unsigned lstm_o;            // ConvLSTM: element offset of the lane's first hidden channel
+};
+// (row = element offset of the pixel row, c4 = first of the lane's 4 channels; n_valid and cout_total are multiples
+// of 4 -- checked at launch -- so a run is never ragged)
+__device__ __forceinline__ f4 ld4(const float* p, unsigned row, int c4, int packed) {
+    if (packed) return load4_packed(p, row, c4);
+    return *(const f4*)(p + row + (unsigned)c4);
+}
+__device__ __forceinline__ void st4(float* p, unsigned row, int c4, f4 v, int packed) {
+    if (packed) store4_packed(p, row, c4, v);
+    else *(f4*)(p + row + (unsigned)c4) = v;
+}
+// output pixel and first channel (inside its column group) of the lane in 32-column block nb
+template <bool GROUPED>
+__device__ __forceinline__ void out_addr(const ConvArgs& a, const EpiCtx& ec, int n0, int h, int nb, unsigned& opx, int& cgb, int& oy, int& ox) {
+    const int g = GROUPED ? (n0 + nb * 32) / a.tp.grp_cols : 0;
+    cgb = n0 + nb * 32 - g * a.tp.grp_cols + 4 * h;
+    oy = ec.e_my * a.os + a.tp.grp_ofy[g]; ox = ec.e_mx * a.os + a.tp.grp_ofx[g];
+    opx = ec.direct ? (unsigned)ec.m : (unsigned)((ec.e_img * a.hout + oy) * a.wout + ox);
+}
+
+template <int NB, bool LSTM, bool GROUPED>
+__device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int hw, int n0, int h, f32x16 (&acc)[NB],
+                                          f32x16 (&pre)[LSTM ? 1 : NB], EpiCtx& ec) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 b4 = *(const f4*)(a.bias + n0 + nb * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[nb][4 * q + j] = b4[j];
+        }
+    const int epi = a.epi;
+    ec.m = m; ec.mvalid = m < M;
+    ec.direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
+    ec.e_img = 0; ec.e_my = 0; ec.e_mx = 0;
+    if (!ec.direct || a.pred_w) {
+        const int mm = ec.mvalid ? m : 0;
+        ec.e_img = mm / hw;
+        const int rem = mm - ec.e_img * hw;
+        ec.e_my = rem / a.wm; ec.e_mx = rem - ec.e_my * a.wm;
+    }
+    const unsigned ct = (unsigned)a.cout_total;
+    const int nvalid = a.n_valid;
+    const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
+    const bool res = (epi == EPI_RESIDUAL_RELU);
+    constexpr int PN = LSTM ? 1 : NB;
+    const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
+    ec.lstm_o = (unsigned)(ec.mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
+    if (pre_ptr) {
+#pragma unroll
+        for (int nb = 0; nb < PN; ++nb) {
+            unsigned opx; int cgb, oy, ox;
+            out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 v = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LSTM) {
+                    if (ec.mvalid) v = *(const f4*)(pre_ptr + ec.lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
+                } else {
+                    const int c4 = cgb + 8 * q;
+                    if (ec.mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct, c4, res ? a.res_packed : a.padd_packed);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pre[nb][4 * q + j] = v[j];
+            }
+        }
+    }
+}
+
+template <int NB, bool LSTM, bool GROUPED, bool FAST>
+__device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, int n0, int h, f32x16 (&acc)[NB],
+                                           f32x16 (&pre)[LSTM ? 1 : NB], float* __restrict__ img_out) {
+    const int epi = a.epi;
+    const int m = ec.m;
+    const bool mvalid = ec.mvalid;
+    if constexpr (LSTM) {
+        static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
+        // N tile of 128 = 4 gates x 32 hidden channels (rows permuted at model creation); the conv is stride 1 on
+        // the state's own grid, so the output pixel is the GEMM row.  submodules.py:227-245
+        if (!mvalid) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f4 cn, hn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gi = sigmoid_t<FAST>(acc[0][4 * q + j]);
+                const float gf = sigmoid_t<FAST>(acc[1][4 * q + j]);
+                const float go = sigmoid_t<FAST>(acc[2][4 * q + j]);
+                const float gc = tanh_t<FAST>(acc[3][4 * q + j]);
+                cn[j] = __fadd_rn(__fmul_rn(gf, pre[0][4 * q + j]), __fmul_rn(gi, gc));   // submodules.py:242
+                hn[j] = go * tanh_t<FAST>(cn[j]);                                          // submodules.py:243
+            }
+            *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
+            if (a.out_packed) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
+            else *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
+        }
+        return;
+    } else {
+        const unsigned ct = (unsigned)a.cout_total;
+        const int nvalid = a.n_valid;
+        const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
+        const bool res = (epi == EPI_RESIDUAL_RELU);
+        const int grp_cols = a.tp.grp_cols;
+        const float* pw = a.pred_w;
+        float pred_part = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            unsigned opx; int cgb, oy, ox;
+            out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n4 = n0 + nb * 32 + 8 * q + 4 * h;   // GEMM column of the run
+                const int c4 = cgb + 8 * q;                    // channel inside the column group
+                f4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
+                if (!mvalid) continue;
+                if (gru) {
+                    // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
+                    const int C = a.hidden;
+                    if (epi == EPI_GRU_ZR) {
+                        if (n4 < C) {
+                            f4 z;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<false>(v[j]);
+                            *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
+                        } else if (n4 < 2 * C) {
+                            const f4 hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
+                            f4 hr;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<false>(v[j]);
+                            st4(a.out, opx * (unsigned)C, n4 - C, hr, a.out_packed);      // h * reset
+                        }
+                    } else if (n4 < C) {
+                        const unsigned o = opx * (unsigned)C + (unsigned)n4;
+                        const f4 z = *(const f4*)(a.aux0 + o), hp = ld4(a.state, opx * (unsigned)C, n4, a.state_packed);
+                        f4 hn;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
+                            hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<false>(v[j]), z[j]));
+                        st4(a.state, opx * (unsigned)C, n4, hn, a.state_packed);
+                    }
+                } else if (c4 < nvalid) {
+                    const unsigned orow = opx * ct;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = v[j];
+                        if (res) t += pre[nb][4 * q + j];
+                        if (epi == EPI_BIAS_TANH) t = tanh_t<false>(t);
+                        else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
+                        v[j] = t;
+                    }
+                    if (pw && a.out) st4(a.out, orow, c4, v, a.out_packed);        // debug copy of the layer's own output
+                    // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
+                    if (a.post_add) {
+                        if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
+                        else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += pre[nb][4 * q + j];
+                        }
+                    }
+                    if (!pw && a.out) st4(a.out, orow, c4, v, a.out_packed);
+                    if (pw) {
+                        const f4 w4 = *(const f4*)(pw + c4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
+                    }
+                }
+            }
+            // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
+            // pixel; the channels of a pixel live in the two lanes r and r+32
+            if (pw && ((n0 + nb * 32 + 32) % grp_cols) == 0) {
+                pred_part += __shfl_xor(pred_part, 32, 64);
+                if (h == 0 && mvalid) {
+                    const int y = oy - a.crop_y0, x = ox - a.crop_x0;
+                    float sres = pred_part + a.pred_b;
+                    if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
+                    if (a.prev_rec) a.prev_rec[opx] = sres;
+                    if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
+                        img_out[(unsigned)((ec.e_img * a.crop_h + y) * a.crop_w + x)] = sres;
+                }
+                pred_part = 0.f;
+            }
+        }
+    }
+}
 #endif
+
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
@@ -243,77 +444,12 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     const int r = lane & 31, h = lane >> 5;
     const int sw = swz<KC>(r);   // rows wmi*32+r and nb*32+r swizzle like r
 
-    // Accumulator layout (the MFMAs run with the WEIGHT fragment as the A operand, so acc holds C^T): lane & 31 =
-    // pixel (GEMM row m0 + wmi*32 + r), register `reg` of block nb = channel n0 + nb*32 + (reg&3) + 8*(reg>>2) + 4*h.
-    // A lane owns ONE pixel and, per 32-column block, four runs of 4 consecutive channels: every epilogue operand
-    // load and result store is a 16-B access, the address arithmetic happens once per lane, and the fused
-    // prediction layer reduces over channels in registers.  The accumulators start at the bias, and the epilogue's
-    // operands (cell state / residual / fused skip) are requested here, a whole main loop before they are needed.
+    // accumulators start at the bias; the epilogue's operands are requested now, a whole main loop early (epi_setup)
     f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f4 b4 = *(const f4*)(a.bias + n0 + nb * 32 + 8 * q + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[nb][4 * q + j] = b4[j];
-        }
-    const int epi = a.epi;
-    const int m = m0 + wmi * 32 + r;
-    const bool mvalid = m < M;
-    const bool direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
-    int e_img = 0, e_my = 0, e_mx = 0;
-    if (!direct || a.pred_w) {
-        const int mm = mvalid ? m : 0;
-        e_img = mm / hw;
-        const int rem = mm - e_img * hw;
-        e_my = rem / a.wm; e_mx = rem - e_my * a.wm;
-    }
-    const unsigned ct = (unsigned)a.cout_total;
-    const int nvalid = a.n_valid;
-    // (row = element offset of the pixel row, c4 = first of the lane's 4 channels; n_valid and cout_total are
-    // multiples of 4 -- checked at launch -- so a run is never ragged)
-    auto ld4 = [&](const float* p, unsigned row, int c4, int packed) -> f4 {
-        if (packed) return load4_packed(p, row, c4);
-        return *(const f4*)(p + row + (unsigned)c4);
-    };
-    auto st4 = [&](float* p, unsigned row, int c4, f4 v, int packed) {
-        if (packed) store4_packed(p, row, c4, v);
-        else *(f4*)(p + row + (unsigned)c4) = v;
-    };
-    // output pixel and first channel (inside its column group) of the lane in 32-column block nb
-    auto out_addr = [&](int nb, unsigned& opx, int& cgb, int& oy, int& ox) {
-        const int g = GROUPED ? (n0 + nb * 32) / grp_cols : 0;
-        cgb = n0 + nb * 32 - g * grp_cols + 4 * h;
-        oy = e_my * a.os + tp.grp_ofy[g]; ox = e_mx * a.os + tp.grp_ofx[g];
-        opx = direct ? (unsigned)m : (unsigned)((e_img * a.hout + oy) * a.wout + ox);
-    };
-    const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
-    const bool res = (epi == EPI_RESIDUAL_RELU);
     constexpr int PN = LSTM ? 1 : NB;
     f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
-    const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
-    const unsigned lstm_o = (unsigned)(mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
-    if (pre_ptr) {
-#pragma unroll
-        for (int nb = 0; nb < PN; ++nb) {
-            unsigned opx; int cgb, oy, ox;
-            out_addr(nb, opx, cgb, oy, ox);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f4 v = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (LSTM) {
-                    if (mvalid) v = *(const f4*)(pre_ptr + lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
-                } else {
-                    const int c4 = cgb + 8 * q;
-                    if (mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct, c4, res ? a.res_packed : a.padd_packed);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pre[nb][4 * q + j] = v[j];
-            }
-        }
-    }
-
+    EpiCtx ec;
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     issue(0);
     if constexpr (REGSTAGE) { store_staged(0); }
@@ -389,114 +525,217 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         if constexpr (REGSTAGE) { if (s + 1 < nsteps) store_staged(buf ^ 1); }   // waits for the loads, ds_write_b128
     }
 
-    // ------------------------------------------------------------------ epilogue (layout: see the accumulator setup)
     if (ablate & 4) return;   // timing ablation: no epilogue at all
-    if constexpr (LSTM) {
-        static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
-        // N tile of 128 = 4 gates x 32 hidden channels (rows permuted at model creation); the conv is stride 1 on
-        // the state's own grid, so the output pixel is the GEMM row.  submodules.py:227-245
-        if (!mvalid) return;
+    epi_finish<NB, LSTM, GROUPED, (X3 != 0)>(a, ec, n0, h, acc, pre, img_out);
+#endif   // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 3x3 stride-1 'same' convolution (ConvLSTM gates, residual blocks) in split-bf16 on PACKED activations with the
+// input rows RESIDENT in LDS -- the "band" kernel.
+//
+// The implicit-GEMM kernel above re-fetches the A tile for each of the 9 taps (L2 -> LDS traffic 32 flop/B: at the
+// split-bf16 MFMA rate the L2 cannot keep up).  Here a block owns TM = 256 consecutive pixels (flattened n*H*W) and
+// 128 output columns, and walks K as  chunk (32 channels) x dy x dx:
+//   A   for (chunk, dy) the TM+2 source pixels [m0 + dy*W - 1, m0 + dy*W + TM + 1) are ONE contiguous run of pixel
+//       rows -> loaded once (double-buffered "band"), and the three dx taps read it at row offsets 0,1,2.  Pixels
+//       that are not real neighbours (image borders, previous/next image of the batch) are zeroed in registers by a
+//       per-lane 9-bit validity mask (8 v_cndmask per 16-k slab, hidden under the MFMAs).
+//   B   the (tap, chunk) weight tile [128 x 32 k] streams through a 3-deep ring: it is requested two tap-steps ahead
+//       and awaited with COUNTED vmcnt (loads complete in order), so a tile has ~2 steps of MFMA time to arrive.
+//   L2 -> LDS bytes per (chunk, dy): 33 KB (A) + 48 KB (B) for 576 MFMAs = 2.4x less than the implicit GEMM.
+// Everything else (fragment layout, C^T accumulators, epilogues) is shared with the kernel above.
+template <int WM, bool LSTM>
+__global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int NB = 4, SP = 8;
+    constexpr int TM = 32 * WM;
+    constexpr int A_ROWS = TM + 8;                  // TM + 2 needed; whole 8-row DMA pieces
+    constexpr int A_PIECES = A_ROWS / 8;            // 1-KiB pieces per band
+    constexpr int A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
+    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // band pieces per wave
+    constexpr int NBW = (B_F4 / 64) / WM;           // weight-tile pieces per wave
+    static_assert((B_F4 / 64) % WM == 0, "weight tile pieces must divide over the waves");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 3 * B_F4];   // [band 0 | band 1 | ring 0..2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.win, H = a.hin;
+    const int hw = H * W;
+    const int M = a.n * hw;
+    const int ntiles = a.cout / (32 * NB);
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;
+    const int c0 = a.c0, c1 = a.c1;
+    const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 32;
+    const int ktot = 9 * nchunks * 32;
+    const unsigned in_pix = (unsigned)M;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
+
+    // per-lane constants of the DMA pieces this wave issues (piece j = wmi + jj*WM; lane -> row 8j + lane/8, slot lane%8)
+    int a_pix[NA_MAX]; unsigned a_q[NA_MAX];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f4 cn, hn;
+    for (int jj = 0; jj < NA_MAX; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        a_pix[jj] = m0 - 1 + row;
+        a_q[jj] = (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+    }
+    unsigned b_off[NBW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float gi = sigmoid_t<(X3 != 0)>(acc[0][4 * q + j]);
-                const float gf = sigmoid_t<(X3 != 0)>(acc[1][4 * q + j]);
-                const float go = sigmoid_t<(X3 != 0)>(acc[2][4 * q + j]);
-                const float gc = tanh_t<(X3 != 0)>(acc[3][4 * q + j]);
-                cn[j] = __fadd_rn(__fmul_rn(gf, pre[0][4 * q + j]), __fmul_rn(gi, gc));   // submodules.py:242
-                hn[j] = go * tanh_t<(X3 != 0)>(cn[j]);                                            // submodules.py:243
+    for (int jj = 0; jj < NBW; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 7) ^ swz<32>(row)) * 4));
+    }
+    // band (chunk cc, dy = dyi - 1) -> LDS band buffer `buf`
+    auto issue_band = [&](int cc, int dyi, int buf) {
+        int coff = cc * 32;
+        const bool second = coff >= c0;
+        const int csrc = second ? c1 : c0;
+        if (second) coff -= c0;
+        const int shift = (dyi - 1) * W;
+#pragma unroll
+        for (int jj = 0; jj < NA_MAX; ++jj) {
+            if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
+                const int pix = a_pix[jj] + shift;
+                unsigned voff = OOB_OFFSET;
+                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
             }
-            *(f4*)(a.state + lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
-            if (a.out_packed) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
-            else *(f4*)(a.out + lstm_o + 8 * q) = hn;
         }
-        return;
-    } else {
-        const float* pw = a.pred_w;
-        float pred_part = 0.f;
+    };
+    // weight tile (tap t, chunk cc) -> ring slot
+    auto issue_w = [&](int t, int cc, int slot) {
+        const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            unsigned opx; int cgb, oy, ox;
-            out_addr(nb, opx, cgb, oy, ox);
+        for (int jj = 0; jj < NBW; ++jj) {
+            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + kofs) * 4u, 0, 0, 0);
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<32>(r);
+    f32x16 acc[NB];
+    constexpr int PN = LSTM ? 1 : NB;
+    f32x16 pre[PN];
+    EpiCtx ec;
+    epi_setup<NB, LSTM, false>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
+
+    // validity of the 9 neighbours of this lane's pixel (bit t = tap (t/3 - 1, t%3 - 1))
+    unsigned vmask = 0;
+    {
+        const int m = m0 + wmi * 32 + r;
+        if (m < M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int py = rem / W, px = rem - py * W;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = n0 + nb * 32 + 8 * q + 4 * h;   // GEMM column of the run
-                const int c4 = cgb + 8 * q;                    // channel inside the column group
-                f4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
-                if (!mvalid) continue;
-                if (gru) {
-                    // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
-                    const int C = a.hidden;
-                    if (epi == EPI_GRU_ZR) {
-                        if (n4 < C) {
-                            f4 z;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<false>(v[j]);
-                            *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
-                        } else if (n4 < 2 * C) {
-                            const f4 hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
-                            f4 hr;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<false>(v[j]);
-                            st4(a.out, opx * (unsigned)C, n4 - C, hr, a.out_packed);      // h * reset
-                        }
-                    } else if (n4 < C) {
-                        const unsigned o = opx * (unsigned)C + (unsigned)n4;
-                        const f4 z = *(const f4*)(a.aux0 + o), hp = ld4(a.state, opx * (unsigned)C, n4, a.state_packed);
-                        f4 hn;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
-                            hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<false>(v[j]), z[j]));
-                        st4(a.state, opx * (unsigned)C, n4, hn, a.state_packed);
-                    }
-                } else if (c4 < nvalid) {
-                    const unsigned orow = opx * ct;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = v[j];
-                        if (res) t += pre[nb][4 * q + j];
-                        if (epi == EPI_BIAS_TANH) t = tanh_t<false>(t);
-                        else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
-                        v[j] = t;
-                    }
-                    if (pw && a.out) st4(a.out, orow, c4, v, a.out_packed);        // debug copy of the layer's own output
-                    // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
-                    if (a.post_add) {
-                        if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
-                        else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += pre[nb][4 * q + j];
-                        }
-                    }
-                    if (!pw && a.out) st4(a.out, orow, c4, v, a.out_packed);
-                    if (pw) {
-                        const f4 w4 = *(const f4*)(pw + c4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
-                    }
-                }
-            }
-            // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
-            // pixel; the channels of a pixel live in the two lanes r and r+32
-            if (pw && ((n0 + nb * 32 + 32) % grp_cols) == 0) {
-                pred_part += __shfl_xor(pred_part, 32, 64);
-                if (h == 0 && mvalid) {
-                    const int y = oy - a.crop_y0, x = ox - a.crop_x0;
-                    float sres = pred_part + a.pred_b;
-                    if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
-                    if (a.prev_rec) a.prev_rec[opx] = sres;
-                    if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
-                        img_out[(unsigned)((e_img * a.crop_h + y) * a.crop_w + x)] = sres;
-                }
-                pred_part = 0.f;
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vmask |= 1u << t;
             }
         }
     }
-#endif   // __HIP_DEVICE_COMPILE__
+
+    // prologue: band 0, weight tiles 0 and 1
+    issue_band(0, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    // (a bare s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
+    if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // ---- requests: weight tile of step s+2, and at the first tap of a band the NEXT band
+            {
+                const int t2 = (t + 2) % 9;
+                int c2 = c + (t + 2) / 9;
+                if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into a free slot
+                issue_w(t2, c2, (t + 2) % 3);
+            }
+            if (t % 3 == 0) {
+                const int d2 = (t / 3 + 1) % 3;
+                int c2 = c + (t / 3 + 1) / 3;
+                if (c2 >= nchunks) c2 = nchunks - 1;
+                issue_band(c2, d2, (pa ^ ((t / 3 + 1) & 1)));
+            }
+            // ---- 24 MFMAs on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
+            const int ab = pa ^ ((t / 3) & 1);
+            const int i = wmi * 32 + r + (t % 3);
+            const int swi = swz<32>(i);
+            const float4* la = &lds[ab * A_F4 + i * SP];
+            const float4* lb = &lds[2 * A_F4 + (t % 3) * B_F4 + r * SP];
+            const bool keep = (vmask >> t) & 1u;
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab) {
+                const int u = 2 * slab + h;
+                u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * u) ^ swi]);
+                u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * u + 1) ^ swi]);
+                if (t != 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ah[e] = keep ? ah[e] : 0u; al[e] = keep ? al[e] : 0u; }
+                }
+                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
+                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
+                }
+            }
+            // ---- the NEXT step's weight tile (and, before a band switch, the next band) must have landed; what was
+            // requested after them may stay in flight (loads complete in order): NBW, plus >= NA_MIN band pieces
+            // lgkmcnt(0): this wave's fragment reads of the step have left LDS before anyone overwrites the buffers
+            if (t % 3 == 2) {
+                if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                static_assert(NBW + NA_MIN == 6 || NBW + NA_MIN == 8, "update the counted waits");
+                if constexpr (NBW + NA_MIN == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+    }
+    epi_finish<NB, LSTM, false, true>(a, ec, n0, h, acc, pre, img_out);
+#endif
+}
+
+template <int WM, bool LSTM>
+static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int M = a.n * a.hm * a.wm;
+    const int mtiles = (M + 32 * WM - 1) / (32 * WM);
+    const int total = mtiles * (a.cout / 128);
+    hipLaunchKernelGGL((conv3x3_band_kernel<WM, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// the band kernel takes: split-bf16 on PACKED inputs, 3x3 taps in row-major order, stride 1 on the input's own grid,
+// N a multiple of 128, and enough pixels to fill the chip with 256-pixel tiles
+static bool band_eligible(const ConvArgs& a, int kc) {
+    static const bool off = getenv("EVR_NO_BAND") != nullptr;
+    if (off) return false;
+    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ngroups == 1 && a.tp.ntaps == 9 && a.stride == 1 && a.os == 1)) return false;
+    if (a.hm != a.hin || a.wm != a.win || a.hout != a.hm || a.wout != a.wm || a.cout % 128 != 0) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.tp.tap[t] != (((t / 3 - 1) & 0xffff) | ((t % 3 - 1) * 65536))) return false;
+    const int64_t M = (int64_t)a.n * a.hm * a.wm;
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 512;   // tests lower it
+    return ((M + 255) / 256) * (a.cout / 128) >= min_blocks;
 }
 
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
@@ -526,6 +765,10 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split-bf16 mode");
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
     const int mode = a.x3 ? (a.in_packed ? 2 : 1) : 0;
+    if (band_eligible(a, kc)) {
+        if (a.epi == EPI_LSTM) return launch_band<8, true>(a, d_args, stream, img);
+        return launch_band<8, false>(a, d_args, stream, img);
+    }
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
         EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 ConvLSTM kernel takes PACKED inputs");

@@ -1,0 +1,31 @@
+"""The model parity suite again under the kernel-selection switches the default run does not reach.
+
+* EVR_BAND_MIN=1  -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
+  takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here.
+* EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split-bf16 / PACKED.
+The switches are read when the library plans its launches, hence one fresh interpreter per mode.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra):
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_model.py', 'tests/test_gpu_color.py',
+           'tests/test_gpu_eval.py', '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_parity_with_band_kernel_on_small_shapes():
+    _run({'EVR_BAND_MIN': '1'})
+
+
+def test_parity_in_exact_fp32_mode():
+    _run({'EVR_FP32': '1'})
