@@ -165,19 +165,32 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
     constexpr int PN = LSTM ? 1 : NB;
     const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
     ec.lstm_o = (unsigned)(ec.mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
-    if (pre_ptr) {
+    if (pre_ptr && !(a.debug_ablate & 16)) {   // (bit 4 of EVR_ABLATE: timing without the operand loads)
+        // The loads are issued back to back and their RAW bits parked in `pre` (PACKED operands are decoded in
+        // epi_finish): anything that consumes a value here, or a per-lane branch around a load, makes hipcc wait
+        // for each load in turn -- 16+ serialised L2 round trips per lane.  Lanes past the end of M read row 0.
+        const int pk = LSTM ? 0 : (res ? a.res_packed : a.padd_packed);
 #pragma unroll
         for (int nb = 0; nb < PN; ++nb) {
             unsigned opx; int cgb, oy, ox;
             out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+            const unsigned row = ec.mvalid ? opx * ct : 0u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 v = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (LSTM) {
-                    if (ec.mvalid) v = *(const f4*)(pre_ptr + ec.lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
+                    v = *(const f4*)(pre_ptr + ec.lstm_o + 8 * q);    // c_prev of the lane's 16 hidden channels
                 } else {
                     const int c4 = cgb + 8 * q;
-                    if (ec.mvalid && c4 < nvalid) v = ld4(pre_ptr, opx * ct, c4, res ? a.res_packed : a.padd_packed);
+                    if (c4 - 4 * h < nvalid) {                        // wave-uniform (n_valid is a multiple of 8 or the run is whole)
+                        if (pk) {
+                            const float* qp = pre_ptr + pk_off(row, c4);
+                            const f4 hi_lo = {qp[0], qp[1], qp[4], qp[5]};   // 8-B hi piece, 8-B lo piece
+                            v = hi_lo;
+                        } else {
+                            v = *(const f4*)(pre_ptr + row + (unsigned)c4);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pre[nb][4 * q + j] = v[j];
@@ -241,13 +254,13 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                         if (n4 < C) {
                             f4 z;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<false>(v[j]);
+                            for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<FAST>(v[j]);
                             *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
                         } else if (n4 < 2 * C) {
                             const f4 hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
                             f4 hr;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<false>(v[j]);
+                            for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<FAST>(v[j]);
                             st4(a.out, opx * (unsigned)C, n4 - C, hr, a.out_packed);      // h * reset
                         }
                     } else if (n4 < C) {
@@ -256,16 +269,22 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                         f4 hn;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
-                            hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<false>(v[j]), z[j]));
+                            hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<FAST>(v[j]), z[j]));
                         st4(a.state, opx * (unsigned)C, n4, hn, a.state_packed);
                     }
                 } else if (c4 < nvalid) {
                     const unsigned orow = opx * ct;
+                    // the prefetched operand (raw bits from epi_setup), decoded if PACKED
+                    f4 pv = {pre[nb][4 * q], pre[nb][4 * q + 1], pre[nb][4 * q + 2], pre[nb][4 * q + 3]};
+                    if (res ? a.res_packed : a.padd_packed) {
+                        const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])}, plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])};
+                        pv = unpack4(phi, plo);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = v[j];
-                        if (res) t += pre[nb][4 * q + j];
-                        if (epi == EPI_BIAS_TANH) t = tanh_t<false>(t);
+                        if (res) t += pv[j];
+                        if (epi == EPI_BIAS_TANH) t = tanh_t<FAST>(t);
                         else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
                         v[j] = t;
                     }
@@ -273,10 +292,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
                     if (a.post_add) {
                         if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
-                        else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += pre[nb][4 * q + j];
-                        }
+                        else v += pv;
                     }
                     if (!pw && a.out) st4(a.out, orow, c4, v, a.out_packed);
                     if (pw) {
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 //       and awaited with COUNTED vmcnt (loads complete in order), so a tile has ~2 steps of MFMA time to arrive.
 //   L2 -> LDS bytes per (chunk, dy): 33 KB (A) + 48 KB (B) for 576 MFMAs = 2.4x less than the implicit GEMM.
 // Everything else (fragment layout, C^T accumulators, epilogues) is shared with the kernel above.
-template <int WM, bool LSTM>
+template <int WM, int RING, bool LSTM, bool GROUPED>
 __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -557,7 +573,9 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
     constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // band pieces per wave
     constexpr int NBW = (B_F4 / 64) / WM;           // weight-tile pieces per wave
     static_assert((B_F4 / 64) % WM == 0, "weight tile pieces must divide over the waves");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 3 * B_F4];   // [band 0 | band 1 | ring 0..2]
+    static_assert(RING == 2 || RING == 3, "weight ring: 2 slots (request 1 step ahead) or 3 (2 steps ahead)");
+    static_assert(!GROUPED || !LSTM, "a transposed conv has no ConvLSTM epilogue");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + RING * B_F4];   // [band 0 | band 1 | ring slots]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -596,7 +614,9 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 7) ^ swz<32>(row)) * 4));
     }
     // band (chunk cc, dy = dyi - 1) -> LDS band buffer `buf`
-    auto issue_band = [&](int cc, int dyi, int buf) {
+    // (live = false: the same number of requests, all out of range -> no memory traffic, zeros land in the buffer;
+    // keeps the counted vmcnt waits valid when a transposed-conv tile skips a band or a tap)
+    auto issue_band = [&](int cc, int dyi, int buf, bool live) {
         int coff = cc * 32;
         const bool second = coff >= c0;
         const int csrc = second ? c1 : c0;
@@ -607,7 +627,7 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
             if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
                 const int pix = a_pix[jj] + shift;
                 unsigned voff = OOB_OFFSET;
-                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
+                if (live && (unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
@@ -615,12 +635,12 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         }
     };
     // weight tile (tap t, chunk cc) -> ring slot
-    auto issue_w = [&](int t, int cc, int slot) {
+    auto issue_w = [&](int t, int cc, int slot, bool live) {
         const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
         for (int jj = 0; jj < NBW; ++jj) {
             lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + kofs) * 4u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, live ? (b_off[jj] + kofs) * 4u : OOB_OFFSET, 0, 0, 0);
         }
     };
 
@@ -630,7 +650,19 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
     constexpr int PN = LSTM ? 1 : NB;
     f32x16 pre[PN];
     EpiCtx ec;
-    epi_setup<NB, LSTM, false>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
+
+    // ConvTranspose2d(k5, s2) as a 3x3 conv whose N is phase-major (model.cpp prep_tconv): a (tap, phase) pair the
+    // transposed kernel does not connect has a zero weight block.  tap_use[t] = phases of THIS N tile that use tap t:
+    // unused blocks skip their MFMAs, unused taps their weight tile, unused dy their band (the steps still
+    // synchronise, so the ring bookkeeping stays that of the dense case)
+    int tile_groups = 0;
+    if constexpr (GROUPED) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0 + nb * 32) / a.tp.grp_cols);
+    }
+    auto tap_use = [&](int t) -> int { return GROUPED ? (a.tp.tap_groups[t] & tile_groups) : 1; };
+    auto band_use = [&](int dyi) -> bool { return !GROUPED || (tap_use(3 * dyi) | tap_use(3 * dyi + 1) | tap_use(3 * dyi + 2)) != 0; };
 
     // validity of the 9 neighbours of this lane's pixel (bit t = tap (t/3 - 1, t%3 - 1))
     unsigned vmask = 0;
@@ -647,12 +679,23 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         }
     }
 
-    // prologue: band 0, weight tiles 0 and 1
-    issue_band(0, 0, 0);
-    issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
-    // (a bare s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
-    if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // timing ablation (EVR_ABLATE, results are garbage when non-zero) only in -DEVR_BAND_ABLATE builds: the runtime
+    // tests cost this kernel 8 %
+#ifdef EVR_BAND_ABLATE
+    const int ablate = a.debug_ablate;
+#else
+    constexpr int ablate = 0;
+#endif
+    // prologue: band 0 and the first RING-1 weight tiles
+    // (bare s_barrier below: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
+    issue_band(0, 0, 0, band_use(0));
+    issue_w(0, 0, 0, tap_use(0) != 0);
+    if constexpr (RING == 3) {
+        issue_w(1, 0, 1, tap_use(1) != 0);
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     for (int c = 0; c < nchunks; ++c) {
         const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1
@@ -660,36 +703,43 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         for (int t = 0; t < 9; ++t) {
             // ---- requests: weight tile of step s+2, and at the first tap of a band the NEXT band
             {
-                const int t2 = (t + 2) % 9;
-                int c2 = c + (t + 2) / 9;
+                constexpr int D = RING - 1;
+                const int t2 = (t + D) % 9;
+                int c2 = c + (t + D) / 9;
                 if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into a free slot
-                issue_w(t2, c2, (t + 2) % 3);
+                // ring slot of step s = 9c + t: s % 3, or s & 1 = (c + t) & 1
+                const int slot2 = (RING == 3) ? (t + D) % 3 : (pa ^ ((t + D) & 1));
+                if (!(ablate & 2)) issue_w(t2, c2, slot2, tap_use(t2) != 0);
             }
-            if (t % 3 == 0) {
+            if (t % 3 == 0 && !(ablate & 2)) {
                 const int d2 = (t / 3 + 1) % 3;
                 int c2 = c + (t / 3 + 1) / 3;
                 if (c2 >= nchunks) c2 = nchunks - 1;
-                issue_band(c2, d2, (pa ^ ((t / 3 + 1) & 1)));
+                issue_band(c2, d2, (pa ^ ((t / 3 + 1) & 1)), band_use(d2));
             }
             // ---- 24 MFMAs on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
             const int ab = pa ^ ((t / 3) & 1);
             const int i = wmi * 32 + r + (t % 3);
             const int swi = swz<32>(i);
             const float4* la = &lds[ab * A_F4 + i * SP];
-            const float4* lb = &lds[2 * A_F4 + (t % 3) * B_F4 + r * SP];
+            const float4* lb = &lds[2 * A_F4 + ((RING == 3) ? (t % 3) : (pa ^ (t & 1))) * B_F4 + r * SP];
             const bool keep = (vmask >> t) & 1u;
+            const int use_t = tap_use(t);
+            if (!GROUPED || use_t) {       // block-uniform: a tap no phase of this tile uses is skipped whole
 #pragma unroll
             for (int slab = 0; slab < 2; ++slab) {
                 const int u = 2 * slab + h;
                 u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * u) ^ swi]);
                 u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * u + 1) ^ swi]);
-                if (t != 4) {
+                if (t != 4 && !(ablate & 8)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { ah[e] = keep ? ah[e] : 0u; al[e] = keep ? al[e] : 0u; }
                 }
                 const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
+                    // (a transposed-conv tap used by only SOME phases of the tile still runs all four blocks: the unused
+                    // ones multiply zero weights; per-block branches would cut the step into 3-MFMA fragments)
                     const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
                     const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
@@ -697,29 +747,39 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
                 }
             }
+            }
             // ---- the NEXT step's weight tile (and, before a band switch, the next band) must have landed; what was
             // requested after them may stay in flight (loads complete in order): NBW, plus >= NA_MIN band pieces
             // lgkmcnt(0): this wave's fragment reads of the step have left LDS before anyone overwrites the buffers
-            if (t % 3 == 2) {
-                if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (ablate & 1) continue;
+            if constexpr (RING == 3) {
+                if (t % 3 == 2) {
+                    if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    static_assert(RING != 3 || NBW + NA_MIN == 6 || NBW + NA_MIN == 8, "update the counted waits");
+                    if constexpr (NBW + NA_MIN == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
             } else {
-                static_assert(NBW + NA_MIN == 6 || NBW + NA_MIN == 8, "update the counted waits");
-                if constexpr (NBW + NA_MIN == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // 2-slot ring: the tile requested first in THIS step is needed next; only band pieces may stay in flight
+                static_assert(NA_MIN == 4, "update the counted waits");
+                if (t % 3 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
     }
-    epi_finish<NB, LSTM, false, true>(a, ec, n0, h, acc, pre, img_out);
+    if (ablate & 4) return;
+    epi_finish<NB, LSTM, GROUPED, true>(a, ec, n0, h, acc, pre, img_out);
 #endif
 }
 
-template <int WM, bool LSTM>
+template <int WM, int RING, bool LSTM, bool GROUPED = false>
 static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 32 * WM - 1) / (32 * WM);
     const int total = mtiles * (a.cout / 128);
-    hipLaunchKernelGGL((conv3x3_band_kernel<WM, LSTM>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -729,8 +789,10 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
 static bool band_eligible(const ConvArgs& a, int kc) {
     static const bool off = getenv("EVR_NO_BAND") != nullptr;
     if (off) return false;
-    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ngroups == 1 && a.tp.ntaps == 9 && a.stride == 1 && a.os == 1)) return false;
-    if (a.hm != a.hin || a.wm != a.win || a.hout != a.hm || a.wout != a.wm || a.cout % 128 != 0) return false;
+    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ntaps == 9 && a.stride == 1)) return false;
+    if (a.hm != a.hin || a.wm != a.win || a.cout % 128 != 0) return false;
+    if (a.tp.ngroups == 1) { if (a.os != 1 || a.hout != a.hm || a.wout != a.wm) return false; }
+    else if (a.os != 2 || a.hout != 2 * a.hm || a.wout != 2 * a.wm || a.epi == EPI_LSTM) return false;     // transposed conv
     for (int t = 0; t < 9; ++t)
         if (a.tp.tap[t] != (((t / 3 - 1) & 0xffff) | ((t % 3 - 1) * 65536))) return false;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
@@ -766,8 +828,22 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
     const int mode = a.x3 ? (a.in_packed ? 2 : 1) : 0;
     if (band_eligible(a, kc)) {
-        if (a.epi == EPI_LSTM) return launch_band<8, true>(a, d_args, stream, img);
-        return launch_band<8, false>(a, d_args, stream, img);
+        // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
+        // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
+        static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
+        if (a.epi == EPI_LSTM) {
+            if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
+            if (cfg == 82) return launch_band<8, 2, true>(a, d_args, stream, img);
+            return launch_band<8, 3, true>(a, d_args, stream, img);
+        }
+        if (a.tp.ngroups > 1) {
+            static const int gcfg = getenv("EVR_BAND_GCFG") ? atoi(getenv("EVR_BAND_GCFG")) : 42;
+            if (gcfg == 42) return launch_band<4, 2, false, true>(a, d_args, stream, img);
+            return launch_band<8, 3, false, true>(a, d_args, stream, img);
+        }
+        if (cfg == 42) return launch_band<4, 2, false>(a, d_args, stream, img);
+        if (cfg == 82) return launch_band<8, 2, false>(a, d_args, stream, img);
+        return launch_band<8, 3, false>(a, d_args, stream, img);
     }
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");

@@ -12,6 +12,7 @@
 // n_seq sequences and zeroed; every layer's launch plan (ConvArgs) is built for both ping-pong parities
 // and kept RESIDENT IN DEVICE MEMORY, so a frame is a fixed chain of kernel launches with 8-byte
 // kernargs, no host arithmetic and no synchronisation.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -230,6 +231,15 @@ int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout
             }
         }
     EVR_REQUIRE((int)taps.size() <= MAX_TAPS, "transposed conv: too many taps");
+    {   // canonical row-major tap order (dy, then dx): what the band kernel of conv.hip walks
+        std::vector<std::pair<int, int>> sorted = taps;
+        std::sort(sorted.begin(), sorted.end());
+        std::vector<int> remap(taps.size());
+        for (size_t i = 0; i < taps.size(); ++i)
+            remap[i] = (int)(std::find(sorted.begin(), sorted.end(), taps[i]) - sorted.begin());
+        for (Use& u : uses) u.t = remap[u.t];
+        taps = sorted;
+    }
     const int nt = (int)taps.size();
     c.tp.ntaps = nt;
     for (int t = 0; t < nt; ++t) c.tp.set_tap(t, taps[t].first, taps[t].second, 0);
