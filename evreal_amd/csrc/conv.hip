@@ -231,25 +231,24 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
         const unsigned ct = (unsigned)a.cout_total;
         const int nvalid = a.n_valid;
         const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
-        const bool res = (epi == EPI_RESIDUAL_RELU);
         const int grp_cols = a.tp.grp_cols;
-        const float* pw = a.pred_w;
-        float pred_part = 0.f;
+        // Each epilogue kind is its OWN loop nest under one block-uniform branch: with every kind inside a single
+        // (nb, q) body the unrolled epilogue was 11k instructions of which a launch executes a few hundred, spread
+        // over the whole range (instruction-cache misses on every iteration).
+        if (gru) {
+            // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
+            const int C = a.hidden;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            unsigned opx; int cgb, oy, ox;
-            out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+            for (int nb = 0; nb < NB; ++nb) {
+                unsigned opx; int cgb, oy, ox;
+                out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n4 = n0 + nb * 32 + 8 * q + 4 * h;   // GEMM column of the run
-                const int c4 = cgb + 8 * q;                    // channel inside the column group
-                f4 v;
+                for (int q = 0; q < 4; ++q) {
+                    const int n4 = n0 + nb * 32 + 8 * q + 4 * h;   // GEMM column of the run
+                    f4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
-                if (!mvalid) continue;
-                if (gru) {
-                    // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
-                    const int C = a.hidden;
+                    for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
+                    if (!mvalid) continue;
                     if (epi == EPI_GRU_ZR) {
                         if (n4 < C) {
                             f4 z;
@@ -272,30 +271,62 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                             hn[j] = __fadd_rn(__fmul_rn(hp[j], 1.0f - z[j]), __fmul_rn(tanh_t<FAST>(v[j]), z[j]));
                         st4(a.state, opx * (unsigned)C, n4, hn, a.state_packed);
                     }
-                } else if (c4 < nvalid) {
+                }
+            }
+            return;
+        }
+        if (epi == EPI_BIAS_TANH) {      // HyperE2VID bases_net (hyper_dynamic.py:41-48): no operands, no fusion
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                unsigned opx; int cgb, oy, ox;
+                out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c4 = cgb + 8 * q;
+                    f4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = tanh_t<FAST>(acc[nb][4 * q + j]);
+                    if (mvalid && c4 < nvalid) st4(a.out, opx * ct, c4, v, a.out_packed);
+                }
+            }
+            return;
+        }
+        // bias [+ residual] [+ ReLU] [+ fused skip] [+ fused prediction layer]
+        const bool res = (epi == EPI_RESIDUAL_RELU);
+        const bool relu = (epi != EPI_BIAS);
+        const bool has_pre = res || a.post_add != nullptr;
+        const int pre_pk = res ? a.res_packed : a.padd_packed;
+        const float* pw = a.pred_w;
+        float pred_part = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            unsigned opx; int cgb, oy, ox;
+            out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = cgb + 8 * q;                    // channel inside the column group
+                f4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
+                if (mvalid && c4 < nvalid) {
                     const unsigned orow = opx * ct;
                     // the prefetched operand (raw bits from epi_setup), decoded if PACKED
                     f4 pv = {pre[nb][4 * q], pre[nb][4 * q + 1], pre[nb][4 * q + 2], pre[nb][4 * q + 3]};
-                    if (res ? a.res_packed : a.padd_packed) {
+                    if (has_pre && pre_pk) {
                         const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])}, plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])};
                         pv = unpack4(phi, plo);
                     }
+                    if (res) v += pv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = v[j];
-                        if (res) t += pv[j];
-                        if (epi == EPI_BIAS_TANH) t = tanh_t<FAST>(t);
-                        else if (epi != EPI_BIAS) t = fmaxf(t, 0.f);
-                        v[j] = t;
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = relu ? fmaxf(v[j], 0.f) : v[j];
                     if (pw && a.out) st4(a.out, orow, c4, v, a.out_packed);        // debug copy of the layer's own output
                     // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
                     if (a.post_add) {
                         if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
                         else v += pv;
                     }
-                    if (!pw && a.out) st4(a.out, orow, c4, v, a.out_packed);
-                    if (pw) {
+                    if (!pw) st4(a.out, orow, c4, v, a.out_packed);
+                    else {
                         const f4 w4 = *(const f4*)(pw + c4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
@@ -320,7 +351,6 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
     }
 }
 #endif
-
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
