@@ -139,7 +139,7 @@ __device__ __forceinline__ void out_addr(const ConvArgs& a, const EpiCtx& ec, in
 
 template <int NB, bool LSTM, bool GROUPED>
 __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int hw, int n0, int h, f32x16 (&acc)[NB],
-                                          f32x16 (&pre)[LSTM ? 1 : NB], EpiCtx& ec) {
+                                          f32x16 (&pre)[LSTM ? 1 : NB], EpiCtx& ec, bool lane_ok = true) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -149,7 +149,7 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
             for (int j = 0; j < 4; ++j) acc[nb][4 * q + j] = b4[j];
         }
     const int epi = a.epi;
-    ec.m = m; ec.mvalid = m < M;
+    ec.m = m; ec.mvalid = lane_ok && m < M;
     ec.direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
     ec.e_img = 0; ec.e_my = 0; ec.e_mx = 0;
     if (!ec.direct || a.pred_w) {
@@ -298,6 +298,12 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
         const int pre_pk = res ? a.res_packed : a.padd_packed;
         const float* pw = a.pred_w;
         float pred_part = 0.f;
+        // prediction weights of the lane's channels, fetched ONCE up front when a column group is one 32-column block
+        // (E2VID's last decoder): a load inside the (nb, q) body is consumed at once, i.e. 16 serialised L2 round trips
+        const bool pw_shared = pw && grp_cols == 32;
+        f4 pwq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pwq[q] = pw_shared ? *(const f4*)(pw + 4 * h + 8 * q) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             unsigned opx; int cgb, oy, ox;
@@ -327,7 +333,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     }
                     if (!pw) st4(a.out, orow, c4, v, a.out_packed);
                     else {
-                        const f4 w4 = *(const f4*)(pw + c4);
+                        const f4 w4 = pw_shared ? pwq[q] : *(const f4*)(pw + c4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
                     }
@@ -591,13 +597,18 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 //       and awaited with COUNTED vmcnt (loads complete in order), so a tile has ~2 steps of MFMA time to arrive.
 //   L2 -> LDS bytes per (chunk, dy): 33 KB (A) + 48 KB (B) for 576 MFMAs = 2.4x less than the implicit GEMM.
 // Everything else (fragment layout, C^T accumulators, epilogues) is shared with the kernel above.
-template <int WM, int RING, bool LSTM, bool GROUPED>
+template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false>
 __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int NB = 4, SP = 8;
     constexpr int TM = 32 * WM;
-    constexpr int A_ROWS = TM + 8;                  // TM + 2 needed; whole 8-row DMA pieces
+    // OVL: tiles overlap by two pixels -- the band is exactly TM rows, the first and last lane of the tile only feed
+    // their neighbours' dx taps and store nothing.  126 useful pixels of 128, but the band buffers shrink to 16 KiB
+    // and 2 bands + a 3-slot ring are exactly 80 KiB: two blocks per CU WITH two-steps-ahead weight prefetch.
+    constexpr int SHIFT = OVL ? 1 : 0;
+    constexpr int TMV = OVL ? TM - 2 : TM;          // output pixels per tile
+    constexpr int A_ROWS = OVL ? TM : TM + 8;       // TM + 2 source pixels needed; whole 8-row DMA pieces
     constexpr int A_PIECES = A_ROWS / 8;            // 1-KiB pieces per band
     constexpr int A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
     constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // band pieces per wave
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
     const int ntile = lin % ntiles, mtile = lin / ntiles;
-    const int m0 = mtile * TM, n0 = ntile * 32 * NB;
+    const int m0 = mtile * TMV, n0 = ntile * 32 * NB;      // band row 0 = source pixel m0 - 1 (+ dy*W)
     const int c0 = a.c0, c1 = a.c1;
     const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 32;
     const int ktot = 9 * nchunks * 32;
@@ -680,7 +691,9 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
     constexpr int PN = LSTM ? 1 : NB;
     f32x16 pre[PN];
     EpiCtx ec;
-    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
+    const int idx = wmi * 32 + r;                          // lane's row of the tile; its output pixel is m0 + idx - SHIFT
+    const bool lane_ok = !OVL || (idx >= 1 && idx <= TM - 2);
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + idx - SHIFT, M, hw, n0, h, acc, pre, ec, lane_ok);
 
     // ConvTranspose2d(k5, s2) as a 3x3 conv whose N is phase-major (model.cpp prep_tconv): a (tap, phase) pair the
     // transposed kernel does not connect has a zero weight block.  tap_use[t] = phases of THIS N tile that use tap t:
@@ -697,8 +710,8 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
     // validity of the 9 neighbours of this lane's pixel (bit t = tap (t/3 - 1, t%3 - 1))
     unsigned vmask = 0;
     {
-        const int m = m0 + wmi * 32 + r;
-        if (m < M) {
+        const int m = m0 + idx - SHIFT;
+        if (lane_ok && m < M) {
             const int img = m / hw, rem = m - img * hw;
             const int py = rem / W, px = rem - py * W;
 #pragma unroll
@@ -749,7 +762,8 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
             }
             // ---- 24 MFMAs on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
             const int ab = pa ^ ((t / 3) & 1);
-            const int i = wmi * 32 + r + (t % 3);
+            int i = idx + (t % 3) - SHIFT;                  // band row of the lane's (dx) neighbour
+            if constexpr (OVL) i = i < 0 ? 0 : (i > TM - 1 ? TM - 1 : i);   // (only the two non-storing edge lanes clamp)
             const int swi = swz<32>(i);
             const float4* la = &lds[ab * A_F4 + i * SP];
             const float4* lb = &lds[2 * A_F4 + ((RING == 3) ? (t % 3) : (pa ^ (t & 1))) * B_F4 + r * SP];
@@ -804,12 +818,13 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
 #endif
 }
 
-template <int WM, int RING, bool LSTM, bool GROUPED = false>
+template <int WM, int RING, bool LSTM, bool GROUPED = false, bool OVL = false>
 static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
-    const int mtiles = (M + 32 * WM - 1) / (32 * WM);
+    const int tmv = OVL ? 32 * WM - 2 : 32 * WM;
+    const int mtiles = (M + tmv - 1) / tmv;
     const int total = mtiles * (a.cout / 128);
-    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -862,15 +877,18 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
         static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
         if (a.epi == EPI_LSTM) {
+            if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);
             if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
             if (cfg == 82) return launch_band<8, 2, true>(a, d_args, stream, img);
             return launch_band<8, 3, true>(a, d_args, stream, img);
         }
         if (a.tp.ngroups > 1) {
             static const int gcfg = getenv("EVR_BAND_GCFG") ? atoi(getenv("EVR_BAND_GCFG")) : 42;
+            if (gcfg == 43) return launch_band<4, 3, false, true, true>(a, d_args, stream, img);
             if (gcfg == 42) return launch_band<4, 2, false, true>(a, d_args, stream, img);
             return launch_band<8, 3, false, true>(a, d_args, stream, img);
         }
+        if (cfg == 43) return launch_band<4, 3, false, false, true>(a, d_args, stream, img);
         if (cfg == 42) return launch_band<4, 2, false>(a, d_args, stream, img);
         if (cfg == 82) return launch_band<8, 2, false>(a, d_args, stream, img);
         return launch_band<8, 3, false>(a, d_args, stream, img);
