@@ -215,10 +215,11 @@ def main():
                                   "count": int(tot[0, 3])}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": pmc,
-                         "kernel": "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=%s> (ConvLSTM gate convolutions)"
-                                   % ("true" if x3 else "false"),
+                         "kernel": ("conv3x3_band_kernel<WM=4,RING=2,LSTM=true> (ConvLSTM gate convolutions)" if x3 else
+                                    "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=0> (ConvLSTM gate convolutions)"),
                          "arithmetic": ("split bf16: x=hi+lo, w=hi+lo, acc += lo*hi + hi*lo + hi*hi on "
-                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate" if x3 else
+                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations stored PACKED (bf16 hi|lo "
+                                        "per 8 channels) by the producer" if x3 else
                                         "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"),
                          "mfma_issue_tflops": round(achieved * (3 if x3 else 1), 2),
                          "mfma_issue_frac": round(achieved * (3 if x3 else 1) / peak, 4),
