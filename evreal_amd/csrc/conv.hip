@@ -1,4 +1,5 @@
-// Convolutions of the recurrent networks as implicit GEMM on the fp32 matrix cores of gfx950.
+// Convolutions of the recurrent networks on the matrix cores of gfx950: an implicit GEMM (this header) and, for the
+// 3x3 stride-1 layers in split-bf16 mode, the band kernel further down (conv3x3_band_kernel).
 //
 // Reference ops (model/submodules.py): ConvLayer :8-35, TransposedConvLayer :38-66,
 // UpsampleConvLayer :69-97, ResidualBlock :152-184, ConvLSTM :187-245, ConvGRU :248-287; wired by
