@@ -40,6 +40,19 @@ struct ConvTaps {
     void set_tap(int i, int dy, int dx, int groups) { tap[i] = (dy & 0xffff) | (dx * 65536); tap_groups[i] = groups; }
 };
 
+// One step of the programmed band kernel = one (tap, 32-channel chunk) whose weights are not structurally zero,
+// packed into 32 bits (the kernel keeps the whole program in two VGPRs and picks entries with v_readlane: a scalar
+// load per step would share lgkmcnt with the fragment ds_reads and force full waits):
+//   bits 0-3   tap t = (dy+1)*3 + (dx+1)
+//   bit  4     first step of its band (chunk, dy)
+//   bit  5     a further band follows -> request it in this step (bits 16-27)
+//   bit  6     that request may stay in flight past this step (the band has more steps)
+//   bits 8-15  K chunk cc of the step: weight tile at float offset (t*nch2 + cc)*32 of a row
+//   bits 16-25 next band's source chunk: py | px << 1 | channel chunk << 2
+//   bits 26-27 next band's dy + 1
+// Entry 0 describes the first band (bits 16-27 only); entries 1..prog_steps are the steps.
+constexpr int BAND_PROG_MAX = 128;
+
 struct ConvArgs {
     const float* in0; const float* in1;
     int c0, c1;               // channels of in0/in1 (IN_SINGLE: c1 == 0)
@@ -68,6 +81,12 @@ struct ConvArgs {
     int in_packed;            //   in0/in1 are PACKED tensors (then the main loop feeds LDS slots straight to the MFMAs)
     int out_packed;           // write `out` PACKED (n_valid and cout_total multiples of 8)
     int res_packed, padd_packed, state_packed;   // format of residual / post_add / the ConvGRU hidden state
+    // space-to-depth form of a k5 stride-2 convolution for the programmed band kernel (conv.hip): the input seen as
+    // [n, hin/2, win/2, 4*c0] (2x2 pixel blocks -> channels, phase-major) makes it a 3x3 stride-1 convolution whose
+    // unused (tap, phase) chunks are simply absent from the step program
+    const float* wgt2;        // [cout][9][4*c0] weights of that form (same split-bf16 packing), or null
+    const unsigned* prog;     // device: BAND_PROG_MAX packed entries (see above)
+    int prog_steps;
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };

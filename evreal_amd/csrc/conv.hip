@@ -846,6 +846,189 @@ static bool band_eligible(const ConvArgs& a, int kc) {
     return ((M + 255) / 256) * (a.cout / 128) >= min_blocks;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Programmed band kernel: the k5 stride-2 encoder convolutions in split-bf16 on PACKED activations.
+//
+// Space-to-depth turns conv(k5, s2) into a 3x3 stride-1 convolution over 2x2 pixel blocks with 4*Cin channels
+// (phase-major): in(2y + ky - 2, 2x + kx - 2) = block(y + dy, x + dx), phase (py, px) with 2*dy + py = ky - 2.  Of the
+// 36 (tap, phase) pairs 25 exist; the others are not zero-padded but simply absent from the step PROGRAM the host
+// builds (model.cpp): a list of (tap, weight-tile offset) steps grouped into bands = (phase, channel chunk, dy).
+// The band of one (chunk, dy) is again ONE run of consecutive blocks -- here addressed as (row, x) with the
+// row pitch of two input rows -- loaded once and read by its dx taps at row offsets 0/1/2, exactly as in
+// conv3x3_band_kernel; the implicit GEMM re-fetches the A tile for all 25 taps (2.4x the L2 -> LDS bytes).
+// Weight tiles: 2-slot ring, requested one step ahead; counted vmcnt + bare s_barrier.
+template <int NB>
+__global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, SP = 8, TM = 32 * WM;
+    constexpr int A_ROWS = TM + 8, A_PIECES = A_ROWS / 8, A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
+    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;
+    constexpr int NBW = (B_F4 / 64) / WM;
+    static_assert(NA_MIN == 4 && (B_F4 / 64) % WM == 0, "tile bookkeeping");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4];   // [band 0 | band 1 | weight slot 0 | 1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wb = a.wm, Hb = a.hm;                 // block grid = output grid
+    const int hw = Hb * Wb;
+    const int M = a.n * hw;
+    const int nrows = a.n * Hb;
+    const int ntiles = a.cout / (32 * NB);
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;
+    const int C = a.c0;
+    const int nch2 = 4 * C / 32;                    // K chunks per tap in space-to-depth form
+    const int ktot = 9 * nch2 * 32;
+    const unsigned row_pitch = 2u * (unsigned)a.win * (unsigned)C, pix_pitch = 2u * (unsigned)C;   // floats
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, (unsigned)a.n * a.hin * a.win * (unsigned)C * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt2, (unsigned)a.cout * ktot * 4u);
+    // the whole step program in two VGPRs (lane l: entries l and 64 + l), read back with v_readlane
+    const unsigned prog_lo = a.prog[lane], prog_hi = a.prog[64 + lane];
+    auto entry = [&](int s) -> unsigned {
+        return s < 64 ? (unsigned)__builtin_amdgcn_readlane((int)prog_lo, s) : (unsigned)__builtin_amdgcn_readlane((int)prog_hi, s - 64);
+    };
+
+    // per-lane constants of the DMA pieces this wave issues: block (row, x) of band row 8j + lane/8 for dy = 0
+    int a_rho[NA_MAX]; unsigned a_xq[NA_MAX];
+#pragma unroll
+    for (int jj = 0; jj < NA_MAX; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        const int mb = m0 - 1 + row;
+        int rho = 0x20000000, x = 0;
+        if (mb >= 0 && mb < M) { rho = mb / Wb; x = mb - rho * Wb; }
+        a_rho[jj] = rho;
+        a_xq[jj] = (unsigned)x * pix_pitch + (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+    }
+    unsigned b_off[NBW];
+#pragma unroll
+    for (int jj = 0; jj < NBW; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 7) ^ swz<32>(row)) * 4));
+    }
+    auto issue_band = [&](int src, int dy, int buf) {
+        const int py = src & 1, px = (src >> 1) & 1, cc = src >> 2;
+        const unsigned choff = (unsigned)((py * a.win + px) * C + cc * 32);
+#pragma unroll
+        for (int jj = 0; jj < NA_MAX; ++jj) {
+            if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
+                const int rho = a_rho[jj] + dy;
+                unsigned voff = OOB_OFFSET;
+                if ((unsigned)rho < (unsigned)nrows) voff = ((unsigned)rho * row_pitch + a_xq[jj] + choff) * 4u;
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int kofs, int slot) {
+#pragma unroll
+        for (int jj = 0; jj < NBW; ++jj) {
+            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + (unsigned)kofs) * 4u, 0, 0, 0);
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<32>(r);
+    const int idx = wmi * 32 + r;
+    f32x16 acc[NB];
+    f32x16 pre[NB];
+    EpiCtx ec;
+    epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec);
+
+    unsigned vmask = 0;      // validity of the 9 neighbour blocks of this lane's output pixel
+    {
+        const int m = m0 + idx;
+        if (m < M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int py = rem / Wb, px = rem - py * Wb;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)Hb && (unsigned)xx < (unsigned)Wb) vmask |= 1u << t;
+            }
+        }
+    }
+
+    const int nsteps = a.prog_steps;
+    auto kofs_of = [&](unsigned e) -> int { return (int)(((e & 15u) * (unsigned)nch2 + ((e >> 8) & 255u)) * 32u); };
+    {
+        const unsigned e0 = entry(0), e1 = entry(1);
+        issue_band((int)((e0 >> 16) & 1023u), (int)((e0 >> 26) & 3u) - 1, 0);
+        issue_w(kofs_of(e1), 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int abuf = 0;
+    for (int s = 1; s <= nsteps; ++s) {
+        const unsigned e = entry(s);
+        const int slot = (s - 1) & 1;
+        if (s < nsteps) issue_w(kofs_of(entry(s + 1)), slot ^ 1);
+        if ((e & 16u) && s > 1) abuf ^= 1;
+        if (e & 32u) issue_band((int)((e >> 16) & 1023u), (int)((e >> 26) & 3u) - 1, abuf ^ 1);
+        const int t = (int)(e & 15u);
+        const int dxi = t - (t / 3) * 3;
+        const int i = idx + dxi;
+        const int swi = swz<32>(i);
+        const float4* la = &lds[abuf * A_F4 + i * SP];
+        const float4* lb = &lds[2 * A_F4 + slot * B_F4 + r * SP];
+        const bool keep = (vmask >> t) & 1u;
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            const int u = 2 * slab + h;
+            u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * u) ^ swi]);
+            u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * u + 1) ^ swi]);
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) { ah[e4] = keep ? ah[e4] : 0u; al[e4] = keep ? al[e4] : 0u; }
+            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
+                const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
+            }
+        }
+        // the next step's weight tile was requested first in this step: it must have landed; a band requested after it
+        // may stay in flight only if this band has further steps (bit 6)
+        if (e & 64u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    epi_finish<NB, false, false, true>(a, ec, n0, h, acc, pre, img_out);
+#endif
+}
+
+template <int NB>
+static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int M = a.n * a.hm * a.wm;
+    const int total = ((M + 127) / 128) * (a.cout / (32 * NB));
+    hipLaunchKernelGGL((conv_band_prog_kernel<NB>), dim3(total), dim3(256), 0, stream, d_args, img);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+static bool band_prog_eligible(const ConvArgs& a, int kc) {
+    static const bool off = getenv("EVR_NO_BAND") != nullptr;
+    if (off || !a.prog || !a.wgt2) return false;
+    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ngroups == 1 && a.tp.ntaps == 25 && a.stride == 2 && a.os == 1)) return false;
+    if (a.in_mode != IN_SINGLE || a.hin != 2 * a.hm || a.win != 2 * a.wm || a.hout != a.hm || a.wout != a.wm) return false;
+    if (a.cout % 64 != 0 || a.pred_w) return false;
+    // measured (64 sequences of 352x264): 64 columns (enc0: 595 -> 510 us) wins; at 128/256 columns the implicit GEMM
+    // is as fast or faster (470/440 vs 480/480 us) -- EVR_BAND_PROG_ALL=1 forces the band form for every width
+    static const bool all = getenv("EVR_BAND_PROG_ALL") != nullptr;
+    if (a.cout % 128 == 0 && !all) return false;
+    const int nb = (a.cout % 128 == 0) ? 4 : 2;
+    const int64_t M = (int64_t)a.n * a.hm * a.wm;
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 512;
+    return ((M + 127) / 128) * (a.cout / (32 * nb)) >= min_blocks;
+}
+
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
 static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
@@ -873,6 +1056,10 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split-bf16 mode");
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
     const int mode = a.x3 ? (a.in_packed ? 2 : 1) : 0;
+    if (band_prog_eligible(a, kc)) {
+        if (a.cout % 128 == 0) return launch_band_prog<4>(a, d_args, stream, img);
+        return launch_band_prog<2>(a, d_args, stream, img);
+    }
     if (band_eligible(a, kc)) {
         // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
         // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring

@@ -54,6 +54,9 @@ struct Conv {   // one prepared implicit-GEMM convolution
     double useful_taps = 0;   // (tap, group) pairs that carry weights (direct-conv FLOP accounting)
     std::vector<float> w, b;    // host, prepared layout
     float* d_w = nullptr; float* d_b = nullptr;
+    // k5 stride-2 convs: space-to-depth weights [n_gemm][9][4*cin] and the step program of the band kernel
+    std::vector<float> w2; std::vector<unsigned> prog; int prog_steps = 0;
+    float* d_w2 = nullptr; unsigned* d_prog = nullptr;
     // per shape
     ConvArgs args[2];
     int wm = 4, nb = 4;
@@ -260,10 +263,67 @@ int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout
     return EVR_OK;
 }
 
+// conv(k5, stride 2, pad 2) in space-to-depth form (conv.hip, conv_band_prog_kernel): a 3x3 stride-1 convolution
+// over 2x2 pixel blocks with 4*cin phase-major channels.  in(2y + ky - 2, .) = block row y + dy, phase py with
+// 2*dy + py = ky - 2; the (dy = +1, py = 1) and (dx = +1, px = 1) combinations do not exist and get no step.
+void prep_s2d(Conv& c) {
+    const int cin = c.cin0, nch = cin / 32, nch2 = 4 * nch, k2 = 9 * 4 * cin;
+    c.w2.assign((size_t)c.n_gemm * k2, 0.f);
+    for (int row = 0; row < c.n_gemm; ++row)
+        for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx)
+            for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+                const int ky = 2 * dy + py + 2, kx = 2 * dx + px + 2;
+                if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+                const float* src = &c.w[((size_t)row * 25 + ky * 5 + kx) * cin];
+                float* dst = &c.w2[((size_t)row * 9 + (dy + 1) * 3 + dx + 1) * 4 * cin + (py * 2 + px) * cin];
+                memcpy(dst, src, (size_t)cin * sizeof(float));
+            }
+    // the program: bands = (phase, channel chunk, dy) in K order, steps = their dx taps
+    struct Band { int src, dy; std::vector<int> taps; };
+    std::vector<Band> bands;
+    for (int cc = 0; cc < nch2; ++cc) {
+        const int phase = cc / nch, py = phase >> 1, px = phase & 1;
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (2 * dy + py > 2) continue;
+            Band b; b.src = py | (px << 1) | ((cc % nch) << 2); b.dy = dy;
+            for (int dx = -1; dx <= 1; ++dx) if (2 * dx + px <= 2) b.taps.push_back((dy + 1) * 3 + dx + 1);
+            bands.push_back(b);
+        }
+    }
+    // packed entries (conv.h): entry 0 = first band, then one per step
+    auto next_bits = [](const Band& b) { return ((unsigned)b.src << 16) | ((unsigned)(b.dy + 1) << 26); };
+    c.prog.assign(BAND_PROG_MAX, 0u);
+    size_t n = 0;
+    c.prog[n++] = next_bits(bands[0]);
+    for (size_t bi = 0; bi < bands.size(); ++bi) {
+        const Band& b = bands[bi];
+        const int phase = (b.src & 1) * 2 + ((b.src >> 1) & 1), cc = phase * nch + (b.src >> 2);
+        for (size_t ti = 0; ti < b.taps.size() && n < (size_t)BAND_PROG_MAX; ++ti) {
+            unsigned e = (unsigned)b.taps[ti] | ((unsigned)cc << 8);
+            if (ti == 0) {
+                e |= 16u;
+                if (bi + 1 < bands.size()) {
+                    e |= 32u | next_bits(bands[bi + 1]);
+                    if (b.taps.size() >= 2) e |= 64u;
+                }
+            }
+            c.prog[n++] = e;
+        }
+    }
+    c.prog_steps = (int)n - 1;
+}
+
 int finish_conv(evr_model* m, Conv& c) {
     int rc;
     // arithmetic mode: split-bf16 (3 MFMA products) for the 32-channel-chunk convolutions unless EVR_FP32=1
     c.x3 = (c.kc == 32) && use_split_bf16();
+    if (c.x3 && c.k == 5 && c.stride == 2 && !c.transposed && c.cin1 == 0 && c.n_gemm % 64 == 0 && 25 * (c.cin0 / 32) < BAND_PROG_MAX - 2) {
+        prep_s2d(c);
+        pack_x3(c.w2);
+        if ((rc = upload(c.w2, &c.d_w2))) return rc;
+        EVR_HIP(hipMalloc((void**)&c.d_prog, c.prog.size() * sizeof(unsigned)));
+        EVR_HIP(hipMemcpy(c.d_prog, c.prog.data(), c.prog.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
     if (c.x3) pack_x3(c.w);
     if ((rc = upload(c.w, &c.d_w))) return rc;
     if ((rc = upload(c.b, &c.d_b))) return rc;
@@ -494,6 +554,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
+        a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;
         if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM || getenv("EVR_ABLATE_ALL")) ? atoi(e) : 0;
