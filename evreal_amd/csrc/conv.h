@@ -135,7 +135,10 @@ struct HeadArgs {
     float* out;
     int relu;
     int out_packed;      // write `out` in the PACKED activation format
+    const void* wfrag;   // k5/32-channel split-bf16 form: weights in MFMA-fragment order (head_mfma_kernel), or null
 };
+// weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B)
+void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out);
 int launch_head_conv(const HeadArgs& a, hipStream_t stream);
 
 // Prediction layer: 1x1 conv C->1 on (x [+ skip]) + bias [+ sigmoid], centre crop -> planar img [n,1,H,W].

@@ -1225,7 +1225,152 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Head convolution on the matrix cores (split-bf16 mode, k = 5, 32 output channels): GEMM M = pixels, N = 32,
+// K = (bin, ky, kx).  The direct VALU kernel above spends 4000 FMAs per pixel (0.65 ms per 64 frames, the HBM
+// floor of its 761-MB output is 0.15 ms); here a pixel costs ~5 instructions per lane.
+//   K order  chosen so the two lane halves of an MFMA operand differ by ONE LDS row: the 5 kernel rows are padded
+//            to 6 (the 6th has zero weights) and half h takes ky = 2*kyp + h.  Element e < 75 = (b, kyp, kx),
+//            8 elements per 16-k slab, 10 slabs (K = 160 incl. padding): every gather address is the lane's base
+//            plus a compile-time offset -- no address arithmetic.
+//   A (weights)  live in 80 VGPRs for the whole kernel, loaded in fragment order (head_pack_wfrag).
+//   B (pixels)   the normalised, zero-padded input tile [B][8+5][32+4] sits in LDS as u32 = hi | lo << 16 (split once
+//            per element); a lane gathers 8 elements per slab and two v_perm build the hi and lo operands.
+//   C^T      lane = pixel, registers = channels -> bias, ReLU, PACKED 8-B stores.
+__global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 8, TW = 32, LR = TH + 5, LC = TW + 4, PLANE = LR * LC;
+    extern __shared__ unsigned htile[];   // [B][LR][LC]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+
+    // weight fragments (slab s, {hi, lo}: 16 B per lane) stay in registers across ALL tiles of this persistent block;
+    // the empty asm makes them opaque so hipcc neither sinks the loads into the tile loop nor re-loads them there
+    const u32x4_t* wf = (const u32x4_t*)a.wfrag;
+    u32x4_t w_hi[10], w_lo[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) { w_hi[s] = wf[(2 * s) * 64 + lane]; w_lo[s] = wf[(2 * s + 1) * 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < 10; ++s) { asm volatile("" : "+v"(w_hi[s])); asm volatile("" : "+v"(w_lo[s])); }
+    f4 bias4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias4[q] = *(const f4*)(a.bias + 8 * q + 4 * h);
+
+    const int tiles_x = (a.wp + TW - 1) / TW, tiles_y = (a.hp + TH - 1) / TH;
+    const int ntiles = a.n * tiles_y * tiles_x;
+    // input tile fetch, software-pipelined: the raw values of tile t+1 are requested (all loads back to back, no
+    // consumer in between) before tile t is computed and land in LDS after it
+    constexpr int NL = (5 * PLANE + 255) / 256;
+    float raw[NL];
+    auto fetch = [&](int tile) {
+        const int n = tile / (tiles_y * tiles_x), trem = tile - n * (tiles_y * tiles_x);
+        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+        const float* vin = a.vox + (int64_t)n * a.B * a.H * a.W;
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int i = tid + it * 256;
+            const int b = i / PLANE, rem = i - b * PLANE, rr = rem / LC, cc = rem - rr * LC;
+            const int y = ty0 + rr - 2 - a.pad_top, x = tx0 + cc - 2 - a.pad_left;
+            const bool ok = i < a.B * PLANE && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const float v = vin[ok ? ((int64_t)b * a.H + y) * a.W + x : 0];      // (no branch around the load)
+            raw[it] = ok ? v : __uint_as_float(0x7fc00001u);                  // NaN payload marks "outside"
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), trem = tile - n * (tiles_y * tiles_x);
+        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+        float mean, sd;
+        const bool norm = norm_params(a.stats, n, mean, sd);   // eval.py:398-410 fused into the load
+        __syncthreads();                                       // everyone is done with the previous tile
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int i = tid + it * 256;
+            float v = raw[it];
+            const bool outside = __float_as_uint(v) == 0x7fc00001u;
+            if (outside) v = 0.f; else if (norm) v = norm_apply(v, mean, sd);
+            const unsigned hi = cvt_pk_bf16(v, 0.f) & 0xffffu;
+            const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+            if (i < a.B * PLANE) htile[i] = hi | (lo << 16);
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll 1
+        for (int rp = 0; rp < 2; ++rp) {
+            const int ty = wv * 2 + rp;
+            const unsigned* base = htile + (ty + h) * LC + r;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j];
+#pragma unroll
+            for (int s = 0; s < 10; ++s) {
+                unsigned e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int el = 8 * s + j; if (el > 74) el = 74;                // padding slots: zero weights, any address
+                    const int b = el / 15, rem = el % 15, kyp = rem / 5, kx = rem % 5;
+                    e[j] = base[b * PLANE + (2 * kyp) * LC + kx];
+                }
+                u32x4_t ah, al;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ah[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
+                    al[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
+                }
+                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, w_hi[s]), b_lo = __builtin_bit_cast(bf16x8, w_lo[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc, 0, 0, 0);
+            }
+            const int oy = ty0 + ty, ox = tx0 + r;
+            if (oy < a.hp && ox < a.wp && !(a.relu & 2)) {
+                float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (a.relu & 1) ? fmaxf(acc[4 * q + j], 0.f) : acc[4 * q + j];
+                    if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
+                    else *(f4*)(o + 8 * q + 4 * h) = v;
+                }
+            }
+        }
+    }
+#endif
+}
+
+void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
+    // out[((2*s + part) * 64 + lane) * 4 + d]: lane = channel c + 32*h; dword d holds k-positions 2d, 2d+1 of the lane's 8
+    out.assign((size_t)20 * 64 * 4, 0u);
+    for (int s = 0; s < 10; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = lane & 31, h = lane >> 5;
+            for (int j = 0; j < 8; ++j) {
+                const int el = 8 * s + j;
+                float v = 0.f;
+                if (el < 15 * B && el <= 74) {
+                    const int b = el / 15, rem = el % 15, ky = 2 * (rem / 5) + h, kx = rem % 5;
+                    if (ky <= 4) v = w[((size_t)(b * 5 + ky) * 5 + kx) * 32 + c];
+                }
+                const unsigned short hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                out[((size_t)(2 * s) * 64 + lane) * 4 + j / 2] |= (unsigned)hi << (16 * (j & 1));
+                out[((size_t)(2 * s + 1) * 64 + lane) * 4 + j / 2] |= (unsigned)lo << (16 * (j & 1));
+            }
+        }
+}
+
 int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
+    if (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5) {
+        HeadArgs a2 = a; if (getenv("EVR_HEAD_NOSTORE")) a2.relu |= 2;   // timing experiment
+        const int ntiles = a.n * ((a.hp + 7) / 8) * ((a.wp + 31) / 32);
+        const dim3 g((unsigned)(ntiles < 768 ? ntiles : 768));        // persistent: 3 blocks per CU walk the tiles
+        hipLaunchKernelGGL(head_mfma_kernel, g, dim3(256), (size_t)a.B * 13 * 36 * sizeof(unsigned), stream, a2);
+        EVR_LAUNCH_CHECK();
+        return EVR_OK;
+    }
     const dim3 grid((a.wp + 15) / 16, (a.hp + 15) / 16, a.n);
     const int IS = 16 + a.k - 1;
     const size_t lds = (size_t)a.B * IS * IS * sizeof(float);

@@ -85,6 +85,7 @@ struct evr_model {
     std::vector<float> head_w, head_b, pred_w;
     float pred_b = 0.f;
     float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
+    unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split-bf16 mode, k5 x 5 bins x 32 channels)
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
     bool packed = false;   // split-bf16 mode: tensors between matrix-core convolutions use the PACKED format
@@ -117,6 +118,7 @@ struct evr_model {
 
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
                    if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
+                   if (d_head_wfrag) (void)hipFree(d_head_wfrag);
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
@@ -434,6 +436,12 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
     if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
+    if (use_split_bf16() && B == 5 && k == 5 && C == 32) {
+        std::vector<unsigned> wf;
+        head_pack_wfrag(m->head_w.data(), B, wf);
+        EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
+        EVR_HIP(hipMemcpy(m->d_head_wfrag, wf.data(), wf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
     if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
     if ((rc = upload(m->pred_w, &m->d_pred_w))) return rc;
     return EVR_OK;
@@ -599,6 +607,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;      // matrix-core head conv in split-bf16 mode
 
     // x[p]: current activation pointer per parity
     const float* x[2] = {head.p, head.p};

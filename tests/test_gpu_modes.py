@@ -1,6 +1,6 @@
 """The model parity suite again under the kernel-selection switches the default run does not reach.
 
-* EVR_BAND_MIN=1  -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
+* EVR_BAND_MIN=1 (+ EVR_BAND_PROG_ALL=1: the space-to-depth form for every encoder width) -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
   takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here.
 * EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split-bf16 / PACKED.
 The switches are read when the library plans its launches, hence one fresh interpreter per mode.
@@ -24,7 +24,7 @@ def _run(env_extra):
 
 
 def test_parity_with_band_kernel_on_small_shapes():
-    _run({'EVR_BAND_MIN': '1'})
+    _run({'EVR_BAND_MIN': '1', 'EVR_BAND_PROG_ALL': '1'})
 
 
 def test_parity_in_exact_fp32_mode():
