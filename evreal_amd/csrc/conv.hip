@@ -37,6 +37,7 @@
 //   grid        1-D, remapped so every XCD (private L2) walks a contiguous range of tiles with the N
 //               tile fastest: an A tile is reused from L2 across its N tiles and neighbouring M tiles
 #include "conv.h"
+#include "packed.h"
 #include <cstdlib>
 
 namespace evr {
@@ -66,39 +67,6 @@ __device__ __forceinline__ int swz(int row) {
 // just needs the kernel's signature to emit the launch stub, so the body is compiled for the device only.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-// two fp32 -> packed bf16 (RNE): `lo` lands in bits 15:0, `hi` in bits 31:16 (no builtin on gfx950)
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-typedef float f4 __attribute__((ext_vector_type(4)));
-// PACKED activation format (conv.h): 4 consecutive channels c4..c4+3 (c4 % 4 == 0) of a pixel row are an 8-B 'hi'
-// piece and, 16 B further, an 8-B 'lo' piece.  pk_off = float-element offset of the hi piece; lo = +4 floats.
-__device__ __forceinline__ unsigned pk_off(unsigned row_off, int c4) { return row_off + (unsigned)((c4 & ~7) + ((c4 & 4) >> 1)); }
-__device__ __forceinline__ f4 unpack4(uint2 hi, uint2 lo) {
-    f4 v;
-    v[0] = __uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16);
-    v[1] = __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u);
-    v[2] = __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16);
-    v[3] = __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u);
-    return v;
-}
-__device__ __forceinline__ void pack4(f4 v, uint2& hi, uint2& lo) {
-    hi.x = cvt_pk_bf16(v[0], v[1]); hi.y = cvt_pk_bf16(v[2], v[3]);
-    lo.x = cvt_pk_bf16(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
-    lo.y = cvt_pk_bf16(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
-}
-__device__ __forceinline__ f4 load4_packed(const float* p, unsigned row_off, int c4) {
-    const float* q = p + pk_off(row_off, c4);
-    return unpack4(*(const uint2*)q, *(const uint2*)(q + 4));
-}
-__device__ __forceinline__ void store4_packed(float* p, unsigned row_off, int c4, f4 v) {
-    uint2 hi, lo;
-    pack4(v, hi, lo);
-    float* q = p + pk_off(row_off, c4);
-    *(uint2*)q = hi; *(uint2*)(q + 4) = lo;
-}
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -843,7 +811,7 @@ static bool band_eligible(const ConvArgs& a, int kc) {
         if (a.tp.tap[t] != (((t / 3 - 1) & 0xffff) | ((t % 3 - 1) * 65536))) return false;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
     static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 512;   // tests lower it
-    return ((M + 255) / 256) * (a.cout / 128) >= min_blocks;
+    return ((M + 127) / 128) * (a.cout / 128) >= min_blocks;     // blocks of the default 128-pixel tiles
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1326,13 +1294,13 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc, 0, 0, 0);
             }
             const int oy = ty0 + ty, ox = tx0 + r;
-            if (oy < a.hp && ox < a.wp && !(a.relu & 2)) {
+            if (oy < a.hp && ox < a.wp) {
                 float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (a.relu & 1) ? fmaxf(acc[4 * q + j], 0.f) : acc[4 * q + j];
+                    for (int j = 0; j < 4; ++j) v[j] = a.relu ? fmaxf(acc[4 * q + j], 0.f) : acc[4 * q + j];
                     if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
                     else *(f4*)(o + 8 * q + 4 * h) = v;
                 }
@@ -1364,7 +1332,7 @@ void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
 
 int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
     if (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5) {
-        HeadArgs a2 = a; if (getenv("EVR_HEAD_NOSTORE")) a2.relu |= 2;   // timing experiment
+        const HeadArgs& a2 = a;
         const int ntiles = a.n * ((a.hp + 7) / 8) * ((a.wp + 31) / 32);
         const dim3 g((unsigned)(ntiles < 768 ? ntiles : 768));        // persistent: 3 blocks per CU walk the tiles
         hipLaunchKernelGGL(head_mfma_kernel, g, dim3(256), (size_t)a.B * 13 * 36 * sizeof(unsigned), stream, a2);
@@ -1383,20 +1351,6 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4 consecutive channels (c4 % 4 == 0) of the pixel row at `row`, PLAIN or PACKED
-__device__ __forceinline__ float4 ld4_any(const float* row, int c4, int packed) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (packed) { const f4 t = load4_packed(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
-#endif
-    return *(const float4*)(row + c4);
-}
-__device__ __forceinline__ void st4_any(float* row, int c4, float4 v, int packed) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(row, 0u, c4, t); return; }
-#endif
-    *(float4*)(row + c4) = v;
-}
-
 __global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
     // 8 lanes per pixel, one float4 (4 channels) each per 32-channel group: a wave reads 8 pixels x 128 B
     // contiguous lines (the thread-per-pixel form over-fetched 3.7x, profiles/r01_pmc_fetch_size_nseq16.md)

@@ -9,14 +9,16 @@
 // the oracle restatement (oracle/lpips.py) on any weights, and with pyiqa only once its weights are supplied.
 //
 // Layers: conv1 (3->64, k11 s4 p2) is a direct VALU kernel on the gray input (the three input channels are affine
-// in the same gray value); conv2..conv5 run on the fp32-MFMA implicit-GEMM kernel of conv.hip; 3x3/2 max pools and
-// the per-layer score are NHWC streaming kernels (one wave per pixel for the channel norms).
+// in the same gray value); conv2..conv5 run on the convolution kernels of conv.hip (split-bf16: conv2 on the implicit
+// GEMM, conv3..conv5 on the band kernel; pool1/feat1.. are then PACKED tensors, conv.h); 3x3/2 max pools and the
+// per-layer score are NHWC streaming kernels (one wave per pixel for the channel norms).
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "conv.h"
+#include "packed.h"
 
 using namespace evr;
 
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void lpips_conv1_kernel(const Conv1Args a) {
 
 // ---- max pool 3x3 stride 2 (no padding), NHWC --------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int n, int h, int w,
-                                                          int c, int ho, int wo) {
+                                                          int c, int ho, int wo, int in_packed, int out_packed) {
     const int c4n = c / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)n * ho * wo * c4n) return;
@@ -106,16 +108,24 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) {
-            const float4 v = *(const float4*)(in + (((int64_t)b * h + 2 * oy + ky) * w + 2 * ox + kx) * c + c4 * 4);
+            const float4 v = ld4_any(in + (((int64_t)b * h + 2 * oy + ky) * w + 2 * ox + kx) * c, c4 * 4, in_packed);
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
-    *(float4*)(out + (((int64_t)b * ho + oy) * wo + ox) * c + c4 * 4) = m;
+    st4_any(out + (((int64_t)b * ho + oy) * wo + ox) * c, c4 * 4, m, out_packed);
+}
+
+// one channel of a pixel row, PLAIN or PACKED (value = hi + lo; bf16 halves at 16-bit positions ch % 8 of the
+// 8-channel unit's two 16-B pieces)
+__device__ __forceinline__ float ld1_any(const float* row, int ch, int packed) {
+    if (!packed) return row[ch];
+    const unsigned short* u16 = (const unsigned short*)(row + (ch & ~7));
+    return __uint_as_float((unsigned)u16[ch & 7] << 16) + __uint_as_float((unsigned)u16[8 + (ch & 7)] << 16);
 }
 
 // ---- per-layer score: one wave per pixel -------------------------------------------------------------------------
 // feat: NHWC [2n, h, w, C] (first n = img, last n = ref); out partial[n][blocks] of sum over pixels
 __global__ __launch_bounds__(256) void lpips_score_kernel(const float* __restrict__ feat, const float* __restrict__ lin, int n, int hw,
-                                                           int C, double* __restrict__ partials, int blocks_per_img) {
+                                                           int C, double* __restrict__ partials, int blocks_per_img, int packed) {
     __shared__ double red[4];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* f0 = feat + (int64_t)b * hw * C;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) void lpips_score_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int ch = lane + 64 * k;
-            a[k] = (ch < C) ? f0[(int64_t)p * C + ch] : 0.f;
-            c[k] = (ch < C) ? f1[(int64_t)p * C + ch] : 0.f;
+            a[k] = (ch < C) ? ld1_any(f0 + (int64_t)p * C, ch, packed) : 0.f;
+            c[k] = (ch < C) ? ld1_any(f1 + (int64_t)p * C, ch, packed) : 0.f;
             s0 = fmaf(a[k], a[k], s0); s1 = fmaf(c[k], c[k], s1);
         }
 #pragma unroll
@@ -306,6 +316,7 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
         a.epi = EPI_BIAS_RELU; a.x3 = L.x3 ? 1 : 0;
+        a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED in split-bf16 mode
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));
@@ -329,21 +340,22 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     if (!attr) { EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
     EVR_LAUNCH_CHECK();
-    auto pool = [&](const float* in, float* o, int h, int w, int c, int ho, int wo) -> int {
+    const int pk = m->L[0].x3 ? 1 : 0;
+    auto pool = [&](const float* in, float* o, int h, int w, int c, int ho, int wo, int in_pk) -> int {
         const int64_t total = (int64_t)n2 * ho * wo * (c / 4);
-        hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, o, n2, h, w, c, ho, wo);
+        hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, o, n2, h, w, c, ho, wo, in_pk, pk);
         EVR_LAUNCH_CHECK();
         return EVR_OK;
     };
-    if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1]))) return rc;
+    if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1], 0))) return rc;
     if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
-    if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2]))) return rc;
+    if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2], pk))) return rc;
     for (int i = 1; i < 4; ++i)
         if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
     const int C[5] = {64, 192, 384, 256, 256};
     for (int l = 0; l < 5; ++l) {
         hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n), dim3(256), 0, stream, m->feat[l], m->d_lin[l], n,
-                           m->h[l] * m->w[l], C[l], m->partials + (size_t)l * n * SCORE_BLOCKS, SCORE_BLOCKS);
+                           m->h[l] * m->w[l], C[l], m->partials + (size_t)l * n * SCORE_BLOCKS, SCORE_BLOCKS, l > 0 ? pk : 0);
         EVR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(lpips_final_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, m->partials, out, SCORE_BLOCKS, 5, n, m->d_hw);
