@@ -566,7 +566,11 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 //       and awaited with COUNTED vmcnt (loads complete in order), so a tile has ~2 steps of MFMA time to arrive.
 //   L2 -> LDS bytes per (chunk, dy): 33 KB (A) + 48 KB (B) for 576 MFMAs = 2.4x less than the implicit GEMM.
 // Everything else (fragment layout, C^T accumulators, epilogues) is shared with the kernel above.
-template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false>
+// PHASES (transposed conv k5 s2 p2 only, checked on the host): how the tile's four 32-column blocks map to sub-pixel
+// phases, so the (tap, block) pairs the transposed kernel does not connect -- phase py = 1 never takes dy = -1, px = 1
+// never dx = -1 -- are dropped at COMPILE time (no branches in the step): 1 = block nb is phase (nb >> 1, nb & 1)
+// [32 columns per phase], 2 = blocks {0,1} px = 0, {2,3} px = 1 [64 columns per phase; py is per tile], 0 = unknown.
+template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false, int PHASES = 0>
 __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -751,8 +755,10 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
                 const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    // (a transposed-conv tap used by only SOME phases of the tile still runs all four blocks: the unused
-                    // ones multiply zero weights; per-block branches would cut the step into 3-MFMA fragments)
+                    // (without PHASES a tap used by only SOME phases of the tile still runs all four blocks: the unused
+                    // ones multiply zero weights; RUNTIME per-block branches cut the step into 3-MFMA fragments)
+                    if constexpr (PHASES == 1) { if ((t / 3 == 0 && (nb >> 1) == 1) || (t % 3 == 0 && (nb & 1) == 1)) continue; }
+                    if constexpr (PHASES == 2) { if (t % 3 == 0 && (nb >> 1) == 1) continue; }
                     const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
                     const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
@@ -787,13 +793,13 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
 #endif
 }
 
-template <int WM, int RING, bool LSTM, bool GROUPED = false, bool OVL = false>
+template <int WM, int RING, bool LSTM, bool GROUPED = false, bool OVL = false, int PHASES = 0>
 static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int tmv = OVL ? 32 * WM - 2 : 32 * WM;
     const int mtiles = (M + tmv - 1) / tmv;
     const int total = mtiles * (a.cout / 128);
-    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -1041,7 +1047,19 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         if (a.tp.ngroups > 1) {
             static const int gcfg = getenv("EVR_BAND_GCFG") ? atoi(getenv("EVR_BAND_GCFG")) : 42;
             if (gcfg == 43) return launch_band<4, 3, false, true, true>(a, d_args, stream, img);
-            if (gcfg == 42) return launch_band<4, 2, false, true>(a, d_args, stream, img);
+            if (gcfg == 42) {
+                // does the tap/phase connectivity follow the k5 s2 p2 rule the PHASES variants compile in?
+                bool rule = a.tp.ngroups == 4;
+                for (int t = 0; t < 9 && rule; ++t) {
+                    int want = 0;
+                    for (int g = 0; g < 4; ++g) if (!((g >> 1) == 1 && t / 3 == 0) && !((g & 1) == 1 && t % 3 == 0)) want |= 1 << g;
+                    rule = a.tp.tap_groups[t] == want;
+                }
+                for (int g = 0; g < 4 && rule; ++g) rule = a.tp.grp_ofy[g] == (g >> 1) && a.tp.grp_ofx[g] == (g & 1);
+                if (rule && a.tp.grp_cols == 32) return launch_band<4, 2, false, true, false, 1>(a, d_args, stream, img);
+                if (rule && a.tp.grp_cols == 64) return launch_band<4, 2, false, true, false, 2>(a, d_args, stream, img);
+                return launch_band<4, 2, false, true>(a, d_args, stream, img);
+            }
             return launch_band<8, 3, false, true>(a, d_args, stream, img);
         }
         if (cfg == 43) return launch_band<4, 3, false, false, true>(a, d_args, stream, img);
