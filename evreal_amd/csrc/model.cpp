@@ -989,3 +989,23 @@ extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names,
     *n_layers = k;
     return EVR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// the PACKED codec on the host (include/evreal_hip.h): the same pack_x3 the weights go through
+extern "C" int evr_split_bf16_pack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 8 == 0, "evr_split_bf16_pack: n = %lld must be a multiple of 8", (long long)n);
+    std::vector<float> w(src, src + n);
+    pack_x3(w);
+    memcpy(dst, w.data(), (size_t)n * sizeof(float));
+    return EVR_OK;
+}
+
+extern "C" int evr_split_bf16_unpack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 8 == 0, "evr_split_bf16_unpack: n = %lld must be a multiple of 8", (long long)n);
+    for (int64_t base = 0; base < n; base += 8) {
+        unsigned short hl[16];
+        memcpy(hl, src + base, 32);
+        for (int k = 0; k < 8; ++k) dst[base + k] = bf16_to_f32(hl[k]) + bf16_to_f32(hl[8 + k]);
+    }
+    return EVR_OK;
+}

@@ -208,6 +208,16 @@ int evr_bayer_split(const float* vox, int n, int B, int H, int W, float* out, ev
 int evr_color_merge(const float* planes, const float* gray, int n, int H, int W, unsigned char* bgr_out,
                     evr_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Split-bf16 storage format (host utilities, no GPU): the default arithmetic mode keeps every tensor that feeds
+ * the matrix cores -- weights and, inside the model, activations -- as bf16 hi|lo halves: each group of 8 values
+ * (32 B) holds the 8 'hi' halves (round-to-nearest-even of the value, 16 B) then the 8 'lo' halves (RNE of
+ * value - hi), value ~ hi + lo to 2^-17 relative.  evr_model_read_tensor decodes it; these two functions expose the
+ * codec itself so the format can be checked on a CPU-only host.  n must be a multiple of 8; src/dst host pointers.
+ */
+int evr_split_bf16_pack(const float* src, float* dst, int64_t n);
+int evr_split_bf16_unpack(const float* src, float* dst, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif
