@@ -3,8 +3,11 @@
     events window -> voxel grid (+stats) -> [normalize] -> pad -> network -> crop -> [robust norm]
                   -> clip -> MSE / SSIM / LPIPS
 
-All launches go to one HIP stream through the C ABI; nothing synchronises with the host inside a
-step (the reference forces a cuda.synchronize() and a D2H copy per frame, eval.py:227-233).
+All launches go through the C ABI; nothing synchronises with the host inside a step (the reference forces a
+cuda.synchronize() and a D2H copy per frame, eval.py:227-233).  With `overlap=True` the evaluation half of a frame
+(robust normalisation, MSE/SSIM, LPIPS) runs on a second HIP stream while the first already reconstructs the next
+frame: those kernels are small and leave most of the chip idle on their own; HIP events order the two streams and
+the image buffer is double-buffered.  Scores then land in `scores_out` asynchronously (synchronise before reading).
 """
 import torch
 
@@ -15,7 +18,7 @@ from .voxel import Voxelizer
 
 class HotPath:
     def __init__(self, model, num_bins, sensor_size, n_seq, event_tensor_normalization=True,
-                 post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0', lpips=None):
+                 post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0', lpips=None, overlap=False):
         _lib.require_gpu()
         self.model, self.B, (self.H, self.W), self.n = model, num_bins, sensor_size, n_seq
         self.norm_in, self.post = event_tensor_normalization, post_process_norm
@@ -28,6 +31,13 @@ class HotPath:
         self.grid = torch.empty((n_seq, num_bins, self.H, self.W), dtype=torch.float32, device=self.dev)
         self.stats = torch.zeros((n_seq, 3), dtype=torch.float64, device=self.dev)
         self.img = torch.empty((n_seq, 1, self.H, self.W), dtype=torch.float32, device=self.dev)
+        self.overlap = bool(overlap)
+        if self.overlap:
+            self.imgs = [self.img, torch.empty_like(self.img)]
+            self.side = torch.cuda.Stream(device=self.dev)
+            self.ev_model = [torch.cuda.Event(), torch.cuda.Event()]     # image k is complete (main stream)
+            self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
+            self.k = 0
         model.reset_states()
 
     def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
@@ -41,7 +51,31 @@ class HotPath:
         self.vox.voxelize(x, y, t, p, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
         return self._rest(ref, scores_out)
 
+    def _rest_overlapped(self, ref, scores_out):
+        k = self.k; self.k ^= 1
+        main = torch.cuda.current_stream(self.dev)
+        img = self.imgs[k]
+        if self.ev_done[k] is not None:
+            main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (two frames ago)
+        self.model(self.grid, stats=self.stats if self.norm_in else None, out=img)
+        self.ev_model[k].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_model[k])
+            im = img.view(self.n, self.H, self.W)
+            if self.post != 'none':
+                post_process_normalization(im, self.post)
+            if ref is not None and scores_out is not None:
+                scores = self.met(im, ref, mse=self.want_mse, ssim=self.want_ssim, clip=True)
+                scores_out[:, :2].copy_(scores)
+                if self.lpips is not None:
+                    lp = self.lpips(im, ref, clip=True)
+                    scores_out[:, 2].copy_(lp)
+            ev = torch.cuda.Event(); ev.record(self.side); self.ev_done[k] = ev
+        return img, scores_out
+
     def _rest(self, ref, scores_out):
+        if self.overlap:
+            return self._rest_overlapped(ref, scores_out)
         self.model(self.grid, stats=self.stats if self.norm_in else None, out=self.img)
         im = self.img.view(self.n, self.H, self.W)
         if self.post != 'none':
