@@ -27,6 +27,26 @@ PER_FILE = {
 }
 
 
+# kernels whose accumulators must stay in registers: hipcc has demoted them to scratch more than once while this code
+# grew (a branchy unrolled epilogue, dynamic indexing of a register array) -- silently, at a 10x slowdown.  These files
+# are compiled with -Rpass-analysis=kernel-resource-usage and the build fails if any of their kernels uses scratch.
+NO_SCRATCH = {'conv.hip', 'lpips.hip'}
+
+
+def _check_no_scratch(fname, remarks):
+    import re
+    bad, cur = [], None
+    for line in remarks.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+        if m and int(m.group(1)) > 0:
+            bad.append((cur, int(m.group(1))))
+    if bad:
+        raise RuntimeError(f'{fname}: kernels spill to scratch: ' + ', '.join(f'{k} ({b} B/lane)' for k, b in bad))
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
 
@@ -51,13 +71,30 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _newer(src, obj, headers):
             cmd = [HIPCC, '-c'] + COMMON + PER_FILE.get(f, []) + ['-x', 'hip', src, '-o', obj]
+            check = f in NO_SCRATCH
+            if check:
+                cmd.append('-Rpass-analysis=kernel-resource-usage')
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((f, subprocess.Popen(cmd)))
+            procs.append((f, subprocess.Popen(cmd, stderr=subprocess.PIPE if check else None, text=check or None), check, obj))
             rebuilt = True
-    for f, p in procs:
+    for f, p, check, obj in procs:
+        err = p.communicate()[1] if check else None
         if p.wait() != 0:
+            if err:     # the remarks carry source excerpts: show the diagnostics only
+                lines = err.splitlines()
+                keep = [i for i, l in enumerate(lines) if 'error:' in l or 'warning:' in l]
+                sys.stderr.write('\n'.join(l for i in keep for l in lines[i:i + 4]) + '\n')
             raise RuntimeError(f'hipcc failed on {f}')
+        if check:
+            other = [l for l in err.splitlines() if 'warning:' in l]
+            if other and verbose:
+                sys.stderr.write('\n'.join(other) + '\n')
+            try:
+                _check_no_scratch(f, err)
+            except RuntimeError:
+                os.remove(obj)
+                raise
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
         if verbose:
