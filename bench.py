@@ -10,6 +10,8 @@ A step = one frame for each of S independent synthetic sequences per GPU (sequen
 SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
 forward (split-bf16 x3 MFMA, fp32 accumulate; EVR_FP32=1: exact fp32 MFMA) -> crop -> robust percentile normalization -> clip -> MSE + SSIM + LPIPS against the
 reference frame (LPIPS = AlexNet v0.1 structure on synthetic weights: the real ones cannot be downloaded here).
+The evaluation half of a frame (robust norm, MSE/SSIM, LPIPS) runs on a second HIP stream and overlaps the
+reconstruction of the next frame (`--no-overlap`: one stream); all of a step's work is inside the timed region either way.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
