@@ -142,6 +142,37 @@ def test_e2vid_full_size_vs_oracle_with_padding_and_norm():
         np.testing.assert_allclose(img, want, rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')
 
 
+def test_e2vid_full_size_batch_takes_the_band_kernels():
+    """The same 346x260 comparison with 8 sequences advanced together: at this size the launches clear the band
+    kernels' fill threshold by themselves (no EVR_BAND_MIN), so the dispatch bench.py times is the one checked here --
+    ConvLSTM / residual / transposed layers on conv3x3_band_kernel, the 64-column encoder on the programmed band
+    kernel, the head on the matrix cores.  Every replica must match the oracle's single-sequence result."""
+    from evreal_amd import model, weights
+    from evreal_amd.voxel import Voxelizer
+    from oracle import model as omod, prepost as op, voxel as ov
+    from golden_inputs import gen_events
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=5)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
+                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    H, W, NS = 260, 346, 8
+    crop = op.CropParams(W, H, 3)
+    vz = Voxelizer()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    m.reset_states()
+    for f in range(2):
+        x, y, t, p = gen_events(700 + f, 15000, W, H)
+        st = torch.zeros((1, 3), dtype=torch.float64, device='cuda')
+        g = vz.voxelize(d(x), d(y), d(t), d(p), d(np.array([0, 15000], dtype=np.int64)), 5, (H, W), stats=st)
+        img = m(g.repeat(NS, 1, 1, 1), stats=st.repeat(NS, 1))['image'].cpu().numpy()
+        v = op.normalize_event_tensor(ov.events_to_voxel(x, y, t, p, 5, (H, W))[None])
+        want = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())
+        for s in range(NS):
+            np.testing.assert_allclose(img[s:s + 1], want, rtol=0, atol=IMG_ATOL, err_msg=f'frame {f} seq {s}')
+
+
 def test_recurrent_drift_30_frames():
     """fp32 MFMA vs torch-CPU over a long recurrence: the 1e-4 per-pixel gate must hold on every frame, and the
     ConvLSTM states must not drift (error compounds through h/c, SURVEY section 7 'hard parts')."""
