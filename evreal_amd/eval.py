@@ -8,7 +8,8 @@ Mirrors evaluate() / eval_method_with_config() / eval_method_on_sequence() (eval
 hot path on the GPU: a sequence's events live in HBM, windows are voxelised in chunks with one launch, the
 recurrent network steps frame by frame without host synchronisation, post-normalisation and MSE/SSIM run per
 chunk.  Under torch.distributed the sequences of every dataset are sharded across ranks and the per-dataset
-totals are folded with ONE all-reduce (evreal_amd.dist).
+totals are folded with ONE all-reduce (evreal_amd.dist).  `--batch-sequences S` (or eval-config key
+`batch_sequences`) additionally advances S sequences of a rank together, one batch slot each.
 """
 import argparse
 import glob
@@ -139,19 +140,9 @@ def get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, m
                               color=eval_config.get('color', False))
 
 
-def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
-    """eval.py:189-246."""
-    ds = open_sequence(sequence)
-    color = eval_config.get('color', False)
-    tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
-    model.reset_states()
-    infer_all = eval_config.get('eval_infer_all', False)
-    post_norm = method_config.get('post_process_norm', "none")
-    norm_in = method_config.get('event_tensor_normalization', False)
-    tb = ds.table()
-    H, W = ds.sensor_resolution
-
-    # which items run (eval.py:212-216); an item the reference's loader raises on stops the loop there
+def _plan_items(ds, tb, sequence, infer_all):
+    """Which items run (eval.py:212-216); an item the reference's loader raises on stops the loop there.
+    Returns (items, index of the raising item or None, the reference loop's last `idx`)."""
     todo, bad, idx = [], None, 0
     for idx in range(len(ds)):
         if not tb['valid'][idx]:
@@ -164,6 +155,22 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
             idx -= 1
             break
         todo.append(idx)
+    return todo, bad, idx
+
+
+def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
+    """eval.py:189-246."""
+    ds = open_sequence(sequence)
+    color = eval_config.get('color', False)
+    tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
+    model.reset_states()
+    infer_all = eval_config.get('eval_infer_all', False)
+    post_norm = method_config.get('post_process_norm', "none")
+    norm_in = method_config.get('event_tensor_normalization', False)
+    tb = ds.table()
+    H, W = ds.sensor_resolution
+
+    todo, bad, idx = _plan_items(ds, tb, sequence, infer_all)
 
     imgs = torch.empty((CHUNK, 1, H, W), dtype=torch.float32, device=ds.device)
     for c0 in range(0, len(todo), CHUNK):
@@ -202,6 +209,68 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
     return tracker.get_num_quan_evaluations(), tracker.get_mean_scores()
 
 
+def eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, sequences, metrics):
+    """The per-frame driver of eval.py:189-246 for SEVERAL sequences of one sensor size in lock-step: every sequence
+    owns one batch slot of the recurrent network (slots are independent: state, normalisation statistics, metrics), so
+    the results equal one eval_method_on_sequence call per sequence, but a frame of batch S costs far less than S
+    frames of batch 1 (the batch-1 step is bound by kernel latency, not by the chip).  Not for colour evaluation.
+    Returns [(num_evaluated, mean_scores)] in the order of `sequences`."""
+    S = len(sequences)
+    dss = [open_sequence(q) for q in sequences]
+    trackers = [get_eval_metrics_tracker(dataset_name, eval_config, method_name, q, metrics) for q in sequences]
+    infer_all = eval_config.get('eval_infer_all', False)
+    post_norm = method_config.get('post_process_norm', "none")
+    norm_in = method_config.get('event_tensor_normalization', False)
+    tbs = [ds.table() for ds in dss]
+    H, W = dss[0].sensor_resolution
+    assert all(tuple(ds.sensor_resolution) == (H, W) for ds in dss), "batched sequences must share the sensor size"
+    plans = [_plan_items(ds, tb, q, infer_all) for ds, tb, q in zip(dss, tbs, sequences)]
+    dev = dss[0].device
+    model.reset_states()
+    steps = max((len(p[0]) for p in plans), default=0)
+    imgs = torch.empty((CHUNK, S, 1, H, W), dtype=torch.float32, device=dev)
+    batch, stats = None, torch.zeros((S, 3), dtype=torch.float64, device=dev)
+    for c0 in range(0, steps, CHUNK):
+        items = [p[0][c0:c0 + CHUNK] for p in plans]
+        vox = [ds.voxel_batch(it) if it else None for ds, it in zip(dss, items)]
+        for i in range(max(len(it) for it in items)):
+            for j in range(S):
+                if i < len(items[j]):
+                    g = vox[j][0][i]
+                    if batch is None:
+                        batch = torch.zeros((S,) + tuple(g.shape), dtype=torch.float32, device=dev)
+                    batch[j].copy_(g); stats[j].copy_(vox[j][1][i])
+                elif batch is not None:
+                    batch[j].zero_(); stats[j].zero_()          # an exhausted slot idles on empty windows
+            model(batch, stats=stats if norm_in else None, out=imgs[i])
+        for j in range(S):
+            it = items[j]
+            if not it:
+                continue
+            tb, ds = tbs[j], dss[j]
+            im = imgs[:len(it), j, 0].contiguous()
+            post_process_normalization(im, post_norm)
+            if ds.has_images:
+                refs = ds.frames(tb['frame_index'][it])[:, 0]
+                ref_ts = [float(v) for v in tb['frame_timestamp'][it]]
+            else:
+                refs, ref_ts = None, None
+            trackers[j].update_batch(it, im, refs, [float(v) for v in tb['voxel_timestamp'][it]], ref_ts)
+            for i in it:
+                cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
+                trackers[j].save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
+    out = []
+    for j in range(S):
+        trackers[j].finalize(plans[j][2])
+        out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
+    for j in range(S):      # the reference raises inside the sequence loop: same message, after the files are written
+        bad = plans[j][1]
+        if bad is not None:
+            raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
+                int(tbs[j]['idx0'][bad]), int(tbs[j]['idx1'][bad]), dss[j].num_events))
+    return out
+
+
 def _dist():
     import torch.distributed as dist
     return dist if dist.is_available() and dist.is_initialized() else None
@@ -227,15 +296,37 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
         try:
             costs = [max(os.path.getsize(os.path.join(s['sequence_path'], 'events_ts.npy')), 1)
                      if os.path.isdir(s['sequence_path']) else 1 for s in seqs]
-            for i in assign_sequences(costs, world)[rank]:
-                sequence = seqs[i]
-                open_sequence(sequence)
-                print(f"[rank {rank}] Evaluating {method_name} with {eval_config['name']} config on "
-                      f"{sequence['name']} from {dataset['name']}")
-                num_evaluated, mean_scores = eval_method_on_sequence(dataset['name'], eval_config, method_name, model,
-                                                                     method_config, sequence, metrics)
-                for metric_name, score in mean_scores.items():
-                    dataset_metrics.update(metric_name, score, num_evaluated)
+            mine = [seqs[i] for i in assign_sequences(costs, world)[rank]]
+            S = int(eval_config.get('batch_sequences', os.environ.get('EVREAL_BATCH_SEQUENCES', '1')))
+            k = 0
+            while k < len(mine):
+                # a batch = up to S consecutive sequences of one sensor size; it ends at a sequence whose loader would
+                # raise (the reference stops the dataset there).  S = 1 (default) is the reference's own loop.
+                group = [mine[k]]
+                if S > 1 and not eval_config.get('color', False):
+                    res0 = tuple(open_sequence(mine[k]).sensor_resolution)
+                    ok0 = bool(open_sequence(mine[k]).table()['valid'].all())
+                    while ok0 and len(group) < S and k + len(group) < len(mine):
+                        nxt = mine[k + len(group)]
+                        if tuple(open_sequence(nxt).sensor_resolution) != res0:
+                            break
+                        group.append(nxt)
+                        if not bool(open_sequence(nxt).table()['valid'].all()):
+                            break
+                k += len(group)
+                for sequence in group:
+                    open_sequence(sequence)
+                    print(f"[rank {rank}] Evaluating {method_name} with {eval_config['name']} config on "
+                          f"{sequence['name']} from {dataset['name']}")
+                if len(group) == 1:
+                    results = [eval_method_on_sequence(dataset['name'], eval_config, method_name, model, method_config,
+                                                       group[0], metrics)]
+                else:
+                    results = eval_method_on_sequences(dataset['name'], eval_config, method_name, model, method_config,
+                                                       group, metrics)
+                for num_evaluated, mean_scores in results:
+                    for metric_name, score in mean_scores.items():
+                        dataset_metrics.update(metric_name, score, num_evaluated)
         except Exception as e:
             print(f"Exception while evaluating method {method_name} on {dataset['name']} dataset:")
             print(e); print(traceback.format_exc())
@@ -300,7 +391,12 @@ def main():
     parser.add_argument('-d', '--dataset', nargs='+', type=str, help='datasets')
     parser.add_argument('-qm', '--metrics', nargs='+', type=str,
                         help='quantitative evaluation metrics that will be used calculate scores')
+    parser.add_argument('--batch-sequences', type=int, default=None,
+                        help='(extension) advance this many sequences of a dataset together, one batch slot each; '
+                             'same outputs as the default 1')
     args = parser.parse_args()
+    if args.batch_sequences:
+        os.environ['EVREAL_BATCH_SEQUENCES'] = str(args.batch_sequences)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world > 1:
         import torch.distributed as dist

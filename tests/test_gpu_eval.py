@@ -33,8 +33,10 @@ def _parse(txt):
     return [(int(a), float(b)) for a, b in (l.split() for l in txt.strip().splitlines())] if txt.strip() else []
 
 
-def test_evaluate_matches_reference_run(tmp_path, monkeypatch):
+def _evaluate_and_compare(tmp_path, monkeypatch, batch_sequences):
     from evreal_amd import eval as ev
+    if batch_sequences > 1:
+        monkeypatch.setenv('EVREAL_BATCH_SEQUENCES', str(batch_sequences))
     g = load_json('eval_loop.json')
     w = load_npz('firenet_weights.npz')
     ckpt = {'state_dict': {k: torch.from_numpy(w[k]) for k in w.files},
@@ -61,6 +63,16 @@ def test_evaluate_matches_reference_run(tmp_path, monkeypatch):
         for metric, d in want[0][0].items():
             assert dm[metric]['count'] == d['count'], (cfg, metric)
             assert abs(dm[metric]['average'] - d['average']) < 1e-5, (cfg, metric, dm[metric]['average'], d['average'])
+
+
+def test_evaluate_matches_reference_run(tmp_path, monkeypatch):
+    _evaluate_and_compare(tmp_path, monkeypatch, 1)
+
+
+def test_evaluate_with_batched_sequences_matches_reference_run(tmp_path, monkeypatch):
+    """--batch-sequences: the sequences of a dataset advance together, one batch slot each; every output file and
+    score must still equal the reference's one-sequence-at-a-time run."""
+    _evaluate_and_compare(tmp_path, monkeypatch, 3)
 
 
 def test_dataset_reader_matches_reference_tables(tmp_path):
