@@ -57,6 +57,7 @@ class EvalMetricsTracker:
         if hist_eq != 'none':
             raise NotImplementedError(f"histeq={hist_eq!r}: every shipped eval config uses 'none' (SURVEY 8f-4)")
         self.save_images, self.output_dir, self.hist_eq = save_images, output_dir, hist_eq
+        self._pending = []
         self.save_processed_images = False
         self.start, self.end, self.tol_ms = quan_eval_start_time, quan_eval_end_time, quan_eval_ts_tol_ms
         self.has_reference_frames, self.color = has_reference_frames, color
@@ -145,18 +146,40 @@ class EvalMetricsTracker:
         quantitative metric in colour mode (utils/eval_metrics.py:272)."""
         self._append(join(self.output_dir, 'timestamps.txt'), zip(indices, img_ts), '{} {:.15f}\n')
         if self.save_images:
-            from PIL import Image
             rgb = bgr_u8.flip(-1).cpu().numpy()          # cv2.imwrite stores BGR arrays as RGB files
             for i, a in zip(indices, rgb):
-                Image.fromarray(a, mode='RGB').save(join(self.output_dir, 'frame_{:010d}.png'.format(i)))
+                self._submit_png(join(self.output_dir, 'frame_{:010d}.png'.format(i)), a, 'RGB')
+
+    # PNG encoding (zlib, ~3 ms per 346x260 frame on one core) leaves the frame loop: a small shared thread pool
+    # encodes and writes while the GPU goes on (PIL releases the GIL in the compressor); same PIL calls, so the
+    # files are byte-identical to the synchronous ones.  finalize() waits for this tracker's files (SURVEY 8f-2).
+    _pool = None
+
+    @classmethod
+    def _writer_pool(cls):
+        if cls._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            cls._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('EVREAL_PNG_THREADS', '4')))
+        return cls._pool
+
+    def _submit_png(self, path, array, mode):
+        def job():
+            from PIL import Image
+            Image.fromarray(array, mode=mode).save(path)
+        if os.environ.get('EVREAL_PNG_THREADS', '') == '0':
+            job()                                            # synchronous, as the reference
+        else:
+            self._pending.append(self._writer_pool().submit(job))
 
     def _save_pngs(self, indices, imgs):
-        from PIL import Image
         u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()
         for i, a in zip(indices, u8):
-            Image.fromarray(a, mode='L').save(join(self.output_dir, 'frame_{:010d}.png'.format(i)))
+            self._submit_png(join(self.output_dir, 'frame_{:010d}.png'.format(i)), a, 'L')
 
     def finalize(self, idx):
+        for f in self._pending:
+            f.result()                                       # re-raises a writer's exception here
+        self._pending = []
         for m in self.metrics:
             m.updated = 0
 

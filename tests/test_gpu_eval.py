@@ -75,6 +75,46 @@ def test_evaluate_with_batched_sequences_matches_reference_run(tmp_path, monkeyp
     _evaluate_and_compare(tmp_path, monkeypatch, 3)
 
 
+def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
+    """save_images: frames are encoded and written by background threads (joined in finalize); the files must be the
+    ones the synchronous path writes -- one per timestamp line, round(clip(img)*255) 8-bit gray (eval_utils.py:80-84)."""
+    import hashlib
+    from PIL import Image
+    from evreal_amd import eval as ev
+    g = load_json('eval_loop.json')
+    w = load_npz('firenet_weights.npz')
+    ckpt = {'state_dict': {k: torch.from_numpy(w[k]) for k in w.files},
+            'config': {'model': {'num_bins': 5, 'skip_type': 'no_skip', 'recurrent_block_type': 'convgru',
+                                 'base_num_channels': 16, 'num_residual_blocks': 2,
+                                 'recurrent_blocks': {'resblock': [0]}, 'kernel_size': 3,
+                                 'final_activation': 'none', 'norm': 'none', 'BN_momentum': 0.01}}}
+    digests = {}
+    for mode in ('async', 'sync'):
+        root = tmp_path / mode
+        os.makedirs(root)
+        model_path = str(root / 'firenet.pth')
+        torch.save(ckpt, model_path)
+        g2 = json.loads(json.dumps(g))
+        g2['cfgs'] = {'k3k': dict(g['cfgs']['k3k'], save_images=True)}
+        _write_tree(str(root), g2, model_path)
+        monkeypatch.chdir(root)
+        if mode == 'sync':
+            monkeypatch.setenv('EVREAL_PNG_THREADS', '0')
+        ev.evaluate(['FireNet'], ['k3k'], ['SYN'], ['mse'])
+        out = {}
+        for d, _, files in os.walk(root / 'outputs'):
+            if 'timestamps.txt' in files:
+                idxs = [int(l.split()[0]) for l in open(os.path.join(d, 'timestamps.txt')).read().strip().splitlines()]
+                pngs = sorted(f for f in files if f.endswith('.png'))
+                assert pngs == ['frame_{:010d}.png'.format(i) for i in idxs] and pngs, d
+                im = Image.open(os.path.join(d, pngs[-1])); im.load()
+                assert im.mode == 'L' and im.size == (64, 48)
+                for f in pngs:
+                    out[os.path.relpath(os.path.join(d, f), root)] = hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()
+        digests[mode] = out
+    assert digests['async'] and digests['async'] == digests['sync']
+
+
 def test_dataset_reader_matches_reference_tables(tmp_path):
     """MemMapDataset mirror: per-item indices/timestamps/dt and voxel grids vs the reference (dataset_windows.json)."""
     from evreal_amd import synth
