@@ -17,6 +17,34 @@ from .config import read_json
 from .voxel import Voxelizer
 
 
+class SequenceFiles:
+    """The memory-mapped columns of one sequence directory (tools/bag_to_npy.py:53-94 writes them):
+    events_ts [N] f64, events_xy [N,2] int, events_p [N] {0,1}; optionally images [F,H,W,1] u8, images_ts [F,1] f64,
+    image_event_indices [F,1] int64 (all three or none)."""
+    EVENT_FILES = ('events_ts.npy', 'events_xy.npy', 'events_p.npy')
+    FRAME_FILES = ('images.npy', 'images_ts.npy', 'image_event_indices.npy')
+
+    def __init__(self, path, t, xy, p, images=None, frame_stamps=None, image_event_indices=None):
+        self.path, self.t, self.xy, self.p = path, t, xy, p
+        self.images, self.frame_stamps, self.image_event_indices = images, frame_stamps, image_event_indices
+        if not (len(t) == len(xy) == len(p)):
+            raise AssertionError("Number of events, timestamps and coordinates do not match")
+        self.num_events = len(t)
+
+    @classmethod
+    def open(cls, path):
+        at = lambda n: os.path.join(path, n)
+        t, xy, p = (np.load(at(n), mmap_mode='r').squeeze() for n in cls.EVENT_FILES)
+        if all(os.path.exists(at(n)) for n in cls.FRAME_FILES):
+            return cls(path, t, xy, p, np.load(at('images.npy'), mmap_mode='r'), np.load(at('images_ts.npy')),
+                       np.load(at('image_event_indices.npy')))
+        return cls(path, t, xy, p)
+
+    def metadata_resolution(self):
+        meta = os.path.join(self.path, 'metadata.json')
+        return read_json(meta)["sensor_resolution"] if os.path.exists(meta) else None
+
+
 class MemMapDataset:
     def __init__(self, data_path, sensor_resolution=None, num_bins=5, voxel_method=None, max_length=None,
                  keep_ratio=1, device=None):
@@ -39,43 +67,40 @@ class MemMapDataset:
         self._dev = None
         self._table = None
 
-    # -- loading (dataset.py:230-281) -----------------------------------------------------------
+    # -- loading: what dataset.py:230-281 establishes, organised around the GPU path ------------
     def load_data(self, data_path):
-        assert os.path.isdir(data_path), f'{data_path} is not a valid data_path'
-        p = lambda n: os.path.join(data_path, n)
-        data = {}
-        if os.path.exists(p('images_ts.npy')) and os.path.exists(p('images.npy')) and \
-                os.path.exists(p('image_event_indices.npy')):
-            data["frame_stamps"] = np.load(p('images_ts.npy'))
-            data["images"] = np.load(p('images.npy'), mmap_mode='r')
-            data["image_event_indices"] = np.load(p('image_event_indices.npy'))
-            self.has_images = True
-        else:
-            self.has_images = False
-        data["t"] = np.load(p('events_ts.npy'), mmap_mode='r').squeeze()
-        data["xy"] = np.load(p('events_xy.npy'), mmap_mode='r').squeeze()
-        data["p"] = np.load(p('events_p.npy'), mmap_mode='r').squeeze()
-        assert len(data['p']) == len(data['xy']) == len(data['t']), \
-            "Number of events, timestamps and coordinates do not match"
-        self.t0, self.tk = data['t'][0], data['t'][-1]
-        self.num_events = len(data['p'])
-        self.frame_ts = []
-        if self.has_images:
-            self.num_frames = len(data['images'])
-            self.frame_ts = [ts.item() for ts in data["frame_stamps"]]
-        else:
-            self.num_frames = 0
-        assert len(self.frame_ts) == self.num_frames, "Number of frames and timestamps do not match"
-        self.filehandle = data
-        if self.sensor_resolution is None:
-            meta = p("metadata.json")
-            if os.path.exists(meta):
-                self.sensor_resolution = read_json(meta)["sensor_resolution"]
-            elif self.has_images and self.num_frames > 0:
-                self.sensor_resolution = data["images"][0].shape[:2]
-            else:
-                self.sensor_resolution = [np.max(data["xy"][:, 1]) + 1, np.max(data["xy"][:, 0]) + 1]
-        self.sensor_resolution = [int(self.sensor_resolution[0]), int(self.sensor_resolution[1])]
+        """Open one sequence directory.  The event columns stay memory-mapped until `upload()` moves them
+        into HBM; only the small per-frame tables are read eagerly.  Establishes the same facts as the reference's
+        loader: `t0`/`tk`, `num_events`, `num_frames`, `frame_ts`, `has_images`, and the sensor resolution taken from,
+        in this order, the constructor argument, metadata.json, the first reference frame, or max(xy)+1."""
+        if not os.path.isdir(data_path):
+            raise AssertionError(f'{data_path} is not a valid data_path')
+        seq = SequenceFiles.open(data_path)
+        self.seq = seq
+        self.has_images = seq.images is not None
+        self.num_events = seq.num_events
+        self.t0, self.tk = seq.t[0], seq.t[-1]
+        self.num_frames = 0 if seq.images is None else len(seq.images)
+        self.frame_ts = [] if seq.images is None else [float(v) for v in seq.frame_stamps.reshape(len(seq.frame_stamps), -1)[:, 0]]
+        if len(self.frame_ts) != self.num_frames:
+            raise AssertionError("Number of frames and timestamps do not match")
+        res = self.sensor_resolution
+        if res is None:
+            res = seq.metadata_resolution()
+        if res is None and self.num_frames > 0:
+            res = seq.images[0].shape[:2]
+        if res is None:
+            res = [np.max(seq.xy[:, 1]) + 1, np.max(seq.xy[:, 0]) + 1]
+        self.sensor_resolution = [int(res[0]), int(res[1])]
+
+    @property
+    def filehandle(self):
+        """The reference's dict of handles (dataset.py:232-251), for code written against it."""
+        d = {'t': self.seq.t, 'xy': self.seq.xy, 'p': self.seq.p}
+        if self.seq.images is not None:
+            d.update(images=self.seq.images, frame_stamps=self.seq.frame_stamps,
+                     image_event_indices=self.seq.image_event_indices)
+        return d
 
     # -- window tables (dataset.py:104-130,168-186,287-294) --------------------------------------
     def set_voxel_method(self):
@@ -191,10 +216,20 @@ class MemMapDataset:
             return self._dev
         fh = self.filehandle
         xy = np.ascontiguousarray(fh["xy"])
-        assert xy.min() >= 0 and xy.max() < 32768, "pixel coordinates do not fit int16"
+        # The reference trusts the coordinates: index_put_ raises beyond the sensor and WRAPS negative
+        # ones.  Here coordinates beyond the sensor are dropped by the kernel and counted (evr_voxelize_dropped); negative
+        # ones cannot be represented in the resident int16 form and are refused outright.
+        if xy.size and (xy.min() < 0 or xy.max() >= 32768):
+            raise ValueError(f"{self.data_path}: pixel coordinates outside [0, 32767] (min {xy.min()}, max {xy.max()})")
+        pol = np.ascontiguousarray(fh["p"])
+        # dataset.py:227 computes p*2-1 from {0,1}; a file that stores -1/+1 (or anything else) would silently become
+        # 255 -> weight 509 after a uint8 cast
+        if pol.size and not np.isin(pol, (0, 1)).all():
+            raise ValueError(f"{self.data_path}: events_p.npy must hold 0/1 (or bool) polarities, found values "
+                             f"{np.unique(pol)[:6].tolist()}")
         d = {'xy': torch.from_numpy(xy.astype(np.int16)).to(self.device),
              'ts': torch.from_numpy(np.array(fh["t"], dtype=np.float64)).to(self.device),
-             'p': torch.from_numpy(np.ascontiguousarray(fh["p"]).astype(np.uint8)).to(self.device)}
+             'p': torch.from_numpy(pol.astype(np.uint8)).to(self.device)}
         if self.has_images:
             d["images"] = torch.from_numpy(np.array(fh["images"][..., 0])).to(self.device)   # [F,H,W] u8
         self._dev = d

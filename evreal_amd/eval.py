@@ -81,8 +81,12 @@ class _ConfigParserShim:
     """Stand-in so torch.load can unpickle the `parse_config.ConfigParser` object stored inside the
     E2VID+/FireNet+/HyperE2VID checkpoints (parse_config.py:1-22 of the reference)."""
 
+    @property
+    def config(self):
+        return self._config
+
     def __getitem__(self, name):
-        return self.config[name]
+        return self._config[name]
 
 
 def _load_checkpoint(path):
@@ -271,6 +275,28 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     return out
 
 
+def fold_dataset_metrics(dataset_metrics, metric_names, dist, device=None):
+    """Fold one dataset's MetricTracker over the ranks: ONE all-reduce(SUM) of [total, count] per requested metric
+    (what MetricTracker.update accumulates, eval.py:259-266).  The column set is the REQUESTED metric list -- identical
+    on every rank, including ranks that own no sequence of this dataset -- so every tracked metric (mse, ssim, lpips,
+    plug-ins) survives the fold; metrics nobody scored (count 0 everywhere) stay absent, as in a single-rank run."""
+    names = list(dict.fromkeys(metric_names))
+    if device is None:
+        device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    sums = torch.zeros((len(names), 2), dtype=torch.float64, device=device)
+    for i, nm in enumerate(names):
+        d = dataset_metrics.data_dict.get(nm)
+        if d is not None:
+            sums[i, 0], sums[i, 1] = d['total'], d['count']
+    tot = reduce_metric_sums(sums, dist)
+    out = MetricTracker()
+    for i, nm in enumerate(names):
+        if tot[i, 1] > 0:
+            out.data_dict[nm] = {'total': float(tot[i, 0]), 'count': int(round(tot[i, 1])),
+                                 'average': float(tot[i, 0] / tot[i, 1])}
+    return out
+
+
 def _dist():
     import torch.distributed as dist
     return dist if dist.is_available() and dist.is_initialized() else None
@@ -331,19 +357,8 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
             print(f"Exception while evaluating method {method_name} on {dataset['name']} dataset:")
             print(e); print(traceback.format_exc())
         finally:
-            if world > 1:      # fold [sum(mean*n) per metric ..., n] over ranks: MetricTracker.update (eval.py:259-266)
-                names = [m for m in metrics if m in ('mse', 'ssim')]
-                sums = torch.zeros((1, len(names) + 1), dtype=torch.float64, device='cuda')
-                for k, nm in enumerate(names):
-                    if nm in dataset_metrics.data_dict:
-                        sums[0, k] = dataset_metrics.data_dict[nm]['total']
-                        sums[0, -1] = dataset_metrics.data_dict[nm]['count']
-                tot = reduce_metric_sums(sums, dist)
-                dataset_metrics = MetricTracker()
-                if tot[0, -1] > 0:
-                    for k, nm in enumerate(names):
-                        dataset_metrics.data_dict[nm] = {'total': float(tot[0, k]), 'count': int(tot[0, -1]),
-                                                         'average': float(tot[0, k] / tot[0, -1])}
+            if world > 1:
+                dataset_metrics = fold_dataset_metrics(dataset_metrics, metrics, dist)
             method_metrics.append(dataset_metrics)
     return method_metrics
 

@@ -38,13 +38,32 @@ class HotPath:
             self.ev_model = [torch.cuda.Event(), torch.cuda.Event()]     # image k is complete (main stream)
             self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
             self.k = 0
+        self._vox_events = None
         model.reset_states()
+
+    def time_voxelizer(self, on):
+        """on=True: bracket the tensorizer launches of every following step with HIP events on the stream they are
+        launched on.  on=False: stop and return their average duration in ms (None if nothing was recorded)."""
+        if on:
+            self._vox_events = []
+            return None
+        ev, self._vox_events = self._vox_events, None
+        if not ev:
+            return None
+        ev[-1][1].synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
         """One frame for every sequence.  xy/ts/pol: resident raw event arrays; win_offsets: int64
         [n_seq+1] device tensor delimiting this step's n_seq windows.  ref: [n_seq,H,W] reference
         frames (already /255) or None.  Returns (img [n_seq,1,H,W], scores [n_seq,2|3] = mse, ssim[, lpips] or None)."""
+        if self._vox_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
+        if self._vox_events is not None:
+            e1.record()
+            self._vox_events.append((e0, e1))
         return self._rest(ref, scores_out)
 
     def step(self, x, y, t, p, win_offsets, ref=None, scores_out=None):

@@ -70,3 +70,63 @@ def test_assign_sequences_lpt():
     assert assign_sequences([5, 9, 1, 3, 7], 2) == plan             # deterministic
     assert assign_sequences([1.0] * 3, 8)[3:] == [[]] * 5           # more ranks than sequences
     assert reduce_metric_sums(torch.ones((1, 3), dtype=torch.float64)).tolist() == [[1.0, 1.0, 1.0]]
+
+
+def _fold_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from evreal_amd.eval import fold_dataset_metrics
+    from evreal_amd.eval_metrics import MetricTracker as MT
+    dm = MT()
+    if rank == 0:       # rank 1 owns no sequence of this dataset: its tracker stays empty
+        dm.update('mse', 0.05, 10); dm.update('ssim', 0.61, 10); dm.update('lpips', 0.33, 10)
+        dm.update('mse', 0.10, 30); dm.update('ssim', 0.40, 30); dm.update('lpips', 0.20, 30)
+    out = fold_dataset_metrics(dm, ['mse', 'ssim', 'lpips', 'niqe'], dist)
+    q.put((rank, {k: (v['total'], v['count'], v['average']) for k, v in out.data_dict.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_keeps_every_tracked_metric():
+    """The multi-rank table must carry the same columns as the single-rank one (lpips and plug-in metrics included);
+    a requested metric nobody scored stays absent."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fold_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    for _, d in res:
+        assert list(d) == ['mse', 'ssim', 'lpips']
+        assert d['lpips'][1] == 40 and abs(d['lpips'][2] - (0.33 * 10 + 0.20 * 30) / 40) < 1e-15
+        assert abs(d['mse'][2] - 0.0875) < 1e-15
+
+
+def test_checkpoint_config_parser_shim(tmp_path):
+    """E2VID+/FireNet+/HyperE2VID checkpoints pickle a parse_config.ConfigParser (reference parse_config.py:1-22) whose
+    only attribute is `_config`; eval.py:150-151 reads config['arch']."""
+    import sys, types
+    from evreal_amd.eval import _load_checkpoint
+    mod = types.ModuleType('parse_config')
+
+    class ConfigParser:
+        def __init__(self, config):
+            self._config = config
+    ConfigParser.__module__ = 'parse_config'
+    ConfigParser.__qualname__ = 'ConfigParser'
+    mod.ConfigParser = ConfigParser
+    sys.modules['parse_config'] = mod
+    try:
+        torch.save({'config': ConfigParser({'arch': {'type': 'FireNet', 'args': {'num_bins': 5}}}),
+                    'state_dict': {}}, tmp_path / 'm.pth')
+    finally:
+        del sys.modules['parse_config']
+    ck = _load_checkpoint(str(tmp_path / 'm.pth'))
+    assert ck['config']['arch']['type'] == 'FireNet' and ck['config']['arch']['args'] == {'num_bins': 5}
+    assert ck['config'].config['arch']['type'] == 'FireNet'
+    real = '/root/reference/pretrained/FireNet+/model.pth'
+    if os.path.exists(real):
+        ck = _load_checkpoint(real)
+        assert ck['config']['arch']['type'] == 'FireNet' and 'num_bins' in ck['config']['arch']['args']

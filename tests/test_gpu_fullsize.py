@@ -1,0 +1,178 @@
+"""GPU parity at the sizes BASELINE.json's configs run at: every comparison is the HIP
+path through the C ABI against the torch-CPU oracle on the same events, 1e-4 absolute per pixel (north_star).
+
+  * 100-frame recurrence, 346x260 (pads to 352x264), 8 different sequences advanced together -- the band kernels'
+    natural dispatch (the one bench.py times), event-tensor normalization fused, ConvLSTM states checked at the end;
+  * E2VID at 640x480 (north_star's second sensor), E2VID+ and HyperE2VID layouts at 346x260;
+  * FireNet with the shipped checkpoint at 240x180 (pads to 240x192) over k_events windows of a synthetic sequence;
+  * ColorNet at 970x624 (half resolution 485x312 pads to 488x312; full resolution to 976x624) and its behaviour on
+    odd sensor sides (BS-ERGB's 970x625): the reference raises there (model/model.py:81-99, see the test).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from golden_inputs import gen_events
+
+pytestmark = pytest.mark.gpu
+IMG_ATOL = 1e-4
+OKEYS = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size', 'norm',
+         'use_upsample_conv', 'recurrent_block_type', 'final_activation']
+
+
+def _pair(kw, seed, fixed=None):
+    """(HIP model, oracle) with the same deterministic synthetic weights."""
+    from evreal_amd import model, weights
+    from oracle import model as omod
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=seed, fixed=fixed)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    okw = {k: kw[k] for k in OKEYS}
+    okw['use_dynamic_decoder'] = kw.get('use_dynamic_decoder', False)
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
+    return m, o
+
+
+def _windows(seeds, n, W, H):
+    """Events of len(seeds) windows, concatenated, + window offsets."""
+    ev = [gen_events(s, n, W, H) for s in seeds]
+    cat = [np.concatenate([e[i] for e in ev]) for i in range(4)]
+    offs = np.arange(len(seeds) + 1, dtype=np.int64) * n
+    return ev, cat, offs
+
+
+def _d(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run(m, o, H, W, num_encoders, frames, n_seq, n_events, seed0, normalize=True, check_states=False):
+    from evreal_amd.voxel import Voxelizer
+    from oracle import prepost as op, voxel as ov
+    crop = op.CropParams(W, H, num_encoders)
+    vz = Voxelizer()
+    st = torch.zeros((n_seq, 3), dtype=torch.float64, device='cuda')
+    m.reset_states(); o.reset_states()
+    worst = 0.0
+    for f in range(frames):
+        ev, cat, offs = _windows([seed0 + 1000 * f + s for s in range(n_seq)], n_events, W, H)
+        g = vz.voxelize(_d(cat[0]), _d(cat[1]), _d(cat[2]), _d(cat[3]), _d(offs), 5, (H, W), stats=st)
+        img = m(g, stats=st if normalize else None)['image'].cpu().numpy()
+        v = np.stack([ov.events_to_voxel(*e, 5, (H, W)) for e in ev])
+        if normalize:
+            v = np.stack([op.normalize_event_tensor(v[s:s + 1])[0] for s in range(n_seq)])
+        with torch.no_grad():
+            want = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())
+        err = float(np.abs(img - want).max())
+        worst = max(worst, err)
+        assert err < IMG_ATOL, (f, err)
+    if check_states:
+        for i in range(num_encoders):
+            h = m.read_tensor(f'h{i}').cpu().numpy().reshape(o.states[i][0].shape)
+            c = m.read_tensor(f'c{i}').cpu().numpy().reshape(o.states[i][1].shape)
+            np.testing.assert_allclose(h, o.states[i][0].numpy(), rtol=2e-4, atol=5e-5, err_msg=f'h{i}')
+            np.testing.assert_allclose(c, o.states[i][1].numpy(), rtol=2e-4, atol=5e-5, err_msg=f'c{i}')
+    return worst
+
+
+def test_drift_100_frames_346x260_8_sequences():
+    """SURVEY section 7's condition for split precision: >= 100 recurrent steps, full size, on the kernels the bench runs."""
+    from evreal_amd import weights
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    m, o = _pair(dict(weights.E2VID_KWARGS), seed=21)
+    worst = _run(m, o, 260, 346, 3, frames=100, n_seq=8, n_events=15000, seed0=40000, check_states=True)
+    print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
+
+
+def test_e2vid_640x480_vs_oracle():
+    from evreal_amd import weights
+    m, o = _pair(dict(weights.E2VID_KWARGS), seed=22)
+    _run(m, o, 480, 640, 3, frames=2, n_seq=2, n_events=50000, seed0=50000)
+
+
+def test_e2vid_plus_layout_346x260():
+    from evreal_amd import weights
+    m, o = _pair(dict(weights.E2VID_PLUS_KWARGS), seed=23)
+    _run(m, o, 260, 346, 3, frames=2, n_seq=2, n_events=15000, seed0=60000, normalize=False)
+
+
+def test_hyper_layout_346x260():
+    z = load_npz('e2vid_hyper_seq.npz')
+    kw = json.loads(bytes(z['kwargs']).decode())
+    fixed = {k[6:]: z[k] for k in z.files if k.startswith('fixed.')}      # the reference's Fourier-Bessel table
+    m, o = _pair(kw, seed=24, fixed=fixed)
+    _run(m, o, 260, 346, 3, frames=3, n_seq=2, n_events=15000, seed0=70000, normalize=False)
+
+
+def test_firenet_real_weights_240x180_k_events(tmp_path):
+    """BASELINE config 3: FireNet (shipped checkpoint) on a 240x180 sequence, k_events windowing through the
+    sequence reader (events resident in HBM, many windows per launch), normalization on (config/method/FireNet.json)."""
+    from evreal_amd import model, synth
+    from evreal_amd.dataset import MemMapDataset
+    from oracle import model as omod, prepost as op, voxel as ov
+    w = load_npz('firenet_weights.npz')
+    sd = {k: w[k] for k in w.files}
+    m = model.FireNet_legacy(unet_kwargs=dict(num_bins=5, recurrent_block_type='convgru', base_num_channels=16,
+                                              num_residual_blocks=2, kernel_size=3, norm='none'))
+    m.load_state_dict(sd)
+    o = omod.FireNetLegacyOracle({k: torch.from_numpy(v) for k, v in sd.items()})
+    H, W, K = 180, 240, 7500
+    synth.write_sequence(str(tmp_path / 's'), 3, 12 * K + 100, 1.0e6, W, H, 50.0)
+    ds = MemMapDataset(str(tmp_path / 's'), num_bins=5, voxel_method={'method': 'k_events', 'k': K, 'sliding_window_w': 0})
+    assert tuple(ds.sensor_resolution) == (H, W) and len(ds) == 12
+    grid, stats = ds.voxel_batch(list(range(12)))
+    fh = ds.filehandle
+    crop = op.CropParams(W, H, 4)
+    m.reset_states()
+    for i in range(12):
+        img = m(grid[i:i + 1], stats=stats[i:i + 1])['image'].cpu().numpy()
+        xs, ys, tf, ps = synth.window_events_f32(np.asarray(fh['t']), np.asarray(fh['xy']), np.asarray(fh['p']), i * K, (i + 1) * K)
+        v = ov.events_to_voxel(xs, ys, tf, ps, 5, (H, W))
+        assert np.array_equal(grid[i].cpu().numpy().view(np.uint32), v.view(np.uint32)), i      # tensorizer: bit exact
+        with torch.no_grad():
+            want = crop.crop(o(torch.from_numpy(crop.pad(op.normalize_event_tensor(v[None])))).numpy())
+        assert float(np.abs(img - want).max()) < IMG_ATOL, i
+
+
+def test_colornet_970x624_streams_vs_oracle():
+    """BS-ERGB-sized colour pass (even crop of 970x625): the four half-resolution streams (485x312 -> 488x312) and the
+    full-resolution stream (970x624 -> 976x624) against the oracle run stream by stream, as model/model.py:85-99 does."""
+    from evreal_amd import model, weights
+    from oracle import color as oc, prepost as op
+    kw = dict(weights.E2VID_PLUS_KWARGS)
+    m, o = _pair(kw, seed=25)
+    net = model.ColorNet(m)
+    H, W = 624, 970
+    ev = gen_events(81000, 50000, W, H)
+    from oracle import voxel as ov
+    v = ov.events_to_voxel(*ev, 5, (H, W))[None]
+    out = net(_d(v))
+    planes = out['planes'][0].cpu().numpy(); gray = out['gray'][0, 0].cpu().numpy()
+    split = oc.bayer_split(v)[0]                                     # [4,B,312,485]
+    ch, cf = op.CropParams(W // 2, H // 2, 3), op.CropParams(W, H, 3)
+    assert (ch.pad(split[:1]).shape[-2:], cf.pad(v).shape[-2:]) == ((312, 488), (624, 976))
+    with torch.no_grad():
+        for c in range(4):
+            o.reset_states()
+            want = ch.crop(o(torch.from_numpy(ch.pad(split[c:c + 1]))).numpy())[0, 0]
+            assert float(np.abs(planes[c] - want).max()) < IMG_ATOL, c
+        o.reset_states()
+        want = cf.crop(o(torch.from_numpy(cf.pad(v))).numpy())[0, 0]
+    assert float(np.abs(gray - want).max()) < IMG_ATOL
+    assert out['image'].shape == (1, H, W, 3) and out['image'].dtype == torch.uint8
+
+
+def test_colornet_odd_sides_raise_like_the_reference():
+    """The reference's ColorNet cannot run an odd sensor side: the R/G rows `0::2` keep ceil(H/2) rows while the crop
+    is built for int(H/2) (model/model.py:81-90), and the first skip connection raises "The size of tensor a must
+    match the size of tensor b" (probed with the reference class at 97x128, 96x129 and 125x194).  BASELINE config 5's
+    970x625 therefore needs an even crop there too; here the boundary raises with that explanation, never truncates."""
+    from evreal_amd import lib as L, model, weights
+    kw = dict(weights.E2VID_PLUS_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=2)
+    base = model.E2VIDRecurrent(kw); base.load_state_dict(sd)
+    net = model.ColorNet(base)
+    for H, W in [(97, 128), (96, 129)]:
+        with pytest.raises(L.EvrError, match='even'):
+            net(torch.zeros((1, 5, H, W), device='cuda'))
