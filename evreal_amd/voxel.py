@@ -18,6 +18,7 @@ class Voxelizer:
         need = self.lib.evr_voxelize_workspace_bytes(n_events, n_windows, B, H, W)
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            self.ws[:256].zero_()          # the header (drop counters) must start at zero; the rest is scratch
         return self.ws
 
     def voxelize(self, x, y, t, p, win_offsets, num_bins, sensor_size, out=None, stats=None, stream=None):

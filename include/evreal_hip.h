@@ -57,6 +57,8 @@ int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_
  *                  each window's voxel grid, the reductions eval.py:402-405 needs.
  * Results are BIT-IDENTICAL to the reference's CPU path: per-cell adds happen in event order.
  * Events whose pixel falls outside [0,W)x[0,H) are dropped and counted (evr_voxelize_dropped).
+ * workspace: caller-owned device memory of evr_voxelize_workspace_bytes(); its first 256 bytes must be ZERO the first
+ * time it is used (hipMemset once after allocation) -- the calls themselves launch no memset.
  */
 size_t evr_voxelize_workspace_bytes(int64_t n_events_total, int n_windows, int B, int H, int W);
 int evr_voxelize(const float* x, const float* y, const float* t, const float* p,

@@ -65,8 +65,11 @@ def test_many_windows_vs_oracle(vox):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     for w in range(len(sizes)):
         assert int(st[w, 2]) == int((want[w] != 0).sum())
-        np.testing.assert_allclose(st[w, 0], want[w].astype(np.float64).sum(), rtol=0, atol=1e-9)
-        np.testing.assert_allclose(st[w, 1], (want[w].astype(np.float64) ** 2).sum(), rtol=1e-12, atol=1e-12)
+        # {sum, sum of squares}: per-thread fp32 partials over a few dozen cells, folded in fp64 in a fixed order
+        # (deterministic).  They feed eval.py:402-405, whose own fp32 torch.sum is only good to ~1e-6.
+        w64 = want[w].astype(np.float64)
+        np.testing.assert_allclose(st[w, 0], w64.sum(), rtol=0, atol=1e-6 * max(1.0, np.abs(w64).sum()))
+        np.testing.assert_allclose(st[w, 1], (w64 ** 2).sum(), rtol=1e-6, atol=1e-12)
 
 
 def test_raw_form_matches_dataset_path(vox):
