@@ -24,6 +24,7 @@ PER_FILE = {
     'prepost.hip': ['-ffp-contract=off'],
     'metrics.hip': ['-ffp-contract=off'],
     'color.hip': ['-ffp-contract=off'],
+    'histeq.hip': ['-ffp-contract=off'],
 }
 
 

@@ -4,15 +4,26 @@ Output files are byte-compatible with the reference (utils/eval_utils.py:57-84):
 ("{idx} {ts:.15f}"), `<metric>.txt` / `event_rate.txt` ("{idx} {score:.5f}"), `frame_%010d.png`
 (round(img*255) uint8) -- the formats analyze_robustness.py:55-65,109-110 and downstream_tasks/ parse.
 Frames arrive in batches; gating (start/end time, |ref_ts-img_ts| <= ts_tol_ms, not color) is per frame.
+
+Metric plug-ins keep the reference's contract (utils/eval_metrics.py:18-75): a `BaseMetric` subclass with `name`,
+`no_ref`, `calculate(img, ref) -> float | list`, `finish_queue()`, `reset()`.  Three kinds live side by side:
+  * 'mse', 'ssim' and -- when a weights file is available -- 'lpips' run batched on the GPU (evr_metrics / evr_lpips_*);
+  * anything registered with `register_metric(name, factory)` runs per frame on host arrays, exactly like the reference's
+    MseMetric / SsimMetric (clipped float32 [H,W] images in, a float or a list of floats out);
+  * any other name is looked up in pyiqa.list_models() when pyiqa is importable (queued in batches of 4 as
+    PyIqaMetricFactory does, :100-156); without pyiqa it is reported as "Unknown metric", as the reference does for a
+    name it does not know (:203).
 """
 import math
 import os
+import traceback
+import warnings
 from os.path import join
 
 import numpy as np
 import torch
 
-from .prepost import Metrics
+from .prepost import Metrics, histogram_equalization
 
 GPU_METRICS = ('mse', 'ssim')
 LPIPS_WEIGHTS_ENV = 'EVREAL_LPIPS_WEIGHTS'      # path to a pyiqa/lpips AlexNet-v0.1 state_dict (torch.save'd)
@@ -28,15 +39,36 @@ def _load_lpips():
 
 
 class BaseMetric:
-    """Score bookkeeping of utils/eval_metrics.py:18-75 (finite scores only; mean or -1)."""
+    """Base class for quantitative evaluation metrics -- the plug-in contract of utils/eval_metrics.py:18-75."""
 
-    def __init__(self, name):
-        self.name, self.scores, self.updated, self.no_ref = name, [], 0, False
+    def __init__(self, name, no_ref=False):
+        self.scores = []
+        self.name = name
+        self.no_ref = no_ref
+        self.updated = 0
+        self.image_queue = []
+        self.ref_queue = []
+        self.batch_size = 4
 
     def reset(self):
-        self.scores, self.updated = [], 0
+        self.scores, self.image_queue, self.ref_queue, self.updated = [], [], [], 0
+
+    def finish_queue(self):
+        self.updated = 0
+
+    def get_num_updated(self):
+        return self.updated
+
+    def calculate(self, img, ref):
+        raise NotImplementedError
+
+    def update(self, img, ref=None):
+        self.updated = 0
+        score = self.calculate(img, ref)
+        self.add(score if isinstance(score, list) else [score])
 
     def add(self, values):
+        """Keep the finite scores (utils/eval_metrics.py:49-53)."""
         self.updated = 0
         for s in values:
             s = float(s)
@@ -44,8 +76,112 @@ class BaseMetric:
                 self.updated += 1
                 self.scores.append(s)
 
+    def get_num_scores(self):
+        return len(self.scores)
+
+    def get_all_scores(self):
+        return self.scores
+
+    def get_last_score(self):
+        return self.scores[-1]
+
+    def get_last_scores(self, n):
+        return self.scores[-n:]
+
     def get_mean_score(self):
         return -1 if not self.scores else sum(self.scores) / len(self.scores)
+
+    def get_name(self):
+        return self.name
+
+
+class GpuMetric(BaseMetric):
+    """'mse' / 'ssim' / 'lpips': the tracker computes a whole batch with one launch and hands the scores to add()."""
+    on_gpu = True
+
+    def calculate(self, img, ref):
+        raise RuntimeError(f"{self.name} is computed in batches by EvalMetricsTracker.update_batch")
+
+
+_REGISTRY = {}
+
+
+def register_metric(name, factory):
+    """Make `name` available to -qm / quan_eval_metric_names: factory() -> BaseMetric (per-frame, host arrays)."""
+    _REGISTRY[name] = factory
+
+
+class PyIqaMetricFactory:
+    """Any pyiqa metric by name (utils/eval_metrics.py:100-156), when pyiqa can be imported: gray frames are replicated
+    to 3 channels (cv2torch(num_ch=3), eval_utils.py:46-54), queued, and scored four at a time; the queue's tail is
+    flushed by finish_queue()."""
+
+    def __init__(self):
+        try:
+            import pyiqa
+        except Exception:
+            pyiqa = None
+        self.pyiqa = pyiqa
+        self.list_of_metrics = list(pyiqa.list_models()) if pyiqa is not None else []
+        self.created_metrics = {}
+
+    def get_metric(self, name):
+        if name in self.created_metrics:
+            return self.created_metrics[name]
+        with warnings.catch_warnings():
+            warnings.filterwarnings("ignore", category=UserWarning)
+            iqa_metric = self.pyiqa.create_metric(name)
+        metric = _QueuedIqaMetric(name.lower(), iqa_metric.metric_mode == 'NR', iqa_metric)
+        self.created_metrics[name] = metric
+        return metric
+
+
+def _as_batch(image, num_ch=3):
+    t = torch.as_tensor(np.asarray(image))
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+        if num_ch > 1:
+            t = t.repeat(num_ch, 1, 1)
+    return t.unsqueeze(0) if t.dim() == 3 else t
+
+
+class _QueuedIqaMetric(BaseMetric):
+    def __init__(self, name, no_ref, fn):
+        super().__init__(name, no_ref)
+        self.fn = fn
+
+    def inference(self):
+        if not self.image_queue:
+            return []
+        imgs = torch.cat(self.image_queue[-self.batch_size:])
+        if self.ref_queue[0] is not None:
+            scores = self.fn(imgs, torch.cat(self.ref_queue[-self.batch_size:]))
+        else:
+            scores = self.fn(imgs)
+        self.image_queue, self.ref_queue = [], []
+        out = scores.squeeze().tolist()
+        return out if isinstance(out, list) else [out]
+
+    def finish_queue(self):
+        self.updated = 0
+        score = self.inference()
+        self.updated += len(score)
+        self.scores.extend(score)
+
+    def calculate(self, img, ref=None):
+        self.image_queue.append(_as_batch(img))
+        self.ref_queue.append(None if ref is None else _as_batch(ref))
+        return [] if len(self.image_queue) < self.batch_size else self.inference()
+
+
+_pyiqa_factory = None
+
+
+def pyiqa_metric_factory():
+    global _pyiqa_factory
+    if _pyiqa_factory is None:
+        _pyiqa_factory = PyIqaMetricFactory()
+    return _pyiqa_factory
 
 
 class EvalMetricsTracker:
@@ -54,22 +190,30 @@ class EvalMetricsTracker:
                  quan_eval_ts_tol_ms=float('inf'), has_reference_frames=False, color=False):
         if quan_eval_metric_names is None:
             quan_eval_metric_names = ['mse', 'ssim', 'lpips']
-        if hist_eq != 'none':
-            raise NotImplementedError(f"histeq={hist_eq!r}: every shipped eval config uses 'none' (SURVEY 8f-4)")
+        if hist_eq not in ('none', 'global', 'local', 'clahe'):
+            raise ValueError(f"Unrecognized histogram equalization argument: {hist_eq}")
         self.save_images, self.output_dir, self.hist_eq = save_images, output_dir, hist_eq
+        self.save_processed_images = save_processed_images
+        if self.hist_eq == 'none' and self.save_processed_images:
+            print("Can not save processed images when hist_eq is none")
+            self.save_processed_images = False
         self._pending = []
-        self.save_processed_images = False
+        self._files = {}
         self.start, self.end, self.tol_ms = quan_eval_start_time, quan_eval_end_time, quan_eval_ts_tol_ms
         self.has_reference_frames, self.color = has_reference_frames, color
         self.quan_eval_indices = []
         self.metrics = []
         for name in quan_eval_metric_names:
             if name in GPU_METRICS:
-                self.metrics.append(BaseMetric(name))
-            elif name == 'lpips' and (self._lpips_model() is not None):
-                self.metrics.append(BaseMetric(name))
+                self.metrics.append(GpuMetric(name))
+            elif name == 'lpips' and self._lpips_model() is not None:
+                self.metrics.append(GpuMetric(name))
+            elif name in _REGISTRY:
+                self.metrics.append(_REGISTRY[name]())
+            elif name in pyiqa_metric_factory().list_of_metrics:
+                self.metrics.append(pyiqa_metric_factory().get_metric(name))
             else:
-                print("Unknown metric " + name)     # utils/eval_metrics.py:203 (LPIPS/pyiqa: not built yet)
+                print("Unknown metric " + name)     # utils/eval_metrics.py:203
         if not self.has_reference_frames:
             self.metrics = [m for m in self.metrics if m.no_ref]
         self.only_no_ref = all(m.no_ref for m in self.metrics)
@@ -84,62 +228,126 @@ class EvalMetricsTracker:
             cls._lpips_cache = [True, _load_lpips()]
             if cls._lpips_cache[1] is None:
                 print(f"lpips: no weights at ${LPIPS_WEIGHTS_ENV} or pretrained/lpips_alex.pth (pyiqa downloads them; "
-                      "offline they must be provided) -> metric skipped")
+                      "offline they must be provided) -> falling back to pyiqa if it is installed")
         return cls._lpips_cache[1]
 
     # -- files --------------------------------------------------------------------------------
     def reset(self):
         os.makedirs(self.output_dir, exist_ok=True)
+        if self.save_processed_images:
+            self.processed_output_dir = self.output_dir + "_processed"
+            os.makedirs(self.processed_output_dir, exist_ok=True)
+        self._close_files()
         open(join(self.output_dir, 'timestamps.txt'), 'w', encoding="utf-8").close()
         for m in self.metrics:
             open(join(self.output_dir, m.name + '.txt'), 'w', encoding="utf-8").close()
             m.reset()
 
-    @staticmethod
-    def _append(path, pairs, fmt='{} {:.5f}\n'):
-        with open(path, 'a', encoding="utf-8") as f:
-            for a, b in pairs:
-                f.write(fmt.format(a, b))
+    # Text outputs: the reference re-opens a file for every line (eval_utils.py:57-69).  Here a tracker keeps its files
+    # open in append mode and writes a batch of lines at a time; finalize() closes them.  Same bytes, no per-frame
+    # open/close on the critical path.
+    def _file(self, path):
+        f = self._files.get(path)
+        if f is None:
+            f = self._files[path] = open(path, 'a', encoding="utf-8")
+        return f
 
-    def save_custom_metric(self, idx, metric_name, metric_value):
+    def _close_files(self):
+        for f in self._files.values():
+            f.close()
+        self._files = {}
+
+    def _append(self, path, pairs, fmt='{} {:.5f}\n'):
+        f = self._file(path)
+        f.write(''.join(fmt.format(a, b) for a, b in pairs))
+
+    def save_custom_metric(self, idx, metric_name, metric_value, is_int=False):
         path = join(self.output_dir, metric_name + '.txt')
-        if idx == 0:
-            open(path, 'w', encoding="utf-8").close()   # the reference only truncates on idx 0 (eval_metrics.py:277-278)
-        self._append(path, [(idx, metric_value)])
+        if idx == 0:      # the reference only truncates on idx 0 (eval_metrics.py:277-278)
+            old = self._files.pop(path, None)
+            if old is not None:
+                old.close()
+            open(path, 'w', encoding="utf-8").close()
+        self._append(path, [(idx, metric_value)], '{} {}\n' if is_int else '{} {:.5f}\n')
+
+    def save_new_scores(self, metric):
+        """eval_metrics.py:217-223: the scores a metric produced since its last update, against the LAST evaluated indices
+        (a queued metric returns nothing until its batch is full, then `batch_size` scores at once)."""
+        n = metric.get_num_updated()
+        if n > 0:
+            self._append(join(self.output_dir, metric.name + '.txt'),
+                         zip(self.quan_eval_indices[-n:], metric.get_last_scores(n)))
 
     # -- per batch ----------------------------------------------------------------------------
     def update_batch(self, indices, imgs, refs, img_ts, ref_ts):
         """indices: dataset indices; imgs [n,H,W] cuda (unclipped); refs [n,H,W] cuda or None;
         img_ts / ref_ts: python floats per frame (ref_ts None -> img_ts)."""
+        try:
+            self._update_batch(indices, imgs, refs, img_ts, ref_ts)
+        finally:
+            for f in self._files.values():      # one write per file per batch reaches the OS even if a later frame raises
+                f.flush()
+
+    def _update_batch(self, indices, imgs, refs, img_ts, ref_ts):
         n = len(indices)
         if ref_ts is None:
             ref_ts = img_ts
         self._append(join(self.output_dir, 'timestamps.txt'), zip(indices, img_ts), '{} {:.15f}\n')
         if self.save_images:
-            self._save_pngs(indices, imgs)
+            self._save_pngs(self.output_dir, indices, imgs)        # clipped inside; BEFORE hist-eq (eval_metrics.py:257-258)
         sel = []
         for j in range(n):
             inside = self.start <= img_ts[j] <= self.end
             tol_ok = abs(ref_ts[j] - img_ts[j]) * 1000 <= self.tol_ms or self.only_no_ref
             if inside and tol_ok and not self.color:
                 sel.append(j)
+        need_proc = self.hist_eq != 'none' and (self.save_processed_images or (sel and self.metrics))
+        if need_proc:
+            # histogram equalisation of the clipped frames (eval_metrics.py:260-265); `none` leaves the clip to the kernels
+            imgs = histogram_equalization(torch.clamp(imgs, 0.0, 1.0).contiguous(), self.hist_eq)
+            if refs is not None and self.has_reference_frames:
+                refs = histogram_equalization(torch.clamp(refs, 0.0, 1.0).contiguous(), self.hist_eq)
+            if self.save_processed_images:
+                self._save_pngs(self.processed_output_dir, indices, imgs)
         if not sel or not self.metrics:
             self.quan_eval_indices.extend(indices[j] for j in sel)
             return
         js = torch.tensor(sel, device=imgs.device)
-        want = {m.name for m in self.metrics}
-        scores = self._gpu(imgs[js].contiguous(), refs[js].contiguous(), mse='mse' in want, ssim='ssim' in want,
-                           clip=True).cpu().numpy()
         idxs = [indices[j] for j in sel]
-        self.quan_eval_indices.extend(idxs)
-        lp = None
-        if 'lpips' in want:
-            lp = self._lpips_model()(imgs[js].contiguous(), refs[js].contiguous(), clip=True).cpu().numpy()
-        for m in self.metrics:
-            col = scores[:, 0] if m.name == 'mse' else scores[:, 1] if m.name == 'ssim' else lp
-            finite = [(i, float(s)) for i, s in zip(idxs, col) if math.isfinite(s)]
-            m.add(col)
-            self._append(join(self.output_dir, m.name + '.txt'), finite)
+        gpu = [m for m in self.metrics if getattr(m, 'on_gpu', False)]
+        host = [m for m in self.metrics if not getattr(m, 'on_gpu', False)]
+        isel = imgs[js].contiguous()
+        rsel = refs[js].contiguous() if refs is not None else None
+        if gpu:
+            want = {m.name for m in gpu}
+            scores = None
+            if want & set(GPU_METRICS):
+                scores = self._gpu(isel, rsel, mse='mse' in want, ssim='ssim' in want, clip=True).cpu().numpy()
+            lp = self._lpips_model()(isel, rsel, clip=True).cpu().numpy() if 'lpips' in want else None
+            for m in gpu:
+                col = scores[:, 0] if m.name == 'mse' else scores[:, 1] if m.name == 'ssim' else lp
+                m.add(col)
+                self._append(join(self.output_dir, m.name + '.txt'),
+                             [(i, float(s)) for i, s in zip(idxs, col) if math.isfinite(s)])
+        if not host:
+            self.quan_eval_indices.extend(idxs)
+            return
+        # plug-in metrics: clipped host arrays, frame by frame, exactly as update_quantitative_metrics (:230-242)
+        himg = torch.clamp(isel, 0.0, 1.0).cpu().numpy()
+        href = torch.clamp(rsel, 0.0, 1.0).cpu().numpy() if (rsel is not None and self.has_reference_frames) else None
+        for k, idx in enumerate(idxs):
+            self.quan_eval_indices.append(idx)
+            for m in host:
+                try:
+                    if not self.has_reference_frames or m.no_ref:
+                        m.update(himg[k])
+                    else:
+                        m.update(himg[k], href[k])
+                    self.save_new_scores(m)
+                except Exception as e:
+                    print("Exception in metric " + m.get_name() + ": " + str(e))
+                    print(traceback.format_exc())
+                    m.reset()
 
     def update_batch_color(self, indices, bgr_u8, img_ts):
         """Colour frames (uint8 BGR [n,H,W,3] on the GPU): timestamps + PNGs only -- the reference skips every
@@ -171,17 +379,27 @@ class EvalMetricsTracker:
         else:
             self._pending.append(self._writer_pool().submit(job))
 
-    def _save_pngs(self, indices, imgs):
-        u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()
+    def _save_pngs(self, folder, indices, imgs):
+        u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()     # eval_utils.py:83
         for i, a in zip(indices, u8):
-            self._submit_png(join(self.output_dir, 'frame_{:010d}.png'.format(i)), a, 'L')
+            self._submit_png(join(folder, 'frame_{:010d}.png'.format(i)), a, 'L')
 
     def finalize(self, idx):
+        """eval_metrics.py:225-228: flush the queued metrics; then wait for this tracker's files."""
+        for m in self.metrics:
+            if getattr(m, 'on_gpu', False):
+                m.updated = 0
+                continue
+            try:
+                m.finish_queue()
+                self.save_new_scores(m)
+            except Exception as e:
+                print("Exception in metric " + m.get_name() + ": " + str(e))
+                m.reset()
         for f in self._pending:
             f.result()                                       # re-raises a writer's exception here
         self._pending = []
-        for m in self.metrics:
-            m.updated = 0
+        self._close_files()
 
     def get_num_quan_evaluations(self):
         return len(self.quan_eval_indices)

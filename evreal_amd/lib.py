@@ -57,6 +57,8 @@ SYMBOLS = {
     'evr_percentile_normalize_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'evr_percentile_normalize': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p,
                                          c_size_t, c_void_p]),
+    'evr_hist_equalize_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'evr_hist_equalize': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'evr_metrics': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_uint, c_int, c_void_p, c_void_p, c_size_t,
                             c_void_p]),
     'evr_metrics_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -55,3 +55,28 @@ class Metrics:
                                         _lib.ptr(out), _lib.ptr(self.ws), self.ws.numel(), _lib.stream_ptr()),
                    'evr_metrics')
         return out
+
+
+HISTEQ_MODES = {'none': 0, 'global': 1, 'local': 2, 'clahe': 3}
+_histeq_ws = {}
+
+
+def histogram_equalization(img, mode):
+    """EvalMetricsTracker.histogram_equalization (utils/eval_metrics.py:326-350) on cuda tensors [N,H,W] already clipped
+    to [0,1], in place.  'none' returns the input; an unknown name raises like the reference."""
+    if mode not in HISTEQ_MODES:
+        raise ValueError(f"Unrecognized histogram equalization argument: {mode}")
+    if mode == 'none':
+        return img
+    lib = _lib.load()
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+    v = img if img.dim() == 3 else img.unsqueeze(0)
+    n, H, W = v.shape
+    code = HISTEQ_MODES[mode]
+    need = lib.evr_hist_equalize_workspace_bytes(n, H, W, code)
+    ws = _histeq_ws.get(img.device)
+    if need and (ws is None or ws.numel() < need):
+        ws = _histeq_ws[img.device] = torch.empty(int(need), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.evr_hist_equalize(_lib.ptr(v), n, H, W, code, _lib.ptr(ws) if need else None, int(need),
+                                     _lib.stream_ptr()), 'evr_hist_equalize')
+    return img

@@ -174,6 +174,20 @@ int evr_percentile_normalize(float* img, int n, int H, int W, float q_lo, float 
                              void* workspace, size_t workspace_bytes, evr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Histogram equalisation of the tracker.  Replaces EvalMetricsTracker.histogram_equalization
+ * (utils/eval_metrics.py:326-350), applied to the clipped image and reference before the metrics:
+ *   EVR_HISTEQ_GLOBAL  skimage.exposure.equalize_hist            (:327-331)
+ *   EVR_HISTEQ_LOCAL   skimage.filters.rank.equalize, disk(55)   (:332-339)
+ *   EVR_HISTEQ_CLAHE   cv2.createCLAHE(2.0, (8, 8)).apply        (:340-345)
+ * img: [n, H, W] fp32 in [0, 1], in place.  PARITY UNPINNED (scikit-image / OpenCV are not available offline): the
+ * kernels restate the published algorithms and are checked against oracle/histeq.py.
+ */
+enum evr_histeq { EVR_HISTEQ_NONE = 0, EVR_HISTEQ_GLOBAL = 1, EVR_HISTEQ_LOCAL = 2, EVR_HISTEQ_CLAHE = 3 };
+size_t evr_hist_equalize_workspace_bytes(int n, int H, int W, int mode);
+int evr_hist_equalize(float* img, int n, int H, int W, int mode, void* workspace, size_t workspace_bytes,
+                      evr_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Per-frame metrics.  Replaces EvalMetricsTracker.update's clip (utils/eval_metrics.py:253-255),
  * MseMetric.calculate (:82-84) and SsimMetric.calculate (:95-97; gaussian_weights=True, sigma=1.5,
  * use_sample_covariance=False, data_range=1.0).  img, ref: [n, H, W]; out: double [n, 2] = {mse, ssim}.

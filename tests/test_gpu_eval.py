@@ -88,6 +88,15 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
                                  'base_num_channels': 16, 'num_residual_blocks': 2,
                                  'recurrent_blocks': {'resblock': [0]}, 'kernel_size': 3,
                                  'final_activation': 'none', 'norm': 'none', 'BN_momentum': 0.01}}}
+    from evreal_amd import eval_metrics as em
+    seen = {}
+    orig = em.EvalMetricsTracker._save_pngs
+
+    def spy(self, folder, indices, imgs):          # what the tracker was asked to write, as host arrays
+        for i, a in zip(indices, imgs.detach().cpu().numpy()):
+            seen[os.path.join(folder, 'frame_{:010d}.png'.format(i))] = a.copy()
+        return orig(self, folder, indices, imgs)
+    monkeypatch.setattr(em.EvalMetricsTracker, '_save_pngs', spy)
     digests = {}
     for mode in ('async', 'sync'):
         root = tmp_path / mode
@@ -111,7 +120,13 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
                 assert im.mode == 'L' and im.size == (64, 48)
                 for f in pngs:
                     out[os.path.relpath(os.path.join(d, f), root)] = hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest()
+                    # independent of the writer: the decoded file is the reference's formula on the frame it was handed
+                    # (eval_utils.py:83 after the clip of eval_metrics.py:253): np.round(clip(img, 0, 1) * 255) as uint8
+                    rel = os.path.relpath(os.path.join(d, f), root)
+                    want = np.round(np.clip(seen[rel], 0.0, 1.0) * 255).astype(np.uint8)
+                    assert np.array_equal(np.asarray(Image.open(os.path.join(d, f))), want), rel
         digests[mode] = out
+        seen.clear()
     assert digests['async'] and digests['async'] == digests['sync']
 
 
