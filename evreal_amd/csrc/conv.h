@@ -173,6 +173,21 @@ int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, 
 // out = x + y (skip_sum, model_util.py:4-5) when it cannot be fused into a producer epilogue
 // (packed: all three tensors are PACKED)
 int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream);
+// SPADE-E2VID helpers (spade.hip; model/spade_e2v.py of the reference)
+struct SpadePredArgs {
+    const float* x; const float* head;   // NHWC [n,hp,wp,32]
+    int x_packed, head_packed;
+    int n, hp, wp;
+    const float* wgt;                    // device [3][32], bn_img folded
+    float bias[3];
+    float* prev;                         // [n,3,hp,wp] planar: prev_recs / the next frame's segmentation map
+    float* img; int H, W, iy0, ix0;      // cropped mean image [n,1,H,W]
+};
+int launch_spade_pad(const float* vox, float* xpad, int n, int B, int H, int W, int hp, int wp, int pad_top, int pad_left, hipStream_t stream);
+int launch_spade_first(float* xpad, float* xorg, int n, int B, int hp, int wp, hipStream_t stream);
+int launch_nearest_half(const float* in, float* out, int planes, int h, int w, hipStream_t stream);
+int launch_spade_apply(const float* xn, const float* gb, const float* skip, float* out, int64_t pix, int C, int skip_packed, int out_packed, hipStream_t stream);
+int launch_spade_pred(const SpadePredArgs& a, hipStream_t stream);
 // NHWC -> NCHW copy (debug/parity reads)
 int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream);
 

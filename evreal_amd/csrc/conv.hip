@@ -1362,7 +1362,7 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.B * IS * IS * sizeof(float);
     EVR_REQUIRE(lds <= 64 * 1024, "head_conv: num_bins %d too large", a.B);
 #define EVR_HEAD(K_, C_) if (a.k == K_ && a.cout == C_) { hipLaunchKernelGGL((head_conv_kernel<K_, C_>), grid, dim3(256), lds, stream, a); EVR_LAUNCH_CHECK(); return EVR_OK; }
-    EVR_HEAD(5, 32) EVR_HEAD(3, 16) EVR_HEAD(3, 32) EVR_HEAD(5, 16)
+    EVR_HEAD(5, 32) EVR_HEAD(3, 16) EVR_HEAD(3, 32) EVR_HEAD(5, 16) EVR_HEAD(3, 64)
 #undef EVR_HEAD
     set_error("head_conv: unsupported kernel_size %d / base channels %d", a.k, a.cout);
     return EVR_ERR_UNSUPPORTED;

@@ -64,7 +64,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
     double flops = 0.0;
 };
 
-enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN };
+enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN,
+                ST_SP_NEAREST, ST_SP_SEG, ST_SP_APPLY };   // SPADE-E2VID (spade.hip)
 struct Step {
     StepKind kind;
     int conv = -1;
@@ -108,6 +109,15 @@ struct evr_model {
     float* prev_rec = nullptr;
     HeadArgs ctxconv;
     CtxArgs ctx;   // conv whose epilogue carries the prediction layer (-1: standalone pred kernel)
+    // SPADE-E2VID (model/spade_e2v.py): explicit padded input, segmentation map (first frame: normalised input
+    // channels; then the previous 3-channel reconstruction), its half-resolution copy, the SPADE MLP heads
+    float* sp_xpad = nullptr; float* sp_xorg = nullptr; float* sp_xorg_half = nullptr;
+    std::vector<HeadArgs> sp_seg;                 // mlp_shared convs (direct small-Cin kernel), one per UpConvLayer3
+    std::vector<std::vector<float>> sp_seg_w, sp_seg_b;
+    std::vector<float*> sp_seg_dw, sp_seg_db;
+    std::vector<float> sp_pred_w; float sp_pred_b[3] = {0.f, 0.f, 0.f}; float* d_sp_pred_w = nullptr;
+    SpadePredArgs sp_pred;
+    const float* sp_skip[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     // per-layer event timing (evr_model_profile_*)
     bool prof_on = false;
     std::string prof_filter;
@@ -119,13 +129,14 @@ struct evr_model {
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
                    if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
                    if (d_head_wfrag) (void)hipFree(d_head_wfrag);
+                   for (float* q : sp_seg_dw) (void)hipFree(q); for (float* q : sp_seg_db) (void)hipFree(q); if (d_sp_pred_w) (void)hipFree(d_sp_pred_w);
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
         allocs.clear();
         if (d_args) { (void)hipFree(d_args); d_args = nullptr; }
         steps.clear(); named[0].clear(); named[1].clear();
-        n_seq = 0; prev_rec = nullptr;
+        n_seq = 0; prev_rec = nullptr; sp_xpad = sp_xorg = sp_xorg_half = nullptr;
     }
 };
 
@@ -147,7 +158,7 @@ int find(const evr_model* m, const std::string& name, const HostTensor** out, bo
 struct Affine { std::vector<double> scale, shift; };   // y = conv*scale + shift (bias and BN folded)
 
 // bias (optional) then BatchNorm in eval mode (optional): y = ((conv + b) - mean)/sqrt(var+eps)*gamma + beta
-int make_affine(const evr_model* m, const std::string& bias_name, const std::string& bn_prefix, bool bn, int cout, Affine* out) {
+int make_affine(const evr_model* m, const std::string& bias_name, const std::string& bn_prefix, bool bn, int cout, Affine* out, bool bn_affine = true) {
     out->scale.assign(cout, 1.0); out->shift.assign(cout, 0.0);
     const HostTensor* b = nullptr;
     int rc = find(m, bias_name, &b, false);
@@ -155,15 +166,17 @@ int make_affine(const evr_model* m, const std::string& bias_name, const std::str
     if (b) { EVR_REQUIRE(b->numel() == cout, "'%s' has %lld elements, expected %d", bias_name.c_str(), (long long)b->numel(), cout);
              for (int i = 0; i < cout; ++i) out->shift[i] = b->data[i]; }
     if (bn) {
-        const HostTensor *g, *be, *mu, *var;
-        if ((rc = find(m, bn_prefix + ".weight", &g))) return rc;
-        if ((rc = find(m, bn_prefix + ".bias", &be))) return rc;
+        // bn_affine = false: BatchNorm2d(affine=False) / InstanceNorm2d(track_running_stats=True) in eval mode --
+        // running statistics only, gamma = 1, beta = 0
+        const HostTensor *g = nullptr, *be = nullptr, *mu, *var;
+        if (bn_affine && (rc = find(m, bn_prefix + ".weight", &g))) return rc;
+        if (bn_affine && (rc = find(m, bn_prefix + ".bias", &be))) return rc;
         if ((rc = find(m, bn_prefix + ".running_mean", &mu))) return rc;
         if ((rc = find(m, bn_prefix + ".running_var", &var))) return rc;
-        EVR_REQUIRE(g->numel() == cout && be->numel() == cout && mu->numel() == cout && var->numel() == cout, "BatchNorm '%s' size mismatch", bn_prefix.c_str());
+        EVR_REQUIRE((!g || g->numel() == cout) && (!be || be->numel() == cout) && mu->numel() == cout && var->numel() == cout, "BatchNorm '%s' size mismatch", bn_prefix.c_str());
         for (int i = 0; i < cout; ++i) {
-            const double s = (double)g->data[i] / std::sqrt((double)var->data[i] + 1e-5);
-            out->shift[i] = (out->shift[i] - (double)mu->data[i]) * s + (double)be->data[i];
+            const double s = (g ? (double)g->data[i] : 1.0) / std::sqrt((double)var->data[i] + 1e-5);
+            out->shift[i] = (out->shift[i] - (double)mu->data[i]) * s + (be ? (double)be->data[i] : 0.0);
             out->scale[i] = s;
         }
     } else {
@@ -527,6 +540,119 @@ int build_firenet(evr_model* m) {
     return EVR_OK;
 }
 
+// SPADE-E2VID = Unet6 (model/spade_e2v.py:113-179).  state_dict names are the module's own.
+//   PixelShuffle(2) of conv0's 4C channels: conv channel oc = c*4 + (i*2 + j) lands at output pixel (2y+i, 2x+j),
+//   channel c -- exactly a phase-major column-group GEMM (rows g*C + c, g = i*2 + j) whose epilogue writes the
+//   interleaved pixels, so the shuffle is free.  SPADE's parameter-free BatchNorm (eval mode) acts per shuffled
+//   channel c and folds into the four conv rows of c.
+int add_shuffle_conv(evr_model* m, const std::string& name, const std::string& wname, const std::string& bn_prefix, int cin, int C) {
+    Conv c; c.name = name;
+    const HostTensor* w; int rc;
+    if ((rc = find(m, wname, &w))) return rc;
+    Affine a1;
+    if ((rc = make_affine(m, "", bn_prefix, true, C, &a1, /*bn_affine=*/false))) return rc;
+    Affine af; af.scale.resize(4 * C); af.shift.resize(4 * C);
+    for (int oc = 0; oc < 4 * C; ++oc) { af.scale[oc] = a1.scale[oc / 4]; af.shift[oc] = a1.shift[oc / 4]; }
+    c.kc = pick_kc(cin, 0);
+    c.cin0 = cin; c.cin1 = 0; c.stride = 1; c.epi = EPI_BIAS; c.n_valid = C;
+    if ((rc = prep_conv2d(c, w, af, 4 * C, cin, 3, 1, [C](int oc) { return (oc % 4) * C + oc / 4; }, 4 * C))) return rc;
+    c.tp.ngroups = 4; c.tp.grp_cols = C;
+    for (int g = 0; g < 4; ++g) { c.tp.grp_ofy[g] = g >> 1; c.tp.grp_ofx[g] = g & 1; }
+    for (int t = 0; t < c.tp.ntaps; ++t) c.tp.tap_groups[t] = 0xF;
+    c.transposed = true;              // x2 output grid, as the transposed convolutions (plan_conv)
+    c.useful_taps = 9;                // every (tap, phase) block carries weights
+    return finish_conv(m, c);
+}
+
+// two Conv2d(cin -> C, k3, bias) stacked into one GEMM: rows [0, C) = first, [C, 2C) = second (SPADE's gamma | beta)
+int add_pair_conv(evr_model* m, const std::string& name, const std::string& p0, const std::string& p1, int cin, int C) {
+    int rc;
+    const HostTensor *w0, *w1;
+    if ((rc = find(m, p0 + ".weight", &w0))) return rc;
+    if ((rc = find(m, p1 + ".weight", &w1))) return rc;
+    Affine a0, a1;
+    if ((rc = make_affine(m, p0 + ".bias", "", false, C, &a0))) return rc;
+    if ((rc = make_affine(m, p1 + ".bias", "", false, C, &a1))) return rc;
+    Conv c; c.name = name; Conv tmp; tmp.name = name;
+    c.kc = pick_kc(cin, 0); c.cin0 = cin; c.stride = 1; c.epi = EPI_BIAS; c.n_valid = 2 * C;
+    if ((rc = prep_conv2d(c, w0, a0, C, cin, 3, 1, [](int co) { return co; }, 2 * C))) return rc;
+    if ((rc = prep_conv2d(tmp, w1, a1, C, cin, 3, 1, [C](int co) { return C + co; }, 2 * C))) return rc;
+    for (size_t i = (size_t)C * 9 * cin; i < (size_t)2 * C * 9 * cin; ++i) c.w[i] = tmp.w[i];
+    for (int i = C; i < 2 * C; ++i) c.b[i] = tmp.b[i];
+    return finish_conv(m, c);
+}
+
+int build_spade(evr_model* m) {
+    const evr_model_desc& d = m->desc;
+    EVR_REQUIRE(d.num_bins == 5 && d.base_num_channels == 32 && d.kernel_size == 5, "SPADE-E2VID is Unet6: 5 bins, 32 base channels, k5");
+    int rc;
+    // fc (head) -- prep_head_pred also wants a 1-channel pred; SPADE's 3-channel conv_img is prepared below
+    {
+        const HostTensor* w;
+        if ((rc = find(m, "fc.weight", &w))) return rc;
+        EVR_REQUIRE(w->ndim == 4 && w->shape[0] == 32 && w->shape[1] == 5 && w->shape[2] == 5 && w->shape[3] == 5, "fc weight shape mismatch");
+        Affine af;
+        if ((rc = make_affine(m, "fc.bias", "", false, 32, &af))) return rc;
+        m->head_w.assign((size_t)5 * 25 * 32, 0.f); m->head_b.assign(32, 0.f);
+        for (int co = 0; co < 32; ++co) {
+            m->head_b[co] = (float)af.shift[co];
+            for (int b = 0; b < 5; ++b) for (int t = 0; t < 25; ++t) m->head_w[((size_t)b * 25 + t) * 32 + co] = w->data[((size_t)co * 5 + b) * 25 + t];
+        }
+        if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
+        if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
+        if (use_split_bf16()) {
+            std::vector<unsigned> wf;
+            head_pack_wfrag(m->head_w.data(), 5, wf);
+            EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
+            EVR_HIP(hipMemcpy(m->d_head_wfrag, wf.data(), wf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
+    }
+    const int cin[3] = {32, 64, 128}, cout[3] = {64, 128, 256}, stride[3] = {1, 2, 2};
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "rec" + std::to_string(i);
+        if ((rc = add_conv(m, p + ".conv", p + ".conv0.weight", "", p + ".bn", true, cin[i], cout[i], 5, stride[i], EPI_BIAS_RELU))) return rc;
+        if ((rc = add_lstm(m, p + ".rec", p + ".recurrent_block", cout[i]))) return rc;
+    }
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = "res" + std::to_string(i);
+        if ((rc = add_conv(m, p + ".conv1", p + ".conv1.weight", "", p + ".bn1", true, 256, 256, 3, 1, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, p + ".conv2", p + ".conv2.weight", "", p + ".bn2", true, 256, 256, 3, 1, EPI_RESIDUAL_RELU))) return rc;
+    }
+    const int uc_in[2] = {256, 128}, uc_out[2] = {128, 64};
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = "up" + std::to_string(i);
+        if ((rc = add_shuffle_conv(m, p + ".conv", p + ".conv0.weight", p + ".norm.param_free_norm", uc_in[i], uc_out[i]))) return rc;
+        // mlp_shared: Conv2d(3 -> 64, k3) + ReLU on the segmentation map (direct small-Cin kernel, [B*k*k][cout] weights)
+        const HostTensor *w, *b;
+        if ((rc = find(m, p + ".norm.mlp_shared.0.weight", &w))) return rc;
+        if ((rc = find(m, p + ".norm.mlp_shared.0.bias", &b))) return rc;
+        EVR_REQUIRE(w->ndim == 4 && w->shape[0] == 64 && w->shape[1] == 3 && w->shape[2] == 3 && b->numel() == 64, "'%s': mlp_shared shape mismatch", p.c_str());
+        std::vector<float> sw((size_t)3 * 9 * 64), sb(b->data, b->data + 64);
+        for (int co = 0; co < 64; ++co) for (int ci = 0; ci < 3; ++ci) for (int t = 0; t < 9; ++t) sw[((size_t)ci * 9 + t) * 64 + co] = w->data[((size_t)co * 3 + ci) * 9 + t];
+        float *dw, *db;
+        if ((rc = upload(sw, &dw))) return rc;
+        if ((rc = upload(sb, &db))) return rc;
+        m->sp_seg_dw.push_back(dw); m->sp_seg_db.push_back(db);
+        if ((rc = add_pair_conv(m, p + ".gb", p + ".norm.mlp_gamma", p + ".norm.mlp_beta", 64, uc_out[i]))) return rc;
+    }
+    if ((rc = add_conv(m, "up2.conv", "up2.conv0.weight", "", "up2.bn", true, 64, 32, 5, 1, EPI_BIAS_RELU))) return rc;
+    if ((rc = add_lstm(m, "up2.rec", "up2.recurrent_block", 32))) return rc;
+    {   // conv_img (1x1, 32 -> 3, bias) + bn_img folded
+        const HostTensor* w;
+        if ((rc = find(m, "conv_img.weight", &w))) return rc;
+        EVR_REQUIRE(w->numel() == 96, "conv_img weight has %lld elements, expected 96", (long long)w->numel());
+        Affine ap;
+        if ((rc = make_affine(m, "conv_img.bias", "bn_img", true, 3, &ap))) return rc;
+        m->sp_pred_w.assign(96, 0.f);
+        for (int k = 0; k < 3; ++k) {
+            m->sp_pred_b[k] = (float)ap.shift[k];
+            for (int ci = 0; ci < 32; ++ci) m->sp_pred_w[k * 32 + ci] = (float)((double)w->data[k * 32 + ci] * ap.scale[k]);
+        }
+        if ((rc = upload(m->sp_pred_w, &m->d_sp_pred_w))) return rc;
+    }
+    return EVR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shape-dependent planning
 int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream, bool packed = false) {
@@ -815,6 +941,143 @@ int plan_firenet(evr_model* m, hipStream_t stream) {
     return EVR_OK;
 }
 
+int plan_spade(evr_model* m, hipStream_t stream) {
+    const int n = m->n_seq, hp = m->hp, wp = m->wp;
+    const bool P = m->packed;
+    int rc;
+    EVR_REQUIRE(hp % 4 == 0 && wp % 4 == 0, "SPADE-E2VID: padded size %dx%d not a multiple of 4", wp, hp);
+    DevTensor xpad, xorg, xorgh, head;
+    if ((rc = alloc(m, &xpad, n, m->desc.num_bins, hp, wp, stream))) return rc;          // planar [n,B,hp,wp]
+    if ((rc = alloc(m, &xorg, n, 3, hp, wp, stream))) return rc;                          // planar [n,3,hp,wp]
+    if ((rc = alloc(m, &xorgh, n, 3, hp / 2, wp / 2, stream))) return rc;
+    if ((rc = alloc(m, &head, n, hp, wp, 32, stream, P))) return rc;
+    m->sp_xpad = xpad.p; m->sp_xorg = xorg.p; m->sp_xorg_half = xorgh.p;
+    name2(m, "head", head, head);
+    m->head.out = head.p; m->head.out_packed = P;
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
+
+    const float* x[2] = {head.p, head.p};
+    int h = hp, w = wp;
+    DevTensor hs[4][2];      // hidden states (new-after-parity-p at index [i][p])
+    auto add_rec = [&](const std::string& nm, int idx, int cin_unused, int cout, int stride) -> int {
+        (void)cin_unused;
+        DevTensor cv;
+        int r;
+        if ((r = alloc(m, &cv, n, h / stride, w / stride, cout, stream, P))) return r;
+        ConvIO io{};
+        io.in_packed = P; io.out_packed = P;
+        io.in0[0] = x[0]; io.in0[1] = x[1]; io.in1[0] = io.in1[1] = nullptr; io.out[0] = io.out[1] = cv.p;
+        const int ci = conv_index(m, nm + ".conv");
+        plan_conv(m, ci, n, h, w, io, cout); push_conv(m, ci);
+        h /= stride; w /= stride;
+        DevTensor hb[2], cb;
+        if ((r = alloc(m, &hb[0], n, h, w, cout, stream, P))) return r;
+        if ((r = alloc(m, &hb[1], n, h, w, cout, stream, P))) return r;
+        if ((r = alloc(m, &cb, n, h, w, cout, stream))) return r;
+        ConvIO q{};
+        q.in_packed = P; q.out_packed = P;
+        for (int p = 0; p < 2; ++p) { q.in0[p] = cv.p; q.in1[p] = hb[p].p; q.out[p] = hb[1 - p].p; q.state[p] = cb.p; }
+        const int ri = conv_index(m, nm + ".rec");
+        plan_conv(m, ri, n, h, w, q, cout); push_conv(m, ri);
+        x[0] = hb[1].p; x[1] = hb[0].p;
+        hs[idx][0] = hb[1]; hs[idx][1] = hb[0];
+        name2(m, "h" + std::to_string(idx), hb[1], hb[0]);
+        name2(m, "c" + std::to_string(idx), cb, cb);
+        return EVR_OK;
+    };
+    if ((rc = add_rec("rec0", 0, 32, 64, 1))) return rc;
+    if ((rc = add_rec("rec1", 1, 64, 128, 2))) return rc;
+    if ((rc = add_rec("rec2", 2, 128, 256, 2))) return rc;
+    int last = -1;
+    for (int i = 0; i < 2; ++i) {
+        const std::string rn = "res" + std::to_string(i);
+        DevTensor t, o;
+        if ((rc = alloc(m, &t, n, h, w, 256, stream, P))) return rc;
+        if ((rc = alloc(m, &o, n, h, w, 256, stream, P))) return rc;
+        ConvIO a{}, b{};
+        a.in_packed = b.in_packed = P; a.out_packed = b.out_packed = P; b.res_packed = P;
+        for (int p = 0; p < 2; ++p) { a.in0[p] = x[p]; a.out[p] = t.p; b.in0[p] = t.p; b.out[p] = o.p; b.residual[p] = x[p]; }
+        const int c1 = conv_index(m, rn + ".conv1"), c2 = conv_index(m, rn + ".conv2");
+        plan_conv(m, c1, n, h, w, a, 256); push_conv(m, c1);
+        plan_conv(m, c2, n, h, w, b, 256); push_conv(m, c2);
+        x[0] = x[1] = o.p;
+        name2(m, rn, o, o);
+        last = c2;
+    }
+    // up0(x + x2, x_org): the skip sum rides on res1.conv2's epilogue (model_util-style fusion)
+    for (int p = 0; p < 2; ++p) { m->convs[last].args[p].post_add = hs[2][p].p; m->convs[last].args[p].padd_packed = P; }
+    m->sp_seg.clear();
+    for (int i = 0; i < 2; ++i) {
+        const std::string un = "up" + std::to_string(i);
+        const int C = (i == 0) ? 128 : 64;
+        DevTensor xn, actv, gb, u;
+        if ((rc = alloc(m, &xn, n, 2 * h, 2 * w, C, stream))) return rc;                   // PLAIN: read by spade_apply
+        ConvIO a{};
+        a.in_packed = P; a.out_packed = false;
+        for (int p = 0; p < 2; ++p) { a.in0[p] = x[p]; a.out[p] = xn.p; }
+        const int ci = conv_index(m, un + ".conv");
+        plan_conv(m, ci, n, h, w, a, C); push_conv(m, ci);
+        h *= 2; w *= 2;
+        const float* seg = m->sp_xorg;
+        if (h != hp) {
+            EVR_REQUIRE(2 * h == hp && 2 * w == wp, "SPADE-E2VID: unexpected decoder resolution");
+            Step s; s.kind = ST_SP_NEAREST; m->steps.push_back(s);
+            seg = m->sp_xorg_half;
+        }
+        if ((rc = alloc(m, &actv, n, h, w, 64, stream, P))) return rc;
+        HeadArgs ha; memset(&ha, 0, sizeof(ha));
+        ha.vox = seg; ha.n = n; ha.B = 3; ha.H = h; ha.W = w; ha.hp = h; ha.wp = w; ha.k = 3; ha.cout = 64;
+        ha.wgt = m->sp_seg_dw[i]; ha.bias = m->sp_seg_db[i]; ha.out = actv.p; ha.relu = 1; ha.out_packed = P;
+        m->sp_seg.push_back(ha);
+        { Step s; s.kind = ST_SP_SEG; s.conv = i; m->steps.push_back(s); }
+        if ((rc = alloc(m, &gb, n, h, w, 2 * C, stream))) return rc;
+        ConvIO g{};
+        g.in_packed = P; g.out_packed = false;
+        for (int p = 0; p < 2; ++p) { g.in0[p] = actv.p; g.out[p] = gb.p; }
+        const int gi = conv_index(m, un + ".gb");
+        plan_conv(m, gi, n, h, w, g, 2 * C); push_conv(m, gi);
+        if ((rc = alloc(m, &u, n, h, w, C, stream, P))) return rc;
+        { Step s; s.kind = ST_SP_APPLY; s.a[0] = s.a[1] = xn.p; s.b[0] = s.b[1] = gb.p; s.out = u.p; s.h = h; s.w = w; s.c = C;
+          s.out_packed = P; s.a_packed = P;          // a_packed: format of the fused skip operand
+          s.conv = i;                                // skip = hidden state of rec(1 - i)
+          m->steps.push_back(s); }
+        m->flops += 2.0 * n * h * w * 9.0 * 3 * 64;
+        x[0] = x[1] = u.p;
+        name2(m, un, u, u);
+    }
+    // skip operands of the two spade_apply steps (parity-dependent hidden states): kept in the model, looked up by step
+    m->sp_skip[0][0] = hs[1][0].p; m->sp_skip[0][1] = hs[1][1].p;     // up0 output + x1
+    m->sp_skip[1][0] = hs[0][0].p; m->sp_skip[1][1] = hs[0][1].p;     // up1 output + x0
+    {   // up2: RecurrentConvLayer(64 -> 32, stride 1)
+        DevTensor cv;
+        if ((rc = alloc(m, &cv, n, h, w, 32, stream, P))) return rc;
+        ConvIO io{};
+        io.in_packed = P; io.out_packed = P;
+        io.in0[0] = x[0]; io.in0[1] = x[1]; io.in1[0] = io.in1[1] = nullptr; io.out[0] = io.out[1] = cv.p;
+        const int ci = conv_index(m, "up2.conv");
+        plan_conv(m, ci, n, h, w, io, 32); push_conv(m, ci);
+        DevTensor hb[2], cb;
+        if ((rc = alloc(m, &hb[0], n, h, w, 32, stream, P))) return rc;
+        if ((rc = alloc(m, &hb[1], n, h, w, 32, stream, P))) return rc;
+        if ((rc = alloc(m, &cb, n, h, w, 32, stream))) return rc;
+        ConvIO q{};
+        q.in_packed = P; q.out_packed = P;
+        for (int p = 0; p < 2; ++p) { q.in0[p] = cv.p; q.in1[p] = hb[p].p; q.out[p] = hb[1 - p].p; q.state[p] = cb.p; }
+        const int ri = conv_index(m, "up2.rec");
+        plan_conv(m, ri, n, h, w, q, 32); push_conv(m, ri);
+        name2(m, "h3", hb[1], hb[0]); name2(m, "c3", cb, cb);
+        m->pred_x[0] = hb[1].p; m->pred_x[1] = hb[0].p;
+    }
+    memset(&m->sp_pred, 0, sizeof(m->sp_pred));
+    m->sp_pred.head = head.p; m->sp_pred.x_packed = P; m->sp_pred.head_packed = P;
+    m->sp_pred.n = n; m->sp_pred.hp = hp; m->sp_pred.wp = wp; m->sp_pred.wgt = m->d_sp_pred_w;
+    for (int k = 0; k < 3; ++k) m->sp_pred.bias[k] = m->sp_pred_b[k];
+    m->sp_pred.prev = m->sp_xorg; m->sp_pred.H = m->H; m->sp_pred.W = m->W; m->sp_pred.iy0 = m->iy0; m->sp_pred.ix0 = m->ix0;
+    m->pred_c = 32; m->pred_fused_conv = -1;
+    m->flops += 2.0 * n * hp * wp * 32.0 * 2;     // conv_img has 3 outputs (the generic account adds one)
+    return EVR_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -832,6 +1095,7 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
     int rc;
     if (desc->arch == EVR_ARCH_UNET_RECURRENT) rc = build_unet(m);
     else if (desc->arch == EVR_ARCH_FIRENET_LEGACY || desc->arch == EVR_ARCH_FIRENET) rc = build_firenet(m);
+    else if (desc->arch == EVR_ARCH_SPADE_E2VID) rc = build_spade(m);
     else { set_error("evr_model_create: unknown arch %d", desc->arch); rc = EVR_ERR_UNSUPPORTED; }
     m->sd.clear();   // host pointers are only valid during this call
     if (rc) { delete m; return rc; }
@@ -857,7 +1121,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
     m->packed = false;
-    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT) {
+    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID) {
         m->packed = true;
         for (const auto& c : m->convs) if (!c.x3) m->packed = false;
     }
@@ -873,7 +1137,11 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->head.n = n_seq; m->head.B = m->desc.num_bins; m->head.H = H; m->head.W = W; m->head.hp = m->hp; m->head.wp = m->wp;
     m->head.pad_top = m->pad_top; m->head.pad_left = m->pad_left; m->head.k = m->desc.kernel_size;
     m->head.cout = m->desc.base_num_channels; m->head.wgt = m->d_head_w; m->head.bias = m->d_head_b; m->head.relu = 1;
-    int rc = (m->desc.arch == EVR_ARCH_UNET_RECURRENT) ? plan_unet(m, stream) : plan_firenet(m, stream);
+    const bool spade = m->desc.arch == EVR_ARCH_SPADE_E2VID;
+    if (spade) {      // the head convolution reads the explicit padded copy (spade.hip): no padding of its own
+        m->head.H = m->hp; m->head.W = m->wp; m->head.pad_top = 0; m->head.pad_left = 0;
+    }
+    int rc = (m->desc.arch == EVR_ARCH_UNET_RECURRENT) ? plan_unet(m, stream) : spade ? plan_spade(m, stream) : plan_firenet(m, stream);
     if (rc) { m->release_shape(); return rc; }
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->pred_c;
@@ -895,6 +1163,15 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
     int rc;
     HeadArgs ha = m->head;
     ha.vox = vox; ha.stats = (flags & 1u) ? stats : nullptr;
+    const bool spade = m->desc.arch == EVR_ARCH_SPADE_E2VID;
+    if (spade) {
+        // Unet6.forward (spade_e2v.py:139-151): cropper.pad made explicit; on a sequence's first frame the first three
+        // channels of the padded input are min/max-normalised IN PLACE (the head conv sees them) and become x_org
+        EVR_REQUIRE(!(flags & 1u), "SPADE-E2VID: event-tensor normalization is off in its method config (not fused here)");
+        if ((rc = launch_spade_pad(vox, m->sp_xpad, m->n_seq, m->desc.num_bins, m->H, m->W, m->hp, m->wp, m->pad_top, m->pad_left, stream))) return rc;
+        if (m->frame == 0 && (rc = launch_spade_first(m->sp_xpad, m->sp_xorg, m->n_seq, m->desc.num_bins, m->hp, m->wp, stream))) return rc;
+        ha.vox = m->sp_xpad; ha.stats = nullptr;
+    }
     if ((rc = launch_head_conv(ha, stream))) return rc;
     for (const Step& s : m->steps) {
         switch (s.kind) {
@@ -928,6 +1205,15 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
             case ST_DYN:
                 if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
                 break;
+            case ST_SP_NEAREST:
+                if ((rc = launch_nearest_half(m->sp_xorg, m->sp_xorg_half, m->n_seq * 3, m->hp, m->wp, stream))) return rc;
+                break;
+            case ST_SP_SEG:
+                if ((rc = launch_head_conv(m->sp_seg[s.conv], stream))) return rc;
+                break;
+            case ST_SP_APPLY:
+                if ((rc = launch_spade_apply(s.a[p], s.b[p], m->sp_skip[s.conv][p], s.out, (int64_t)m->n_seq * s.h * s.w, s.c, s.a_packed, s.out_packed, stream))) return rc;
+                break;
             default: break;
         }
     }
@@ -936,7 +1222,11 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
     pa.wgt = m->d_pred_w; pa.bias = m->pred_b; pa.sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
     pa.H = m->H; pa.W = m->W; pa.iy0 = m->iy0; pa.ix0 = m->ix0; pa.img = img;
     pa.x_packed = m->pred_x_packed; pa.skip_packed = m->pred_skip_packed;
-    if (m->pred_fused_conv < 0 && (rc = launch_pred(pa, stream))) return rc;
+    if (spade) {
+        SpadePredArgs sa = m->sp_pred;
+        sa.x = m->pred_x[p]; sa.img = img;
+        if ((rc = launch_spade_pred(sa, stream))) return rc;
+    } else if (m->pred_fused_conv < 0 && (rc = launch_pred(pa, stream))) return rc;
     m->frame++;
     return EVR_OK;
 }

@@ -105,9 +105,11 @@ def _load_checkpoint(path):
 
 def get_model_from_checkpoint_path(model_name, checkpoint_path):
     checkpoint = _load_checkpoint(checkpoint_path)
-    if model_name in ("SPADE-E2VID", "ET-Net"):
-        raise EvrError(f"{model_name} is not part of the MI355X hot path (SURVEY 2.1: out of scope)")
-    if model_name == "SSL-E2VID":      # eval.py:134-139
+    if model_name == "ET-Net":
+        raise EvrError("ET-Net (model/eitr, transformer encoder/decoder) is not built (SURVEY 8f-4)")
+    if model_name == "SPADE-E2VID":    # eval.py:130-133
+        model, state_dict = model_arch.SpadeE2vid(), checkpoint
+    elif model_name == "SSL-E2VID":    # eval.py:134-139
         kw = {"base_num_channels": 32, "kernel_size": 5, "num_bins": 5, "num_encoders": 3,
               "recurrent_block_type": "convlstm", "num_residual_blocks": 2, "skip_type": "sum", "norm": None,
               "use_upsample_conv": True}

@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _lib
 
-ARCH_UNET, ARCH_FIRENET_LEGACY, ARCH_FIRENET = 0, 1, 2
+ARCH_UNET, ARCH_FIRENET_LEGACY, ARCH_FIRENET, ARCH_SPADE_E2VID = 0, 1, 2, 3
 
 
 def _np_state_dict(state_dict):
@@ -230,6 +230,31 @@ class FireNet(_HipModel):
         d.base_num_channels = self.base_num_channels
         d.num_residual_blocks = 2
         d.kernel_size = self.kernel_size
+        d.pad_multiple_log2 = self.num_encoders
+        return d
+
+
+class SpadeE2vid(_HipModel):
+    """model/spade_e2v.py:113-179 (Unet6, exported as SpadeE2vid in model/__init__.py:4), the 'SPADE-E2VID' method:
+    full-resolution ConvLSTM encoder, pixel-shuffle decoders with SPADE normalisation conditioned on the previous
+    3-channel reconstruction (first frame: the min/max-normalised first three input channels, rewritten in place),
+    image = mean of the three sigmoid outputs.  eval.py:130-133 sets num_encoders = 3 for the cropper."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_bins = 5
+        self.num_encoders = 3
+
+    def _desc(self):
+        d = _lib.ModelDesc()
+        d.arch = ARCH_SPADE_E2VID
+        d.num_bins = 5
+        d.base_num_channels = 32
+        d.num_encoders = 3
+        d.num_residual_blocks = 2
+        d.kernel_size = 5
+        d.norm = 1
+        d.final_activation = 1
         d.pad_multiple_log2 = self.num_encoders
         return d
 

@@ -106,6 +106,36 @@ def firenet_legacy_schema(num_bins=5, base_num_channels=16, kernel_size=3, prefi
     return s
 
 
+def spade_e2vid_schema(**_):
+    """Unet6.state_dict() (model/spade_e2v.py:113-137), the 'SPADE-E2VID' method."""
+    s = OrderedDict()
+    _conv(s, 'fc', 32, 5, 5)
+
+    def rec(name, cin, cout):
+        _conv(s, name + '.conv0', cout, cin, 5, bias=False)
+        _bn(s, name + '.bn', cout)
+        _conv(s, name + '.recurrent_block.Gates', 4 * cout, 2 * cout, 3)
+
+    def res(name):
+        _conv(s, name + '.conv1', 256, 256, 3, bias=False); _conv(s, name + '.conv2', 256, 256, 3, bias=False)
+        _bn(s, name + '.bn1', 256); _bn(s, name + '.bn2', 256)
+
+    def up(name, cin, cout):
+        _conv(s, name + '.conv0', 4 * cout, cin, 3, bias=False)
+        p = name + '.norm.param_free_norm'               # BatchNorm2d(affine=False): running statistics only
+        s[p + '.running_mean'] = (cout,); s[p + '.running_var'] = (cout,); s[p + '.num_batches_tracked'] = ()
+        _conv(s, name + '.norm.mlp_shared.0', 64, 3, 3)
+        _conv(s, name + '.norm.mlp_gamma', cout, 64, 3); _conv(s, name + '.norm.mlp_beta', cout, 64, 3)
+
+    rec('rec0', 32, 64); rec('rec1', 64, 128); rec('rec2', 128, 256)
+    res('res0'); res('res1')
+    up('up0', 256, 128); up('up1', 128, 64)
+    rec('up2', 64, 32)
+    _conv(s, 'conv_img', 3, 32, 1)
+    _bn(s, 'bn_img', 3)
+    return s
+
+
 def firenet_schema(num_bins=5, base_num_channels=16, kernel_size=3, **_):
     """FireNet.state_dict() (model/model.py:154-165), the 'FireNet+' method."""
     s = OrderedDict(); c = base_num_channels

@@ -104,9 +104,11 @@ int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W, const dou
  *                            bilinear-upsample decoders, ConvLSTM or ConvGRU, optional sigmoid)
  *   EVR_ARCH_FIRENET_LEGACY  model/legacy.py:32-111,155-187 (the "FireNet" method)
  *   EVR_ARCH_FIRENET         model/model.py:147-190 (the "FireNet+" method)
+ *   EVR_ARCH_SPADE_E2VID     model/spade_e2v.py:113-179 (Unet6: full-resolution ConvLSTMs, pixel-shuffle decoders
+ *                            with SPADE normalisation conditioned on the previous reconstruction, 3-channel head)
  * Weights are handed over as the reference's own state_dict: names + host fp32 arrays.
  */
-enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2 };
+enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2, EVR_ARCH_SPADE_E2VID = 3 };
 enum evr_norm { EVR_NORM_NONE = 0, EVR_NORM_BN = 1 };
 enum evr_recurrent { EVR_REC_CONVLSTM = 0, EVR_REC_CONVGRU = 1 };
 enum evr_activation { EVR_ACT_NONE = 0, EVR_ACT_SIGMOID = 1 };

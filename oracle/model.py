@@ -211,3 +211,70 @@ class FireNetOracle:
         x = conv_gru(sd, 'G2', x, self.states[1]); self.states[1] = x
         x = residual_block(sd, 'R2', x)
         return conv_layer(sd, 'pred', x, 1, 0, None, None)
+
+
+class SpadeE2vidOracle:
+    """Unet6 (model/spade_e2v.py:113-179), the 'SPADE-E2VID' method: fc head; three RecurrentConvLayers (conv k5 no
+    bias -> BN -> relu -> ConvLSTM; strides 1, 2, 2); two BN residual blocks; two UpConvLayer3 (conv3 -> PixelShuffle(2)
+    -> SPADE(BatchNorm2d(affine=False); segmap -> conv3+relu -> gamma, beta) -> relu) fed x + skip; a fourth
+    RecurrentConvLayer; conv_img 1x1 -> bn_img -> sigmoid (3 channels = prev_recs); image = their mean.
+    First frame: x[:, :3] is min/max-normalised IN PLACE (the head sees it) and used as the segmentation map."""
+
+    def __init__(self, sd):
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        self.num_encoders = 3
+        self.reset_states()
+
+    def reset_states(self):
+        self.states = None
+        self.prev_recs = None
+
+    def _rec(self, name, x, state, stride):
+        sd = self.sd
+        x = F.conv2d(x, sd[name + '.conv0.weight'], None, stride, 2)
+        x = torch.relu(_bn(sd, name + '.bn', x))
+        st = conv_lstm(sd, name + '.recurrent_block', x, state)
+        return st[0], st
+
+    def _res(self, name, x):
+        sd = self.sd
+        out = torch.relu(_bn(sd, name + '.bn1', F.conv2d(x, sd[name + '.conv1.weight'], None, padding=1)))
+        out = _bn(sd, name + '.bn2', F.conv2d(out, sd[name + '.conv2.weight'], None, padding=1))
+        return torch.relu(out + x)
+
+    def _up(self, name, x, seg):
+        sd = self.sd
+        x = F.pixel_shuffle(F.conv2d(x, sd[name + '.conv0.weight'], None, padding=1), 2)
+        p = name + '.norm'
+        normalized = F.batch_norm(x, sd[p + '.param_free_norm.running_mean'], sd[p + '.param_free_norm.running_var'],
+                                  None, None, False, 0.1, 1e-5)
+        seg = F.interpolate(seg, size=x.shape[-2:], mode='nearest')
+        actv = torch.relu(F.conv2d(seg, sd[p + '.mlp_shared.0.weight'], sd[p + '.mlp_shared.0.bias'], padding=1))
+        gamma = F.conv2d(actv, sd[p + '.mlp_gamma.weight'], sd[p + '.mlp_gamma.bias'], padding=1)
+        beta = F.conv2d(actv, sd[p + '.mlp_beta.weight'], sd[p + '.mlp_beta.bias'], padding=1)
+        return torch.relu(normalized * (1 + gamma) + beta)
+
+    def __call__(self, x):
+        sd = self.sd
+        x = x.clone()
+        prev = [None] * 4 if self.states is None else self.states
+        if self.prev_recs is None:
+            x_org = x[:, :3]
+            x_org -= x_org.min()
+            if x_org.max() > 0:
+                x_org /= x_org.max()
+        else:
+            x_org = self.prev_recs
+        head = torch.relu(F.conv2d(x, sd['fc.weight'], sd['fc.bias'], padding=2))
+        x0, s0 = self._rec('rec0', head, prev[0], 1)
+        x1, s1 = self._rec('rec1', x0, prev[1], 2)
+        x2, s2 = self._rec('rec2', x1, prev[2], 2)
+        y = self._res('res1', self._res('res0', x2))
+        y = self._up('up0', y + x2, x_org)
+        y = self._up('up1', y + x1, x_org)
+        y, s3 = self._rec('up2', y + x0, prev[3], 1)
+        y = F.conv2d(torch.relu(y + head), sd['conv_img.weight'], sd['conv_img.bias'])
+        y = torch.sigmoid(_bn(sd, 'bn_img', y))
+        self.states = [s0, s1, s2, s3]
+        self.prev_recs = y
+        return y.mean(1, keepdim=True)

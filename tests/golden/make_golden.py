@@ -407,8 +407,27 @@ def make_color():
              weights_sha=np.array(weights.state_dict_digest(sd)), **out)
 
 
+def make_spade():
+    """SPADE-E2VID (reference class Unet6, exported as SpadeE2vid) with deterministic synthetic weights: 4 frames of
+    one 64x96 sequence -> images, final hidden states, and the 3-channel prev_recs of the last frame."""
+    sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=13)
+    net = ref_model.SpadeE2vid()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.eval()
+    F, H, W = 4, 64, 96
+    vox = synth.sparse_voxels(131, F, 5, H, W, density=0.15)
+    imgs = []
+    with torch.no_grad():
+        for f in range(F):
+            imgs.append(net(torch.from_numpy(vox[f:f + 1].copy()))['image'].numpy())
+    out = {f'h{i}_sub': net.states[i][0].numpy()[:, ::4] for i in range(4)}
+    out.update({f'c{i}_sub': net.states[i][1].numpy()[:, ::4] for i in range(4)})
+    save_npz('spade_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([131, F, 5, H, W]), seed=np.array(13),
+             weights_sha=np.array(weights.state_dict_digest(sd)), images=np.concatenate(imgs), prev_recs=net.prev_recs.numpy(), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade}[w]()

@@ -176,3 +176,28 @@ def test_colornet_odd_sides_raise_like_the_reference():
     for H, W in [(97, 128), (96, 129)]:
         with pytest.raises(L.EvrError, match='even'):
             net(torch.zeros((1, 5, H, W), device='cuda'))
+
+
+def test_spade_e2vid_346x260_vs_oracle():
+    """SPADE-E2VID at 346x260 (pads to 352x264): two different sequences advanced together, three frames, the cropper's
+    explicit padding included in the first frame's min/max rewrite."""
+    from evreal_amd import model, weights
+    from evreal_amd.voxel import Voxelizer
+    from oracle import model as omod, prepost as op, voxel as ov
+    sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=26)
+    m = model.SpadeE2vid(); m.load_state_dict(sd)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if np.asarray(v).dtype.kind == 'f'}
+    oracles = [omod.SpadeE2vidOracle(tsd), omod.SpadeE2vidOracle(tsd)]
+    H, W = 260, 346
+    crop = op.CropParams(W, H, 3)
+    vz = Voxelizer()
+    m.reset_states()
+    for f in range(3):
+        ev, cat, offs = _windows([90000 + 1000 * f + s for s in range(2)], 15000, W, H)
+        g = vz.voxelize(_d(cat[0]), _d(cat[1]), _d(cat[2]), _d(cat[3]), _d(offs), 5, (H, W))
+        img = m(g)['image'].cpu().numpy()
+        for s in range(2):
+            v = ov.events_to_voxel(*ev[s], 5, (H, W))[None]
+            with torch.no_grad():
+                want = crop.crop(oracles[s](torch.from_numpy(crop.pad(v))).numpy())
+            assert float(np.abs(img[s:s + 1] - want).max()) < IMG_ATOL, (f, s)

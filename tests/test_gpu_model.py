@@ -225,3 +225,48 @@ def test_firenet_real_weights_40_frames_and_reset():
     m.reset_states()
     again = m(torch.from_numpy(vox[0:1]).cuda())['image'].cpu().numpy()
     assert np.array_equal(again, first)          # deterministic kernels + zeroed state
+
+
+def test_spade_e2vid_golden():
+    """SPADE-E2VID (Unet6, model/spade_e2v.py) against the reference class: pixel-shuffle decoders (written through the
+    phase-major column groups), SPADE normalisation, the first-frame in-place rewrite of x[:, :3], 3-channel head."""
+    from evreal_amd import model, synth, weights
+    z = load_npz('spade_seq.npz')
+    sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=int(z['seed']))
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    m = model.SpadeE2vid(); m.load_state_dict(sd)
+    assert m.num_encoders == 3
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W, density=0.15)
+    assert sha(vox) == str(z['voxel_sha'])
+    for n_seq in (1, 2):                     # every batch slot is its own sequence (own min/max on the first frame)
+        m.reset_states()
+        for f in range(F):
+            x = torch.from_numpy(vox[f:f + 1]).cuda().repeat(n_seq, 1, 1, 1)
+            img = m(x)['image'].cpu().numpy()
+            for s in range(n_seq):
+                np.testing.assert_allclose(img[s:s + 1], z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f} seq {s}')
+        for i in range(4):
+            want = z[f'h{i}_sub']
+            h = m.read_tensor(f'h{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
+            c = m.read_tensor(f'c{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
+            np.testing.assert_allclose(h[:1, ::4], want, rtol=1e-4, atol=2e-5, err_msg=f'h{i}')
+            np.testing.assert_allclose(c[:1, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=2e-5, err_msg=f'c{i}')
+    m.reset_states()                          # reset -> the first-frame path again, bit for bit
+    a = m(torch.from_numpy(vox[0:1]).cuda())['image'].cpu().numpy()
+    m.reset_states()
+    b = m(torch.from_numpy(vox[0:1]).cuda())['image'].cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_spade_e2vid_through_the_method_registry(tmp_path):
+    """eval.py:130-133: the 'SPADE-E2VID' checkpoint IS the state_dict; num_encoders = 3 for the cropper."""
+    from evreal_amd import eval as ev, model, weights
+    sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=3)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, tmp_path / 'spade.pth')
+    m = ev.get_model_from_checkpoint_path('SPADE-E2VID', str(tmp_path / 'spade.pth'))
+    assert isinstance(m, model.SpadeE2vid) and m.num_encoders == 3
+    img = m(torch.zeros((1, 5, 60, 90), device='cuda'))['image']            # pads to 64x96, crops back
+    assert img.shape == (1, 1, 60, 90) and bool(torch.isfinite(img).all())
+    with pytest.raises(Exception, match='ET-Net'):
+        ev.get_model_from_checkpoint_path('ET-Net', str(tmp_path / 'spade.pth'))
