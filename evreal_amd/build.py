@@ -71,7 +71,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, f + '.o')
         objs.append(obj)
         if force or _newer(src, obj, headers):
-            cmd = [HIPCC, '-c'] + COMMON + PER_FILE.get(f, []) + ['-x', 'hip', src, '-o', obj]
+            cmd = [HIPCC, '-c'] + COMMON + PER_FILE.get(f, []) + os.environ.get('EVR_EXTRA_HIPCC_FLAGS', '').split() + ['-x', 'hip', src, '-o', obj]
             check = f in NO_SCRATCH
             if check:
                 cmd.append('-Rpass-analysis=kernel-resource-usage')

@@ -188,6 +188,9 @@ int launch_spade_first(float* xpad, float* xorg, int n, int B, int hp, int wp, h
 int launch_nearest_half(const float* in, float* out, int planes, int h, int w, hipStream_t stream);
 int launch_spade_apply(const float* xn, const float* gb, const float* skip, float* out, int64_t pix, int C, int skip_packed, int out_packed, hipStream_t stream);
 int launch_spade_pred(const SpadePredArgs& a, hipStream_t stream);
+// InstanceNorm2d of the norm='IN' ResidualBlocks (spade.hip): out = relu(IN(x) [+ res]) [+ skip]
+int launch_instnorm(const float* x, const float* res, const float* skip, float* out, int n, int hw, int c, int res_packed,
+                    int skip_packed, int out_packed, hipStream_t stream);
 // NHWC -> NCHW copy (debug/parity reads)
 int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream);
 

@@ -65,7 +65,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
 };
 
 enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN,
-                ST_SP_NEAREST, ST_SP_SEG, ST_SP_APPLY };   // SPADE-E2VID (spade.hip)
+                ST_SP_NEAREST, ST_SP_SEG, ST_SP_APPLY,     // SPADE-E2VID (spade.hip)
+                ST_INORM };                                // InstanceNorm2d of the norm='IN' residual blocks
 struct Step {
     StepKind kind;
     int conv = -1;
@@ -351,12 +352,12 @@ int pick_kc(int c0, int c1) { return (c0 % 32 == 0 && (c1 == 0 || c1 % 32 == 0))
 // plain conv: prefix.{weight,bias}; bn under bn_prefix.  The reference's ConvLayer/ResidualBlock drop the conv bias
 // when they use BN (submodules.py:13,155); keep_bias_with_bn covers nn.Sequential(Conv2d(bias), BatchNorm2d).
 int add_conv(evr_model* m, const std::string& name, const std::string& wname, const std::string& bname, const std::string& bn_prefix,
-             bool bn, int cin, int cout, int k, int stride, int epi, bool keep_bias_with_bn = false) {
+             bool bn, int cin, int cout, int k, int stride, int epi, bool keep_bias_with_bn = false, bool bn_affine = true) {
     Conv c; c.name = name;
     const HostTensor* w; int rc;
     if ((rc = find(m, wname, &w))) return rc;
     Affine af;
-    if ((rc = make_affine(m, (bn && !keep_bias_with_bn) ? std::string() : bname, bn_prefix, bn, cout, &af))) return rc;
+    if ((rc = make_affine(m, (bn && !keep_bias_with_bn) ? std::string() : bname, bn_prefix, bn, cout, &af, bn_affine))) return rc;
     EVR_REQUIRE(cin % 16 == 0, "'%s': %d input channels (need a multiple of 16)", name.c_str(), cin);
     c.kc = pick_kc(cin, 0);
     c.cin0 = cin; c.cin1 = 0; c.stride = stride; c.epi = epi; c.n_valid = cout;
@@ -364,12 +365,12 @@ int add_conv(evr_model* m, const std::string& name, const std::string& wname, co
     return finish_conv(m, c);
 }
 
-int add_tconv(evr_model* m, const std::string& name, const std::string& prefix, bool bn, int cin, int cout, int k) {
+int add_tconv(evr_model* m, const std::string& name, const std::string& prefix, bool bn, int cin, int cout, int k, bool inn = false) {
     Conv c; c.name = name;
     const HostTensor* w; int rc;
     if ((rc = find(m, prefix + ".transposed_conv2d.weight", &w))) return rc;
     Affine af;
-    if ((rc = make_affine(m, bn ? std::string() : prefix + ".transposed_conv2d.bias", prefix + ".norm_layer", bn, cout, &af))) return rc;
+    if ((rc = make_affine(m, bn ? std::string() : prefix + ".transposed_conv2d.bias", prefix + ".norm_layer", bn || inn, cout, &af, !inn))) return rc;
     c.kc = pick_kc(cin, 0);
     c.cin0 = cin; c.stride = 1; c.epi = EPI_BIAS_RELU; c.n_valid = cout;
     if ((rc = prep_tconv(c, w, af, cin, cout, k, k / 2, round_up(cout, 32)))) return rc;
@@ -427,7 +428,7 @@ int conv_index(const evr_model* m, const std::string& name) {
 }
 
 // head: Conv2d(num_bins -> C, k) [B*k*k][C]; pred: 1x1 C -> 1 (+BN)
-int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::string& pred_prefix, bool pred_bn, int C) {
+int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::string& pred_prefix, bool pred_bn, int C, bool pred_in = false) {
     const evr_model_desc& d = m->desc;
     const HostTensor* w; int rc;
     if ((rc = find(m, head_prefix + ".weight", &w))) return rc;
@@ -444,7 +445,7 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     if ((rc = find(m, pred_prefix + ".conv2d.weight", &w))) return rc;
     EVR_REQUIRE(w->numel() == C, "pred weight has %lld elements, expected %d", (long long)w->numel(), C);
     Affine ap;
-    if ((rc = make_affine(m, pred_bn ? std::string() : pred_prefix + ".conv2d.bias", pred_prefix + ".norm_layer", pred_bn, 1, &ap))) return rc;
+    if ((rc = make_affine(m, pred_bn ? std::string() : pred_prefix + ".conv2d.bias", pred_prefix + ".norm_layer", pred_bn || pred_in, 1, &ap, !pred_in))) return rc;
     m->pred_w.assign(C, 0.f);
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
@@ -464,14 +465,19 @@ int build_unet(evr_model* m) {
     const evr_model_desc& d = m->desc;
     const std::string pre = "unetrecurrent.";
     const bool bn = d.norm == EVR_NORM_BN;
+    // norm='IN' (submodules.py:22-23,48-49,79-80): the conv layers carry InstanceNorm2d(track_running_stats=True), which in
+    // eval mode (eval.py:112) is a fixed per-channel affine from the running statistics -> folded like BatchNorm (gamma = 1,
+    // beta = 0, conv bias kept); the residual blocks carry a TRUE InstanceNorm2d (:160-162) -> ST_INORM steps
+    const bool inn = d.norm == EVR_NORM_IN;
+    EVR_REQUIRE(!inn || !((d.reserved[1] & 1)), "norm='IN' with the dynamic decoder is not supported");
     const int E = d.num_encoders, base = d.base_num_channels, k = d.kernel_size;
     EVR_REQUIRE(E >= 1 && E <= 6 && base % 32 == 0, "UNetRecurrent: num_encoders %d / base_num_channels %d unsupported", E, base);
     int rc;
-    if ((rc = prep_head_pred(m, pre + "head.conv2d", pre + "pred", bn, base))) return rc;
+    if ((rc = prep_head_pred(m, pre + "head.conv2d", pre + "pred", bn, base, inn))) return rc;
     for (int i = 0; i < E; ++i) {
         const int cin = base << i, cout = base << (i + 1);
         const std::string p = pre + "encoders." + std::to_string(i);
-        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", bn, cin, cout, k, 2, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", bn || inn, cin, cout, k, 2, EPI_BIAS_RELU, inn, !inn))) return rc;
         if (d.recurrent_block == EVR_REC_CONVLSTM) rc = add_lstm(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout);
         else rc = add_gru(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout);
         if (rc) return rc;
@@ -479,8 +485,8 @@ int build_unet(evr_model* m) {
     const int cm = base << E;
     for (int i = 0; i < d.num_residual_blocks; ++i) {
         const std::string p = pre + "resblocks." + std::to_string(i), n = "res" + std::to_string(i);
-        if ((rc = add_conv(m, n + ".conv1", p + ".conv1.weight", p + ".conv1.bias", p + ".bn1", bn, cm, cm, 3, 1, EPI_BIAS_RELU))) return rc;
-        if ((rc = add_conv(m, n + ".conv2", p + ".conv2.weight", p + ".conv2.bias", p + ".bn2", bn, cm, cm, 3, 1, EPI_RESIDUAL_RELU))) return rc;
+        if ((rc = add_conv(m, n + ".conv1", p + ".conv1.weight", p + ".conv1.bias", p + ".bn1", bn, cm, cm, 3, 1, inn ? EPI_BIAS : EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, n + ".conv2", p + ".conv2.weight", p + ".conv2.bias", p + ".bn2", bn, cm, cm, 3, 1, inn ? EPI_BIAS : EPI_RESIDUAL_RELU))) return rc;
     }
     m->dynamic = (d.reserved[1] & 1) != 0;
     for (int i = 0; i < E; ++i) {
@@ -511,8 +517,8 @@ int build_unet(evr_model* m) {
             if ((rc = add_conv(m, n, p + ".dynamic_conv.compositional_coefficients", p + ".dynamic_conv.bias", "", false, cin * 6, cout, 1, 1, EPI_BIAS_RELU))) return rc;
             continue;
         }
-        if (d.use_upsample_conv) rc = add_conv(m, n, p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", bn, cin, cout, k, 1, EPI_BIAS_RELU);
-        else rc = add_tconv(m, n, p, bn, cin, cout, k);
+        if (d.use_upsample_conv) rc = add_conv(m, n, p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", bn || inn, cin, cout, k, 1, EPI_BIAS_RELU, inn, !inn);
+        else rc = add_tconv(m, n, p, bn, cin, cout, k, inn);
         if (rc) return rc;
     }
     return EVR_OK;
@@ -790,24 +796,44 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     // where the first decoder's skip-sum can be fused: into the last plain conv before it
     const bool fuse = !d.use_upsample_conv;
     int last_plain = -1;   // conv index whose epilogue may take post_add
+    const bool inn = d.norm == EVR_NORM_IN;
+    int last_inorm = -1;   // step index of the last ST_INORM (takes the first decoder's fused skip instead of a conv epilogue)
     for (int i = 0; i < d.num_residual_blocks; ++i) {
         const std::string rn = "res" + std::to_string(i);
         DevTensor t, o;
         if ((rc = alloc(m, &t, n, h, w, cm, stream, P))) return rc;
         if ((rc = alloc(m, &o, n, h, w, cm, stream, P))) return rc;
+        const int c1 = conv_index(m, rn + ".conv1"), c2 = conv_index(m, rn + ".conv2");
+        if (inn) {
+            // conv (bias) -> InstanceNorm2d -> relu -> conv (bias) -> InstanceNorm2d -> + x -> relu  (submodules.py:169-184)
+            DevTensor raw;
+            if ((rc = alloc(m, &raw, n, h, w, cm, stream))) return rc;                 // PLAIN: the norm kernel's input
+            ConvIO a{}, b{};
+            a.in_packed = b.in_packed = P;
+            for (int p = 0; p < 2; ++p) { a.in0[p] = x[p]; a.out[p] = raw.p; b.in0[p] = t.p; b.out[p] = raw.p; }
+            plan_conv(m, c1, n, h, w, a, cm); push_conv(m, c1);
+            { Step s; s.kind = ST_INORM; s.a[0] = s.a[1] = raw.p; s.out = t.p; s.h = h; s.w = w; s.c = cm; s.out_packed = P; m->steps.push_back(s); }
+            plan_conv(m, c2, n, h, w, b, cm); push_conv(m, c2);
+            { Step s; s.kind = ST_INORM; s.a[0] = s.a[1] = raw.p; s.b[0] = x[0]; s.b[1] = x[1]; s.b_packed = P; s.out = o.p; s.h = h; s.w = w; s.c = cm;
+              s.out_packed = P; m->steps.push_back(s); last_inorm = (int)m->steps.size() - 1; }
+            x[0] = x[1] = o.p;
+            name2(m, rn, o, o);
+            last_plain = -1;
+            continue;
+        }
         ConvIO a{}, b{};
         a.in_packed = b.in_packed = P; a.out_packed = b.out_packed = P; b.res_packed = P;
         for (int p = 0; p < 2; ++p) {
             a.in0[p] = x[p]; a.out[p] = t.p;
             b.in0[p] = t.p; b.out[p] = o.p; b.residual[p] = x[p];
         }
-        const int c1 = conv_index(m, rn + ".conv1"), c2 = conv_index(m, rn + ".conv2");
         plan_conv(m, c1, n, h, w, a, cm); push_conv(m, c1);
         plan_conv(m, c2, n, h, w, b, cm); push_conv(m, c2);
         x[0] = x[1] = o.p;
         name2(m, rn, o, o);
         last_plain = c2;
     }
+    (void)last_inorm;
     for (int i = 0; i < E; ++i) {
         const int cin = base << (E - i), cout = base << (E - i - 1);
         const DevTensor sk[2] = {blk0[E - 1 - i], blk1[E - 1 - i]};
@@ -1204,6 +1230,9 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             case ST_DYN:
                 if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
+                break;
+            case ST_INORM:
+                if ((rc = launch_instnorm(s.a[p], s.b[p], nullptr, s.out, m->n_seq, s.h * s.w, s.c, s.b_packed, 0, s.out_packed, stream))) return rc;
                 break;
             case ST_SP_NEAREST:
                 if ((rc = launch_nearest_half(m->sp_xorg, m->sp_xorg_half, m->n_seq * 3, m->hp, m->wp, stream))) return rc;

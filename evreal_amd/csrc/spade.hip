@@ -155,3 +155,58 @@ int launch_spade_pred(const SpadePredArgs& a, hipStream_t stream) {
 }
 
 }  // namespace evr
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm2d (no running statistics, no affine) of the ResidualBlocks built with norm='IN' (model/submodules.py:
+// 160-162,171-179): per (image, channel) mean / biased variance over H x W, y = (x - mean) / sqrt(var + 1e-5), then
+// relu, or + residual then relu, [+ the next decoder's fused skip].  x: PLAIN [n, hw, c]; one 256-thread workgroup per
+// (image, 32 channels): lane % 32 = channel (a pixel's 32 channels are one 128-B line), 8 pixel stripes.
+namespace evr {
+
+__global__ __launch_bounds__(256) void instnorm_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ skip,
+                                                        float* __restrict__ out, int hw, int c, int res_packed, int skip_packed, int out_packed) {
+    __shared__ double s1[8][32], s2[8][32];
+    __shared__ float s_mean[32], s_inv[32];
+    const int tid = threadIdx.x, ch = tid & 31, stripe = tid >> 5;
+    const int c0 = blockIdx.x * 32;
+    const int64_t base = (int64_t)blockIdx.y * hw * c;
+    double a = 0.0, b = 0.0;
+    for (int i = stripe; i < hw; i += 8) {
+        const double v = (double)x[base + (int64_t)i * c + c0 + ch];
+        a += v; b += v * v;
+    }
+    s1[stripe][ch] = a; s2[stripe][ch] = b;
+    __syncthreads();
+    if (tid < 32) {
+        double sa = 0.0, sb = 0.0;
+        for (int q = 0; q < 8; ++q) { sa += s1[q][tid]; sb += s2[q][tid]; }
+        const double mean = sa / hw;
+        double var = sb / hw - mean * mean;            // biased variance (F.instance_norm / batch_norm training statistics)
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_inv[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    // apply: a thread handles 4 consecutive channels of a pixel (16-B accesses; PACKED runs are 4 channels)
+    const int c4 = (tid & 7) * 4, prow = tid >> 3;      // 8 runs per 32 channels, 32 pixel rows per pass
+    for (int i = prow; i < hw; i += 32) {
+        const int64_t o = base + (int64_t)i * c;
+        float4 v = *(const float4*)(x + o + c0 + c4);
+        v.x = (v.x - s_mean[c4]) * s_inv[c4]; v.y = (v.y - s_mean[c4 + 1]) * s_inv[c4 + 1];
+        v.z = (v.z - s_mean[c4 + 2]) * s_inv[c4 + 2]; v.w = (v.w - s_mean[c4 + 3]) * s_inv[c4 + 3];
+        if (res) { const float4 r = ld4_any(res + o, c0 + c4, res_packed); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (skip) { const float4 k = ld4_any(skip + o, c0 + c4, skip_packed); v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w; }
+        st4_any(out + o, c0 + c4, v, out_packed);
+    }
+}
+
+int launch_instnorm(const float* x, const float* res, const float* skip, float* out, int n, int hw, int c, int res_packed,
+                    int skip_packed, int out_packed, hipStream_t stream) {
+    EVR_REQUIRE(c % 32 == 0, "instance norm: %d channels (need a multiple of 32)", c);
+    hipLaunchKernelGGL(instnorm_kernel, dim3(c / 32, n), dim3(256), 0, stream, x, res, skip, out, hw, c, res_packed, skip_packed, out_packed);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+}  // namespace evr

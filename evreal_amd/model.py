@@ -161,8 +161,8 @@ class E2VIDRecurrent(_HipModel):
         self.num_encoders = kw['num_encoders']
         if kw.get('skip_type', 'sum') != 'sum':
             raise _lib.EvrError("only skip_type='sum' exists in the reference (model/unet.py:4,31)")
-        if kw.get('norm') not in (None, 'none', 'BN'):
-            raise _lib.EvrError(f"norm={kw.get('norm')!r} is not supported (BN or none)")
+        if kw.get('norm') not in (None, 'none', 'BN', 'IN'):
+            raise _lib.EvrError(f"norm={kw.get('norm')!r} is not supported (BN, IN or none)")
         if kw.get('num_output_channels', 1) != 1:
             raise _lib.EvrError("only num_output_channels=1 (image) is supported")
 
@@ -175,7 +175,7 @@ class E2VIDRecurrent(_HipModel):
         d.num_encoders = kw['num_encoders']
         d.num_residual_blocks = kw.get('num_residual_blocks', 2)
         d.kernel_size = kw.get('kernel_size', 5)
-        d.norm = 1 if kw.get('norm') == 'BN' else 0
+        d.norm = {'BN': 1, 'IN': 2}.get(kw.get('norm'), 0)
         d.use_upsample_conv = 1 if kw.get('use_upsample_conv', True) else 0
         d.recurrent_block = 0 if kw.get('recurrent_block_type', 'convlstm') == 'convlstm' else 1
         # getattr(torch, name, None) in model/unet.py:95-96: only 'sigmoid' is used by the reference

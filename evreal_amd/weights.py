@@ -37,6 +37,13 @@ def _bn(shapes, name, c):
     shapes[name + '.num_batches_tracked'] = ()
 
 
+def _in_tracked(shapes, name, c):
+    """InstanceNorm2d(track_running_stats=True): running statistics only (no affine parameters)."""
+    shapes[name + '.running_mean'] = (c,)
+    shapes[name + '.running_var'] = (c,)
+    shapes[name + '.num_batches_tracked'] = ()
+
+
 def _gru(shapes, name, c):
     for g in ('reset_gate', 'update_gate', 'out_gate'):
         _conv(shapes, f'{name}.{g}', c, 2 * c, 3)
@@ -49,6 +56,8 @@ def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_
     UNetRecurrent.__init__, model/unet.py:99-106)."""
     s = OrderedDict()
     bn = norm == 'BN'
+    inn = norm == 'IN'          # ConvLayers: InstanceNorm2d(track_running_stats=True); ResidualBlocks: plain InstanceNorm2d (no state)
+    norm_of = lambda sh, name, c: _bn(sh, name, c) if bn else (_in_tracked(sh, name, c) if inn else None)
     k = kernel_size
     cin = [base_num_channels * 2 ** i for i in range(num_encoders)]
     cout = [base_num_channels * 2 ** (i + 1) for i in range(num_encoders)]
@@ -56,8 +65,7 @@ def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_
     for i in range(num_encoders):
         p = f'{prefix}encoders.{i}'
         _conv(s, p + '.conv.conv2d', cout[i], cin[i], k, bias=not bn)
-        if bn:
-            _bn(s, p + '.conv.norm_layer', cout[i])
+        norm_of(s, p + '.conv.norm_layer', cout[i])
         if recurrent_block_type == 'convlstm':
             _conv(s, p + '.recurrent_block.Gates', 4 * cout[i], 2 * cout[i], 3)
         else:
@@ -86,11 +94,9 @@ def unet_recurrent_schema(num_bins=5, base_num_channels=32, num_encoders=3, num_
             s[p + '.transposed_conv2d.weight'] = (ci, co, k, k)
             if not bn:
                 s[p + '.transposed_conv2d.bias'] = (co,)
-        if bn:
-            _bn(s, p + '.norm_layer', co)
+        norm_of(s, p + '.norm_layer', co)
     _conv(s, prefix + 'pred.conv2d', 1, base_num_channels, 1, bias=not bn)
-    if bn:
-        _bn(s, prefix + 'pred.norm_layer', 1)
+    norm_of(s, prefix + 'pred.norm_layer', 1)
     return s
 
 

@@ -109,7 +109,9 @@ int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W, const dou
  * Weights are handed over as the reference's own state_dict: names + host fp32 arrays.
  */
 enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2, EVR_ARCH_SPADE_E2VID = 3 };
-enum evr_norm { EVR_NORM_NONE = 0, EVR_NORM_BN = 1 };
+enum evr_norm { EVR_NORM_NONE = 0, EVR_NORM_BN = 1,
+                EVR_NORM_IN = 2 /* submodules.py:22-23,160-162: running-statistics InstanceNorm in the conv layers (folded),
+                                   true InstanceNorm2d inside the residual blocks */ };
 enum evr_recurrent { EVR_REC_CONVLSTM = 0, EVR_REC_CONVGRU = 1 };
 enum evr_activation { EVR_ACT_NONE = 0, EVR_ACT_SIGMOID = 1 };
 

@@ -23,6 +23,16 @@ def _bn(sd, prefix, x):
                         sd[prefix + '.weight'], sd[prefix + '.bias'], False, 0.1, 1e-5)
 
 
+def _norm(sd, prefix, x, norm):
+    """norm layer of ConvLayer / TransposedConvLayer / UpsampleConvLayer (submodules.py:20-23): BatchNorm2d, or
+    InstanceNorm2d(track_running_stats=True) which in eval mode normalises with its RUNNING statistics (no affine)."""
+    if norm == 'BN':
+        return _bn(sd, prefix, x)
+    if norm == 'IN':
+        return F.instance_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'], None, None, False, 0.1, 1e-5)
+    return x
+
+
 def _act(x, activation):
     if activation is None:
         return x
@@ -31,24 +41,21 @@ def _act(x, activation):
 
 def conv_layer(sd, p, x, stride=1, padding=0, activation='relu', norm=None):
     x = F.conv2d(x, sd[p + '.conv2d.weight'], sd.get(p + '.conv2d.bias'), stride, padding)
-    if norm == 'BN':
-        x = _bn(sd, p + '.norm_layer', x)
+    x = _norm(sd, p + '.norm_layer', x, norm)
     return _act(x, activation)
 
 
 def transposed_conv_layer(sd, p, x, padding, activation='relu', norm=None):
     x = F.conv_transpose2d(x, sd[p + '.transposed_conv2d.weight'], sd.get(p + '.transposed_conv2d.bias'),
                            stride=2, padding=padding, output_padding=1)
-    if norm == 'BN':
-        x = _bn(sd, p + '.norm_layer', x)
+    x = _norm(sd, p + '.norm_layer', x, norm)
     return _act(x, activation)
 
 
 def upsample_conv_layer(sd, p, x, padding, activation='relu', norm=None):
     x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
     x = F.conv2d(x, sd[p + '.conv2d.weight'], sd.get(p + '.conv2d.bias'), 1, padding)
-    if norm == 'BN':
-        x = _bn(sd, p + '.norm_layer', x)
+    x = _norm(sd, p + '.norm_layer', x, norm)
     return _act(x, activation)
 
 
@@ -102,13 +109,18 @@ def dynamic_upsample_layer(sd, p, x, ev_tensor, prev_recs):
 
 
 def residual_block(sd, p, x, norm=None):
+    # norm='IN' here is a plain InstanceNorm2d (submodules.py:160-162): instance statistics even in eval mode
     out = F.conv2d(x, sd[p + '.conv1.weight'], sd.get(p + '.conv1.bias'), padding=1)
     if norm == 'BN':
         out = _bn(sd, p + '.bn1', out)
+    elif norm == 'IN':
+        out = F.instance_norm(out)
     out = torch.relu(out)
     out = F.conv2d(out, sd[p + '.conv2.weight'], sd.get(p + '.conv2.bias'), padding=1)
     if norm == 'BN':
         out = _bn(sd, p + '.bn2', out)
+    elif norm == 'IN':
+        out = F.instance_norm(out)
     return torch.relu(out + x)
 
 

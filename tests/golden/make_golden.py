@@ -255,6 +255,7 @@ def make_firenet():
 
 # ---------------------------------------------------------------- 6. E2VID layouts (synthetic weights)
 def make_e2vid():
+    only = os.environ.get('E2VID_ONLY')        # regenerate one layout without touching the others
     for tag, kw in [('e2vid_bn', weights.E2VID_KWARGS), ('e2vid_plus', weights.E2VID_PLUS_KWARGS),
                     ('e2vid_hyper', dict(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
                                          kernel_size=5, norm=None, use_upsample_conv=True, recurrent_block_type='convlstm',
@@ -262,7 +263,12 @@ def make_e2vid():
                     ('e2vid_gru_tiny', dict(num_bins=5, base_num_channels=32, num_encoders=2, num_residual_blocks=1,
                                             kernel_size=5, norm=None, use_upsample_conv=False,
                                             recurrent_block_type='convgru', skip_type='sum',
-                                            final_activation='sigmoid'))]:
+                                            final_activation='sigmoid')),
+                    ('e2vid_in', dict(num_bins=5, base_num_channels=32, num_encoders=3, num_residual_blocks=2,
+                                      kernel_size=5, norm='IN', use_upsample_conv=False, recurrent_block_type='convlstm',
+                                      skip_type='sum', final_activation='sigmoid'))]:
+        if only and tag != only:
+            continue
         schema = weights.unet_recurrent_schema(**kw)
         m = ref_model.E2VIDRecurrent(dict(kw))
         ref_sd = m.state_dict()

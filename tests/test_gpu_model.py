@@ -103,6 +103,12 @@ def test_e2vid_gru_tiny():
     _e2vid('e2vid_gru_tiny')
 
 
+def test_e2vid_instance_norm_layout():
+    """norm='IN' (model/submodules.py:22-23,160-162): running-statistics InstanceNorm folded into the conv layers, a true
+    InstanceNorm2d kernel inside the residual blocks -- against the reference class."""
+    _e2vid('e2vid_in')
+
+
 def test_e2vid_hyper_dynamic_decoder():
     _e2vid('e2vid_hyper')
 
