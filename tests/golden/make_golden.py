@@ -413,6 +413,49 @@ def make_color():
              weights_sha=np.array(weights.state_dict_digest(sd)), **out)
 
 
+def make_metrics_published():
+    """Known-answer vectors for MSE and SSIM from the PUBLISHED definitions, independent of oracle/metrics.py:
+
+    SSIM: Z. Wang, A. C. Bovik, H. R. Sheikh, E. P. Simoncelli, "Image quality assessment: from error visibility to
+    structural similarity", IEEE TIP 13(4), 2004, and the authors' ssim_index.m: an 11x11 circular-symmetric Gaussian
+    window with sigma = 1.5 samples, normalised to unit sum; local means, variances and covariance by 'valid' filtering
+    (no padding: the map is (H-10) x (W-10)); K1 = 0.01, K2 = 0.03, L = dynamic range;
+    SSIM = mean over the map of ((2 mu_x mu_y + C1)(2 sigma_xy + C2)) / ((mu_x^2 + mu_y^2 + C1)(sigma_x^2 + sigma_y^2 + C2)).
+    Evaluated here in float64 with an explicit double loop over the window (no scipy filter, no separability).
+    The reference's call -- structural_similarity(gaussian_weights=True, sigma=1.5, use_sample_covariance=False,
+    data_range=1.0), utils/eval_metrics.py:96 -- is scikit-image's implementation of exactly this configuration (its
+    docstring: "to match the implementation of Wang et al."), so these values pin the restatement to the published
+    algorithm; scikit-image's own float32 rounding stays unpinned (it is not installed here).
+    MSE: mean((x - y)^2) in float64."""
+    rng = np.random.default_rng(2004)
+    H, W = 48, 64
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    cases = {}
+    base = 0.5 + 0.25 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 0.15 * np.sin((xx + 2 * yy) / 11.0)
+    cases['smooth_vs_noisy'] = (np.clip(base, 0, 1), np.clip(base + rng.normal(0, 0.05, (H, W)), 0, 1))
+    cases['noise_vs_noise'] = (rng.random((H, W)), rng.random((H, W)))
+    cases['shifted'] = (np.clip(base, 0, 1), np.clip(np.roll(base, 2, axis=1) * 0.9 + 0.03, 0, 1))
+    g = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    win = np.outer(g, g); win /= win.sum()
+    out, meta = {}, []
+    for name, (x, y) in cases.items():
+        x = x.astype(np.float32); y = y.astype(np.float32)             # the tracker hands float32 images to the metric
+        X, Y = x.astype(np.float64), y.astype(np.float64)
+        C1, C2 = (0.01 * 1.0) ** 2, (0.03 * 1.0) ** 2
+        acc = 0.0
+        for i in range(H - 10):
+            for j in range(W - 10):
+                px, py = X[i:i + 11, j:j + 11], Y[i:i + 11, j:j + 11]
+                mx, my = (win * px).sum(), (win * py).sum()
+                sx = (win * px * px).sum() - mx * mx; sy = (win * py * py).sum() - my * my
+                sxy = (win * px * py).sum() - mx * my
+                acc += ((2 * mx * my + C1) * (2 * sxy + C2)) / ((mx * mx + my * my + C1) * (sx + sy + C2))
+        out[name + '.x'] = x; out[name + '.y'] = y
+        meta.append({'name': name, 'ssim': acc / ((H - 10) * (W - 10)), 'mse': float(((X - Y) ** 2).mean())})
+    save_npz('metrics_published.npz', meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **out)
+    print(meta)
+
+
 def make_spade():
     """SPADE-E2VID (reference class Unet6, exported as SpadeE2vid) with deterministic synthetic weights: 4 frames of
     one 64x96 sequence -> images, final hidden states, and the 3-channel prev_recs of the last frame."""
@@ -433,7 +476,7 @@ def make_spade():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade', 'metrics']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade, 'metrics': make_metrics_published}[w]()

@@ -94,3 +94,15 @@ def test_lpips_vs_oracle(shape):
     want = ol.lpips(sd, img, ref)
     assert got[0] == 0.0
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
+
+
+def test_metrics_kernel_against_the_published_definition():
+    """evr_metrics vs the Wang et al. known answers (tests/golden/metrics_published.npz, float64, explicit window loops)."""
+    import json
+    from evreal_amd.prepost import Metrics
+    z = load_npz('metrics_published.npz')
+    met = Metrics()
+    for m in json.loads(bytes(z['meta']).decode()):
+        x, y = z[m['name'] + '.x'], z[m['name'] + '.y']
+        out = met(torch.from_numpy(x[None]).cuda(), torch.from_numpy(y[None]).cuda(), clip=False).cpu().numpy()[0]
+        assert abs(out[0] - m['mse']) < 1e-9 and abs(out[1] - m['ssim']) < 5e-6, (m['name'], out)

@@ -101,3 +101,18 @@ def test_ssim_mse_properties():
     s = om.ssim(b, a)
     assert 0.0 < s < 1.0 and abs(om.ssim(a, b) - s) < 1e-6
     assert abs(om.mse(b, a) - float(np.mean((a.astype(np.float64) - b) ** 2))) < 1e-8
+
+
+def test_ssim_mse_against_the_published_definition():
+    """tests/golden/metrics_published.npz: SSIM exactly as Wang et al. (2004) / ssim_index.m define it (11x11 Gaussian,
+    sigma 1.5, 'valid' region, K1 = 0.01, K2 = 0.03), evaluated in float64 with explicit window loops by
+    make_golden.py -- independent of scipy's filters and of this repo's restatement.  scikit-image's float32 rounding
+    is the only part of the reference's call that stays unpinned."""
+    import json
+    from conftest import load_npz
+    from oracle import metrics as om
+    z = load_npz('metrics_published.npz')
+    for m in json.loads(bytes(z['meta']).decode()):
+        x, y = z[m['name'] + '.x'], z[m['name'] + '.y']
+        assert abs(om.ssim(x, y) - m['ssim']) < 1e-6, m['name']
+        assert abs(om.mse(x, y) - m['mse']) < 1e-9, m['name']
