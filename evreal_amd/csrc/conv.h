@@ -188,6 +188,17 @@ int launch_spade_first(float* xpad, float* xorg, int n, int B, int hp, int wp, h
 int launch_nearest_half(const float* in, float* out, int planes, int h, int w, hipStream_t stream);
 int launch_spade_apply(const float* xn, const float* gb, const float* skip, float* out, int64_t pix, int C, int skip_packed, int out_packed, hipStream_t stream);
 int launch_spade_pred(const SpadePredArgs& a, hipStream_t stream);
+// ET-Net token kernels (etnet.hip; model/eitr of the reference)
+struct AttnArgs {
+    const float* q; const float* k; const float* v;   // PLAIN fp32 rows; head h = columns [off + 32h, off + 32h + 32)
+    int ldq, ldk, ldv, qo, ko, vo;
+    int n, Lq, Lk, heads;
+    float* out; int out_packed;                       // [n, Lq, 256]
+};
+int launch_layernorm256(const float* x, const float* w, const float* b, float* out, int64_t rows, int out_packed, hipStream_t stream);
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+int launch_add_pos(const float* x, const float* pos, float* out, int n, int L, int x_packed, hipStream_t stream);
+int launch_mean6(const float* const* in, float* out, int64_t rows, int out_packed, hipStream_t stream);
 // InstanceNorm2d of the norm='IN' ResidualBlocks (spade.hip): out = relu(IN(x) [+ res]) [+ skip]
 int launch_instnorm(const float* x, const float* res, const float* skip, float* out, int n, int hw, int c, int res_packed,
                     int skip_packed, int out_packed, hipStream_t stream);

@@ -66,7 +66,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
 
 enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN,
                 ST_SP_NEAREST, ST_SP_SEG, ST_SP_APPLY,     // SPADE-E2VID (spade.hip)
-                ST_INORM };                                // InstanceNorm2d of the norm='IN' residual blocks
+                ST_INORM,                                  // InstanceNorm2d of the norm='IN' residual blocks
+                ST_LN, ST_ATTN, ST_ADDPOS, ST_MEAN6 };     // ET-Net token kernels (etnet.hip)
 struct Step {
     StepKind kind;
     int conv = -1;
@@ -118,6 +119,11 @@ struct evr_model {
     std::vector<float*> sp_seg_dw, sp_seg_db;
     std::vector<float> sp_pred_w; float sp_pred_b[3] = {0.f, 0.f, 0.f}; float* d_sp_pred_w = nullptr;
     SpadePredArgs sp_pred;
+    // ET-Net (model/eitr): LayerNorm parameters, attention launches, the sine position table
+    std::vector<std::pair<float*, float*>> et_ln;      // device (weight, bias) per LayerNorm, indexed by Step::conv
+    std::vector<AttnArgs> et_attn;                     // indexed by Step::conv
+    float* et_pos = nullptr;                           // [L, 256] for the current shape
+    const float* et_mean_in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const float* sp_skip[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     // per-layer event timing (evr_model_profile_*)
     bool prof_on = false;
@@ -130,6 +136,7 @@ struct evr_model {
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
                    if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
                    if (d_head_wfrag) (void)hipFree(d_head_wfrag);
+                   for (auto& pr : et_ln) { (void)hipFree(pr.first); (void)hipFree(pr.second); }
                    for (float* q : sp_seg_dw) (void)hipFree(q); for (float* q : sp_seg_db) (void)hipFree(q); if (d_sp_pred_w) (void)hipFree(d_sp_pred_w);
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
     void release_shape() {
@@ -137,7 +144,7 @@ struct evr_model {
         allocs.clear();
         if (d_args) { (void)hipFree(d_args); d_args = nullptr; }
         steps.clear(); named[0].clear(); named[1].clear();
-        n_seq = 0; prev_rec = nullptr; sp_xpad = sp_xorg = sp_xorg_half = nullptr;
+        n_seq = 0; prev_rec = nullptr; sp_xpad = sp_xorg = sp_xorg_half = nullptr; et_pos = nullptr; et_attn.clear();
     }
 };
 
@@ -659,6 +666,99 @@ int build_spade(evr_model* m) {
     return EVR_OK;
 }
 
+// ET-Net = EITR / mls_tpa (model/eitr/u_trans.py:13-123).  Linear layers and the MultiheadAttention projections are
+// 1x1 convolutions over the token tensor [n, L, 1, 256]; the patch embeddings split1 / split2 are k x k stride-k convs.
+int add_linear(evr_model* m, const std::string& name, const std::string& wname, const std::string& bname, int row0, int nout, int nin, int epi) {
+    const HostTensor *w, *b; int rc;
+    if ((rc = find(m, wname, &w))) return rc;
+    if ((rc = find(m, bname, &b))) return rc;
+    EVR_REQUIRE(w->ndim == 2 && w->shape[1] == nin && w->shape[0] >= row0 + nout && b->numel() >= row0 + nout, "'%s': linear weight shape mismatch", wname.c_str());
+    HostTensor wv; wv.data = w->data + (size_t)row0 * nin; wv.ndim = 4; wv.shape[0] = nout; wv.shape[1] = nin; wv.shape[2] = 1; wv.shape[3] = 1;
+    Affine af; af.scale.assign(nout, 1.0); af.shift.resize(nout);
+    for (int i = 0; i < nout; ++i) af.shift[i] = b->data[row0 + i];
+    Conv c; c.name = name;
+    c.kc = pick_kc(nin, 0); c.cin0 = nin; c.cin1 = 0; c.stride = 1; c.epi = epi; c.n_valid = nout;
+    if ((rc = prep_conv2d(c, &wv, af, nout, nin, 1, 0, [](int co) { return co; }, round_up(nout, 32)))) return rc;
+    return finish_conv(m, c);
+}
+
+int add_patch_conv(evr_model* m, const std::string& name, const std::string& prefix, int cin, int cout, int k) {
+    const HostTensor* w; int rc;
+    if ((rc = find(m, prefix + ".weight", &w))) return rc;
+    Affine af;
+    if ((rc = make_affine(m, prefix + ".bias", "", false, cout, &af))) return rc;
+    Conv c; c.name = name;
+    c.kc = pick_kc(cin, 0); c.cin0 = cin; c.cin1 = 0; c.stride = k; c.epi = EPI_BIAS; c.n_valid = cout;
+    if ((rc = prep_conv2d(c, w, af, cout, cin, k, 0, [](int co) { return co; }, round_up(cout, 32)))) return rc;   // pad 0: taps (ky, kx)
+    return finish_conv(m, c);
+}
+
+int add_layernorm(evr_model* m, const std::string& prefix, int* index) {
+    const HostTensor *w, *b; int rc;
+    if ((rc = find(m, prefix + ".weight", &w))) return rc;
+    if ((rc = find(m, prefix + ".bias", &b))) return rc;
+    EVR_REQUIRE(w->numel() == 256 && b->numel() == 256, "'%s': LayerNorm(256) expected", prefix.c_str());
+    std::vector<float> hw(w->data, w->data + 256), hb(b->data, b->data + 256);
+    float *dw, *db;
+    if ((rc = upload(hw, &dw))) return rc;
+    if ((rc = upload(hb, &db))) return rc;
+    *index = (int)m->et_ln.size();
+    m->et_ln.push_back({dw, db});
+    return EVR_OK;
+}
+
+struct EtLayer { int ln1, ln2, ln21, ln22, ln3; };       // LayerNorm indices (encoder: ln1, ln2; decoder: ln1, ln21, ln22, ln3)
+
+int build_etnet(evr_model* m) {
+    const evr_model_desc& d = m->desc;
+    const bool bn = d.norm == EVR_NORM_BN, inn = d.norm == EVR_NORM_IN;
+    EVR_REQUIRE(d.base_num_channels == 32 && d.kernel_size == 5, "ET-Net: 32 base channels, k5");
+    int rc;
+    if ((rc = prep_head_pred(m, "head.conv2d", "pred", bn, 32, inn))) return rc;
+    // NB the head ConvLayer of mls_tpa takes `norm` too (u_trans.py:19); prep_head_pred folds none into the head:
+    EVR_REQUIRE(!bn && !inn, "ET-Net with norm != None is not supported (the head convolution would carry a norm layer)");
+    for (int i = 0; i < 3; ++i) {
+        const int cin = 32 << i, cout = 64 << i;
+        const std::string p = "DownsampleConv." + std::to_string(i);
+        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", false, cin, cout, 5, 2, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_lstm(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout))) return rc;
+    }
+    if ((rc = add_patch_conv(m, "split1", "split1", 128, 256, 2))) return rc;
+    if ((rc = add_patch_conv(m, "split2", "split2", 64, 256, 4))) return rc;
+    int dummy;
+    for (int s = 0; s < 3; ++s) {
+        for (int l = 0; l < 3; ++l) {
+            const std::string p = "trans_encoder" + std::to_string(s) + ".encoder.layers." + std::to_string(l), n = "te" + std::to_string(s) + "." + std::to_string(l);
+            if ((rc = add_layernorm(m, p + ".norm1", &dummy))) return rc;
+            if ((rc = add_layernorm(m, p + ".norm2", &dummy))) return rc;
+            if ((rc = add_linear(m, n + ".qkv", p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 0, 768, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".out", p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 0, 256, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".ff1", p + ".linear1.weight", p + ".linear1.bias", 0, 1024, 256, EPI_BIAS_RELU))) return rc;
+            if ((rc = add_linear(m, n + ".ff2", p + ".linear2.weight", p + ".linear2.bias", 0, 256, 1024, EPI_BIAS))) return rc;
+        }
+        for (int l = 0; l < 2; ++l) {
+            const std::string p = "trans_decoder" + std::to_string(s) + ".decoder.layers." + std::to_string(l), n = "td" + std::to_string(s) + "." + std::to_string(l);
+            if ((rc = add_layernorm(m, p + ".norm1", &dummy))) return rc;
+            if ((rc = add_layernorm(m, p + ".norm21", &dummy))) return rc;
+            if ((rc = add_layernorm(m, p + ".norm22", &dummy))) return rc;
+            if ((rc = add_layernorm(m, p + ".norm3", &dummy))) return rc;
+            if ((rc = add_linear(m, n + ".qkv", p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 0, 768, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".out", p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 0, 256, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".cq", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 0, 256, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".ckv", p + ".cross_attn.in_proj_weight", p + ".cross_attn.in_proj_bias", 256, 512, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".cout", p + ".cross_attn.out_proj.weight", p + ".cross_attn.out_proj.bias", 0, 256, 256, EPI_BIAS))) return rc;
+            if ((rc = add_linear(m, n + ".ff1", p + ".linear1.weight", p + ".linear1.bias", 0, 1024, 256, EPI_BIAS_RELU))) return rc;
+            if ((rc = add_linear(m, n + ".ff2", p + ".linear2.weight", p + ".linear2.bias", 0, 256, 1024, EPI_BIAS))) return rc;
+        }
+    }
+    const int uin[3] = {256, 128, 64}, uout[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "UpsampleConv." + std::to_string(i);
+        if ((rc = add_conv(m, "dec" + std::to_string(i), p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", false, uin[i], uout[i], 5, 1, EPI_BIAS_RELU))) return rc;
+    }
+    return EVR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shape-dependent planning
 int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream, bool packed = false) {
@@ -1104,6 +1204,177 @@ int plan_spade(evr_model* m, hipStream_t stream) {
     return EVR_OK;
 }
 
+int plan_etnet(evr_model* m, hipStream_t stream) {
+    const int n = m->n_seq, hp = m->hp, wp = m->wp;
+    const bool P = m->packed;
+    int rc;
+    EVR_REQUIRE(hp % 8 == 0 && wp % 8 == 0, "ET-Net: padded size %dx%d not a multiple of 8", wp, hp);
+    DevTensor head;
+    if ((rc = alloc(m, &head, n, hp, wp, 32, stream, P))) return rc;
+    name2(m, "head", head, head);
+    m->head.out = head.p; m->head.out_packed = P;
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
+    const float* x[2] = {head.p, head.p};
+    int h = hp, w = wp;
+    DevTensor blk[3][2];
+    for (int i = 0; i < 3; ++i) {       // DownsampleConv: conv k5 s2 + ConvLSTM (as the UNet encoders)
+        const int cout = 64 << i;
+        const std::string en = "enc" + std::to_string(i);
+        DevTensor cv;
+        if ((rc = alloc(m, &cv, n, h / 2, w / 2, cout, stream, P))) return rc;
+        ConvIO io{};
+        io.in_packed = P; io.out_packed = P;
+        io.in0[0] = x[0]; io.in0[1] = x[1]; io.in1[0] = io.in1[1] = nullptr; io.out[0] = io.out[1] = cv.p;
+        const int ci = conv_index(m, en + ".conv");
+        plan_conv(m, ci, n, h, w, io, cout); push_conv(m, ci);
+        h /= 2; w /= 2;
+        DevTensor hb[2], cb;
+        if ((rc = alloc(m, &hb[0], n, h, w, cout, stream, P))) return rc;
+        if ((rc = alloc(m, &hb[1], n, h, w, cout, stream, P))) return rc;
+        if ((rc = alloc(m, &cb, n, h, w, cout, stream))) return rc;
+        ConvIO r{};
+        r.in_packed = P; r.out_packed = P;
+        for (int p = 0; p < 2; ++p) { r.in0[p] = cv.p; r.in1[p] = hb[p].p; r.out[p] = hb[1 - p].p; r.state[p] = cb.p; }
+        const int ri = conv_index(m, en + ".rec");
+        plan_conv(m, ri, n, h, w, r, cout); push_conv(m, ri);
+        x[0] = hb[1].p; x[1] = hb[0].p;
+        blk[i][0] = hb[1]; blk[i][1] = hb[0];
+        name2(m, "h" + std::to_string(i), hb[1], hb[0]);
+        name2(m, "c" + std::to_string(i), cb, cb);
+    }
+    const int th = hp / 8, tw = wp / 8, L = th * tw;
+
+    // sine position table (position_encoding.py:14-23: float64 numpy, cast to float32)
+    {
+        std::vector<float> pos((size_t)L * 256);
+        for (int l = 0; l < L; ++l)
+            for (int j = 0; j < 256; ++j) {
+                const double ang = (double)l / std::pow(10000.0, 2.0 * (j / 2) / 256.0);
+                pos[(size_t)l * 256 + j] = (float)((j & 1) ? std::cos(ang) : std::sin(ang));
+            }
+        DevTensor pt;
+        if ((rc = alloc(m, &pt, 1, L, 1, 256, stream))) return rc;
+        EVR_HIP(hipMemcpyAsync(pt.p, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        EVR_HIP(hipStreamSynchronize(stream));       // `pos` is a local
+        m->et_pos = pt.p;
+    }
+    auto tok = [&](DevTensor* t, int c, bool packed) { return alloc(m, t, n, L, 1, c, stream, packed); };
+    DevTensor Wd[3], HS[3], HC[3], Ta, Tb, Tm, Tm2, XA, MEMN, QKV, CQ, CKV, AO, FF, SP;
+    for (int s2 = 0; s2 < 3; ++s2) { if ((rc = tok(&Wd[s2], 256, false))) return rc; if ((rc = tok(&HS[s2], 256, false))) return rc; if ((rc = tok(&HC[s2], 256, false))) return rc; }
+    if ((rc = tok(&Ta, 256, false))) return rc; if ((rc = tok(&Tb, 256, false))) return rc;
+    if ((rc = tok(&Tm, 256, false))) return rc; if ((rc = tok(&Tm2, 256, false))) return rc;
+    if ((rc = tok(&XA, 256, P))) return rc; if ((rc = tok(&MEMN, 256, P))) return rc;
+    if ((rc = tok(&QKV, 768, false))) return rc; if ((rc = tok(&CQ, 256, false))) return rc; if ((rc = tok(&CKV, 512, false))) return rc;
+    if ((rc = tok(&AO, 256, P))) return rc; if ((rc = tok(&FF, 1024, P))) return rc; if ((rc = tok(&SP, 256, false))) return rc;
+
+    auto ln = [&](int idx, const float* in, float* out, bool out_packed) {
+        Step s; s.kind = ST_LN; s.conv = idx; s.a[0] = s.a[1] = in; s.out = out; s.out_packed = out_packed; m->steps.push_back(s);
+    };
+    // linear layer = 1x1 conv over [n, L, 1, C]: in (PACKED when P) -> out [+ post_add]
+    auto lin = [&](const std::string& nm, const float* in, float* out, int cout_total, bool out_packed, const float* add) {
+        const int ci = conv_index(m, nm);
+        ConvIO io{};
+        io.in_packed = P; io.out_packed = out_packed;
+        for (int p = 0; p < 2; ++p) { io.in0[p] = in; io.in1[p] = nullptr; io.out[p] = out; io.post_add[p] = add; }
+        io.padd_packed = false;
+        plan_conv(m, ci, n, L, 1, io, cout_total); push_conv(m, ci);
+    };
+    auto attn = [&](const float* q, int ldq, int qo, const float* k, int ldk, int ko, const float* v, int ldv, int vo, float* out) {
+        AttnArgs a; memset(&a, 0, sizeof(a));
+        a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.qo = qo; a.ko = ko; a.vo = vo;
+        a.n = n; a.Lq = L; a.Lk = L; a.heads = 8; a.out = out; a.out_packed = P;
+        Step s; s.kind = ST_ATTN; s.conv = (int)m->et_attn.size(); m->et_attn.push_back(a); m->steps.push_back(s);
+        m->flops += 2.0 * 2.0 * n * (double)L * L * 256;
+    };
+    for (int sc = 0; sc < 3; ++sc) {
+        // ---- words + position embedding (u_trans.py:93-104) ----
+        if (sc == 0) {
+            Step s; s.kind = ST_ADDPOS; s.a[0] = blk[2][0].p; s.a[1] = blk[2][1].p; s.a_packed = P; s.out = Wd[0].p; m->steps.push_back(s);
+        } else {
+            const std::string nm = sc == 1 ? "split1" : "split2";
+            const int src = 2 - sc, ks = sc == 1 ? 2 : 4;
+            const int ci = conv_index(m, nm);
+            ConvIO io{};
+            io.in_packed = P; io.out_packed = false;
+            for (int p = 0; p < 2; ++p) { io.in0[p] = blk[src][p].p; io.in1[p] = nullptr; io.out[p] = SP.p; }
+            plan_conv(m, ci, n, th * ks, tw * ks, io, 256); push_conv(m, ci);
+            Step s; s.kind = ST_ADDPOS; s.a[0] = s.a[1] = SP.p; s.a_packed = 0; s.out = Wd[sc].p; m->steps.push_back(s);
+        }
+        // ---- encoder: 3 pre-norm layers (transformer_encoder.py:64-76) ----
+        const float* cur = Wd[sc].p;
+        for (int l = 0; l < 3; ++l) {
+            const std::string nm = "te" + std::to_string(sc) + "." + std::to_string(l);
+            const int lb = sc * 14 + l * 2;
+            float* outp = (l == 2) ? HS[sc].p : ((l & 1) ? Tb.p : Ta.p);
+            ln(lb + 0, cur, XA.p, P);
+            lin(nm + ".qkv", XA.p, QKV.p, 768, false, nullptr);
+            attn(QKV.p, 768, 0, QKV.p, 768, 256, QKV.p, 768, 512, AO.p);
+            lin(nm + ".out", AO.p, Tm.p, 256, false, cur);
+            ln(lb + 1, Tm.p, XA.p, P);
+            lin(nm + ".ff1", XA.p, FF.p, 1024, P, nullptr);
+            lin(nm + ".ff2", FF.p, outp, 256, false, Tm.p);
+            cur = outp;
+        }
+    }
+    for (int sc = 0; sc < 3; ++sc) {
+        // ---- decoder: tgt = hs[sc], memory = hs[0], hs[0], hs[1] (u_trans.py:106-108; transformer_decoder.py:66-84) ----
+        const float* mem = HS[sc == 2 ? 1 : 0].p;
+        const float* cur = HS[sc].p;
+        for (int l = 0; l < 2; ++l) {
+            const std::string nm = "td" + std::to_string(sc) + "." + std::to_string(l);
+            const int lb = sc * 14 + 6 + l * 4;
+            float* outp = (l == 1) ? HC[sc].p : Ta.p;
+            ln(lb + 0, cur, XA.p, P);
+            lin(nm + ".qkv", XA.p, QKV.p, 768, false, nullptr);
+            attn(QKV.p, 768, 0, QKV.p, 768, 256, QKV.p, 768, 512, AO.p);
+            lin(nm + ".out", AO.p, Tm.p, 256, false, cur);                 // tgt2
+            ln(lb + 1, Tm.p, XA.p, P);
+            ln(lb + 2, mem, MEMN.p, P);
+            lin(nm + ".cq", XA.p, CQ.p, 256, false, nullptr);
+            lin(nm + ".ckv", MEMN.p, CKV.p, 512, false, nullptr);
+            attn(CQ.p, 256, 0, CKV.p, 512, 0, CKV.p, 512, 256, AO.p);
+            lin(nm + ".cout", AO.p, Tm2.p, 256, false, Tm.p);              // tgt4
+            ln(lb + 3, Tm2.p, XA.p, P);
+            lin(nm + ".ff1", XA.p, FF.p, 1024, P, nullptr);
+            lin(nm + ".ff2", FF.p, outp, 256, false, Tm2.p);
+            cur = outp;
+        }
+    }
+    // ---- hs_trans = mean of the six token sets -> [n, h/8, w/8, 256] (u_trans.py:112-113) ----
+    DevTensor hm;
+    if ((rc = alloc(m, &hm, n, th, tw, 256, stream, P))) return rc;
+    m->et_mean_in[0] = HS[0].p; m->et_mean_in[1] = HS[1].p; m->et_mean_in[2] = HS[2].p;
+    m->et_mean_in[3] = HC[0].p; m->et_mean_in[4] = HC[1].p; m->et_mean_in[5] = HC[2].p;
+    { Step s; s.kind = ST_MEAN6; s.out = hm.p; s.out_packed = P; s.h = L; m->steps.push_back(s); }
+    name2(m, "hs_trans", hm, hm);
+    // ---- UpsampleConv decoders with skip sums (u_trans.py:116-117) ----
+    const float* y[2] = {hm.p, hm.p};
+    bool ypk = P;
+    h = th; w = tw;
+    for (int i = 0; i < 3; ++i) {
+        const int cin = 256 >> i, cout = 128 >> i;
+        DevTensor up, o;
+        if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
+        Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = ypk; s.b_packed = P;
+        for (int p = 0; p < 2; ++p) { s.a[p] = y[p]; s.b[p] = blk[2 - i][p].p; }
+        m->steps.push_back(s);
+        h *= 2; w *= 2;
+        if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
+        ConvIO a{};
+        a.out_packed = P;
+        for (int p = 0; p < 2; ++p) { a.in0[p] = up.p; a.out[p] = o.p; }
+        const int di = conv_index(m, "dec" + std::to_string(i));
+        plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
+        y[0] = y[1] = o.p; ypk = P;
+        name2(m, "dec" + std::to_string(i), o, o);
+    }
+    m->pred_x[0] = y[0]; m->pred_x[1] = y[1];
+    m->pred_skip[0] = m->pred_skip[1] = head.p;
+    m->pred_c = 32; m->pred_x_packed = P; m->pred_skip_packed = P;
+    try_fuse_pred(m, conv_index(m, "dec2"), head.p, P);
+    return EVR_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1122,6 +1393,7 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
     if (desc->arch == EVR_ARCH_UNET_RECURRENT) rc = build_unet(m);
     else if (desc->arch == EVR_ARCH_FIRENET_LEGACY || desc->arch == EVR_ARCH_FIRENET) rc = build_firenet(m);
     else if (desc->arch == EVR_ARCH_SPADE_E2VID) rc = build_spade(m);
+    else if (desc->arch == EVR_ARCH_ETNET) rc = build_etnet(m);
     else { set_error("evr_model_create: unknown arch %d", desc->arch); rc = EVR_ERR_UNSUPPORTED; }
     m->sd.clear();   // host pointers are only valid during this call
     if (rc) { delete m; return rc; }
@@ -1147,7 +1419,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
     m->packed = false;
-    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID) {
+    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID || m->desc.arch == EVR_ARCH_ETNET) {
         m->packed = true;
         for (const auto& c : m->convs) if (!c.x3) m->packed = false;
     }
@@ -1167,7 +1439,8 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     if (spade) {      // the head convolution reads the explicit padded copy (spade.hip): no padding of its own
         m->head.H = m->hp; m->head.W = m->wp; m->head.pad_top = 0; m->head.pad_left = 0;
     }
-    int rc = (m->desc.arch == EVR_ARCH_UNET_RECURRENT) ? plan_unet(m, stream) : spade ? plan_spade(m, stream) : plan_firenet(m, stream);
+    int rc = (m->desc.arch == EVR_ARCH_UNET_RECURRENT) ? plan_unet(m, stream) : spade ? plan_spade(m, stream)
+           : (m->desc.arch == EVR_ARCH_ETNET) ? plan_etnet(m, stream) : plan_firenet(m, stream);
     if (rc) { m->release_shape(); return rc; }
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->pred_c;
@@ -1233,6 +1506,18 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             case ST_INORM:
                 if ((rc = launch_instnorm(s.a[p], s.b[p], nullptr, s.out, m->n_seq, s.h * s.w, s.c, s.b_packed, 0, s.out_packed, stream))) return rc;
+                break;
+            case ST_LN:
+                if ((rc = launch_layernorm256(s.a[p], m->et_ln[s.conv].first, m->et_ln[s.conv].second, s.out, (int64_t)m->n_seq * (m->hp / 8) * (m->wp / 8), s.out_packed, stream))) return rc;
+                break;
+            case ST_ATTN:
+                if ((rc = launch_attention(m->et_attn[s.conv], stream))) return rc;
+                break;
+            case ST_ADDPOS:
+                if ((rc = launch_add_pos(s.a[p], m->et_pos, s.out, m->n_seq, (m->hp / 8) * (m->wp / 8), s.a_packed, stream))) return rc;
+                break;
+            case ST_MEAN6:
+                if ((rc = launch_mean6(m->et_mean_in, s.out, (int64_t)m->n_seq * s.h, s.out_packed, stream))) return rc;
                 break;
             case ST_SP_NEAREST:
                 if ((rc = launch_nearest_half(m->sp_xorg, m->sp_xorg_half, m->n_seq * 3, m->hp, m->wp, stream))) return rc;

@@ -105,8 +105,6 @@ def _load_checkpoint(path):
 
 def get_model_from_checkpoint_path(model_name, checkpoint_path):
     checkpoint = _load_checkpoint(checkpoint_path)
-    if model_name == "ET-Net":
-        raise EvrError("ET-Net (model/eitr, transformer encoder/decoder) is not built (SURVEY 8f-4)")
     if model_name == "SPADE-E2VID":    # eval.py:130-133
         model, state_dict = model_arch.SpadeE2vid(), checkpoint
     elif model_name == "SSL-E2VID":    # eval.py:134-139
@@ -126,7 +124,9 @@ def get_model_from_checkpoint_path(model_name, checkpoint_path):
         if cls is None:
             raise EvrError(f"architecture {arch['type']!r} is not available in evreal_amd.model")
         model = cls(**dict(arch['args']))
-        if model_name == "FireNet+":
+        if model_name == "ET-Net":          # eval.py:152-153
+            model.num_encoders = 3
+        elif model_name == "FireNet+":
             model.num_encoders = 0
         state_dict = checkpoint['state_dict']
     model.load_state_dict(state_dict)

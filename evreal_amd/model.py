@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _lib
 
-ARCH_UNET, ARCH_FIRENET_LEGACY, ARCH_FIRENET, ARCH_SPADE_E2VID = 0, 1, 2, 3
+ARCH_UNET, ARCH_FIRENET_LEGACY, ARCH_FIRENET, ARCH_SPADE_E2VID, ARCH_ETNET = 0, 1, 2, 3, 4
 
 
 def _np_state_dict(state_dict):
@@ -254,6 +254,33 @@ class SpadeE2vid(_HipModel):
         d.num_residual_blocks = 2
         d.kernel_size = 5
         d.norm = 1
+        d.final_activation = 1
+        d.pad_multiple_log2 = self.num_encoders
+        return d
+
+
+class EITR(_HipModel):
+    """model/eitr/eitr.py:4-16 over model/eitr/u_trans.py:13-123 (the 'ET-Net' method): ConvLSTM encoder, three token
+    scales (1/8 resolution; the 1/4 and 1/2 maps through 2x2 / 4x4 patch embeddings) each through a 3-layer pre-norm
+    transformer encoder and a 2-layer decoder (8 heads, d = 256, sine position table), the mean of the six token sets,
+    three bilinear-upsample decoders with skip sums, sigmoid.  eval.py:152-153 sets num_encoders = 3 for the cropper."""
+
+    def __init__(self, eitr_kwargs):
+        super().__init__()
+        kw = dict(eitr_kwargs)
+        self.kwargs = kw
+        self.num_bins = int(kw['num_bins'])
+        self.num_encoders = 3
+        if kw.get('norm') not in (None, 'none'):
+            raise _lib.EvrError(f"ET-Net with norm={kw.get('norm')!r} is not supported")
+
+    def _desc(self):
+        d = _lib.ModelDesc()
+        d.arch = ARCH_ETNET
+        d.num_bins = self.num_bins
+        d.base_num_channels = 32
+        d.num_encoders = 3
+        d.kernel_size = 5
         d.final_activation = 1
         d.pad_multiple_log2 = self.num_encoders
         return d

@@ -142,6 +142,48 @@ def spade_e2vid_schema(**_):
     return s
 
 
+def etnet_schema(num_bins=5, norm=None, **_):
+    """EITR.state_dict() (model/eitr/u_trans.py:17-58), the 'ET-Net' method."""
+    s = OrderedDict()
+    bn = norm == 'BN'
+    norm_of = lambda name, c: _bn(s, name, c) if bn else (_in_tracked(s, name, c) if norm == 'IN' else None)
+    _conv(s, 'head.conv2d', 32, num_bins, 5, bias=not bn); norm_of('head.norm_layer', 32)
+    for i, (ci, co) in enumerate([(32, 64), (64, 128), (128, 256)]):
+        _conv(s, f'DownsampleConv.{i}.conv.conv2d', co, ci, 5, bias=not bn); norm_of(f'DownsampleConv.{i}.conv.norm_layer', co)
+        _conv(s, f'DownsampleConv.{i}.recurrent_block.Gates', 4 * co, 2 * co, 3)
+
+    def mha(p):
+        s[p + '.in_proj_weight'] = (768, 256); s[p + '.in_proj_bias'] = (768,)
+        s[p + '.out_proj.weight'] = (256, 256); s[p + '.out_proj.bias'] = (256,)
+
+    def ln(p):
+        s[p + '.weight'] = (256,); s[p + '.bias'] = (256,)
+
+    def lin(p, o, i):
+        s[p + '.weight'] = (o, i); s[p + '.bias'] = (o,)
+
+    def enc(p):
+        for l in range(3):
+            q = f'{p}.encoder.layers.{l}'
+            mha(q + '.self_attn'); ln(q + '.norm1'); lin(q + '.linear1', 1024, 256); lin(q + '.linear2', 256, 1024); ln(q + '.norm2')
+
+    def dec(p):
+        for l in range(2):
+            q = f'{p}.decoder.layers.{l}'
+            mha(q + '.self_attn'); ln(q + '.norm1'); mha(q + '.cross_attn'); ln(q + '.norm21'); ln(q + '.norm22')
+            lin(q + '.linear1', 1024, 256); lin(q + '.linear2', 256, 1024); ln(q + '.norm3')
+
+    enc('trans_encoder0'); dec('trans_decoder0')
+    _conv(s, 'split1', 256, 128, 2)
+    enc('trans_encoder1'); dec('trans_decoder1')
+    _conv(s, 'split2', 256, 64, 4)
+    enc('trans_encoder2'); dec('trans_decoder2')
+    for i, (ci, co) in enumerate([(256, 128), (128, 64), (64, 32)]):
+        _conv(s, f'UpsampleConv.{i}.conv2d', co, ci, 5, bias=not bn); norm_of(f'UpsampleConv.{i}.norm_layer', co)
+    _conv(s, 'pred.conv2d', 1, 32, 1, bias=not bn); norm_of('pred.norm_layer', 1)
+    return s
+
+
 def firenet_schema(num_bins=5, base_num_channels=16, kernel_size=3, **_):
     """FireNet.state_dict() (model/model.py:154-165), the 'FireNet+' method."""
     s = OrderedDict(); c = base_num_channels
@@ -193,6 +235,9 @@ def synth_state_dict(schema, seed=0, gain=1.0, fixed=None):
             out[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
         elif leaf == 'running_mean':
             out[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif len(shape) == 2:          # nn.Linear / MultiheadAttention projections: fan_in = in_features
+            a = gain * np.sqrt(3.0 / shape[1])
+            out[name] = rng.uniform(-a, a, shape).astype(np.float32)
         elif len(shape) == 4:
             # ConvTranspose2d weight is [Cin, Cout, k, k]; fan_in there is Cin*k*k/stride^2
             fan_in = shape[1] * shape[2] * shape[3]

@@ -106,9 +106,12 @@ int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W, const dou
  *   EVR_ARCH_FIRENET         model/model.py:147-190 (the "FireNet+" method)
  *   EVR_ARCH_SPADE_E2VID     model/spade_e2v.py:113-179 (Unet6: full-resolution ConvLSTMs, pixel-shuffle decoders
  *                            with SPADE normalisation conditioned on the previous reconstruction, 3-channel head)
+ *   EVR_ARCH_ETNET           model/eitr/ (EITR / mls_tpa): ConvLSTM encoder, three token scales through pre-norm
+ *                            transformer encoders and decoders (8 heads, d = 256), bilinear-upsample decoders
  * Weights are handed over as the reference's own state_dict: names + host fp32 arrays.
  */
-enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2, EVR_ARCH_SPADE_E2VID = 3 };
+enum evr_arch { EVR_ARCH_UNET_RECURRENT = 0, EVR_ARCH_FIRENET_LEGACY = 1, EVR_ARCH_FIRENET = 2, EVR_ARCH_SPADE_E2VID = 3,
+                EVR_ARCH_ETNET = 4 };
 enum evr_norm { EVR_NORM_NONE = 0, EVR_NORM_BN = 1,
                 EVR_NORM_IN = 2 /* submodules.py:22-23,160-162: running-statistics InstanceNorm in the conv layers (folded),
                                    true InstanceNorm2d inside the residual blocks */ };

@@ -290,3 +290,100 @@ class SpadeE2vidOracle:
         self.states = [s0, s1, s2, s3]
         self.prev_recs = y
         return y.mean(1, keepdim=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ET-Net (model/eitr/): conv-LSTM encoder, three token scales through pre-norm transformer encoders/decoders, bilinear
+# upsample decoders.  TEST INFRASTRUCTURE ONLY.
+def _layer_norm(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + '.weight'], sd[p + '.bias'], 1e-5)
+
+
+def _mha(sd, p, q_in, k_in, v_in, nhead=8):
+    """nn.MultiheadAttention (batch_first=False) restated: inputs [L, N, E]; packed in_proj; softmax(q k^T / sqrt(d)) v."""
+    E = q_in.shape[-1]
+    W, b = sd[p + '.in_proj_weight'], sd[p + '.in_proj_bias']
+    q = F.linear(q_in, W[:E], b[:E]); k = F.linear(k_in, W[E:2 * E], b[E:2 * E]); v = F.linear(v_in, W[2 * E:], b[2 * E:])
+    L, N, _ = q.shape; S = k.shape[0]; d = E // nhead
+    q = q.reshape(L, N * nhead, d).transpose(0, 1); k = k.reshape(S, N * nhead, d).transpose(0, 1)
+    v = v.reshape(S, N * nhead, d).transpose(0, 1)
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / (d ** 0.5), dim=-1)
+    o = torch.bmm(att, v).transpose(0, 1).reshape(L, N, E)
+    return F.linear(o, sd[p + '.out_proj.weight'], sd[p + '.out_proj.bias'])
+
+
+def _enc_layer(sd, p, src):
+    """TransformerEncoderLayer.forward (transformer_encoder.py:64-76): pre-norm self-attention + FFN."""
+    x = _layer_norm(sd, p + '.norm1', src)
+    src2 = src + _mha(sd, p + '.self_attn', x, x, x)
+    y = _layer_norm(sd, p + '.norm2', src2)
+    return src2 + F.linear(torch.relu(F.linear(y, sd[p + '.linear1.weight'], sd[p + '.linear1.bias'])),
+                           sd[p + '.linear2.weight'], sd[p + '.linear2.bias'])
+
+
+def _dec_layer(sd, p, tgt, memory):
+    """TransformerDecoderLayer.forward (transformer_decoder.py:66-84)."""
+    x = _layer_norm(sd, p + '.norm1', tgt)
+    tgt2 = tgt + _mha(sd, p + '.self_attn', x, x, x)
+    q = _layer_norm(sd, p + '.norm21', tgt2); kv = _layer_norm(sd, p + '.norm22', memory)
+    tgt4 = tgt2 + _mha(sd, p + '.cross_attn', q, kv, kv)
+    y = _layer_norm(sd, p + '.norm3', tgt4)
+    return tgt4 + F.linear(torch.relu(F.linear(y, sd[p + '.linear1.weight'], sd[p + '.linear1.bias'])),
+                           sd[p + '.linear2.weight'], sd[p + '.linear2.bias'])
+
+
+def sine_position_table(n_position, d_hid=256):
+    """PositionalEncodingSine (position_encoding.py:14-23): float64 numpy table cast to float32."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)
+    ang = pos / np.power(10000, 2 * (j // 2) / d_hid)[None, :]
+    ang[:, 0::2] = np.sin(ang[:, 0::2]); ang[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.FloatTensor(ang)
+
+
+class ETNetOracle:
+    """EITR / mls_tpa (model/eitr/eitr.py:4-16, u_trans.py:13-123)."""
+
+    def __init__(self, sd, norm=None):
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        self.norm = norm
+        self.num_encoders = 3            # eval.py:152-153
+        self.reset_states()
+
+    def reset_states(self):
+        self.states = [None] * 3
+
+    def __call__(self, x):
+        sd, norm = self.sd, self.norm
+        x = conv_layer(sd, 'head', x, 1, 2, 'relu', norm)
+        head = x
+        blocks = []
+        for i in range(3):
+            p = f'DownsampleConv.{i}'
+            x = conv_layer(sd, p + '.conv', x, 2, 2, 'relu', norm)
+            st = conv_lstm(sd, p + '.recurrent_block', x, self.states[i]); x = st[0]
+            self.states[i] = st
+            blocks.append(x)
+        n, c, H, W = head.shape
+        words = [blocks[2].flatten(2).transpose(1, 2),                                            # nn.Unfold(1): the pixels
+                 F.conv2d(blocks[1], sd['split1.weight'], sd['split1.bias'], stride=2).flatten(2).transpose(1, 2),
+                 F.conv2d(blocks[0], sd['split2.weight'], sd['split2.bias'], stride=4).flatten(2).transpose(1, 2)]
+        pos = sine_position_table(words[0].shape[1])[None]
+        hs = []
+        for s in range(3):
+            t = (words[s] + pos).transpose(0, 1)                                                 # [L, N, E]
+            for l in range(3):
+                t = _enc_layer(sd, f'trans_encoder{s}.encoder.layers.{l}', t)
+            hs.append(t)
+        hc = []
+        for s, mem in enumerate([hs[0], hs[0], hs[1]]):
+            t = hs[s]
+            for l in range(2):
+                t = _dec_layer(sd, f'trans_decoder{s}.decoder.layers.{l}', t, mem)
+            hc.append(t)
+        t = (hs[0] + hs[1] + hs[2] + hc[0] + hc[1] + hc[2]) / 6
+        y = t.permute(1, 2, 0).reshape(n, 256, H // 8, W // 8)                                   # '(h w) n c -> n c h w'
+        for i in range(3):
+            y = upsample_conv_layer(sd, f'UpsampleConv.{i}', y + blocks[2 - i], 2, 'relu', norm)
+        return torch.sigmoid(conv_layer(sd, 'pred', y + head, 1, 0, None, norm))

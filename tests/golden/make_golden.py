@@ -456,6 +456,27 @@ def make_metrics_published():
     print(meta)
 
 
+def make_etnet():
+    """ET-Net (reference class EITR) with deterministic synthetic weights: 3 frames of one 64x96 sequence (96 tokens per
+    scale) -> images, the mean token map of the first frame, final ConvLSTM states."""
+    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=17)
+    net = ref_model.EITR({'num_bins': 5, 'norm': None})
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    net.eval()
+    F, H, W = 3, 64, 96
+    vox = synth.sparse_voxels(171, F, 5, H, W, density=0.15)
+    imgs = []
+    with torch.no_grad():
+        for f in range(F):
+            imgs.append(net(torch.from_numpy(vox[f:f + 1]))['image'].numpy())
+    st = net._states
+    out = {f'h{i}_sub': st[i][0].numpy()[:, ::4] for i in range(3)}
+    out.update({f'c{i}_sub': st[i][1].numpy()[:, ::4] for i in range(3)})
+    save_npz('etnet_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([171, F, 5, H, W]), seed=np.array(17),
+             weights_sha=np.array(weights.state_dict_digest(sd)), images=np.concatenate(imgs), **out)
+
+
 def make_spade():
     """SPADE-E2VID (reference class Unet6, exported as SpadeE2vid) with deterministic synthetic weights: 4 frames of
     one 64x96 sequence -> images, final hidden states, and the 3-channel prev_recs of the last frame."""
@@ -476,7 +497,7 @@ def make_spade():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade', 'metrics']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade', 'metrics', 'etnet']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade, 'metrics': make_metrics_published}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade, 'metrics': make_metrics_published, 'etnet': make_etnet}[w]()

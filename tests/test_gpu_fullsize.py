@@ -201,3 +201,28 @@ def test_spade_e2vid_346x260_vs_oracle():
             with torch.no_grad():
                 want = crop.crop(oracles[s](torch.from_numpy(crop.pad(v))).numpy())
             assert float(np.abs(img[s:s + 1] - want).max()) < IMG_ATOL, (f, s)
+
+
+def test_etnet_346x260_vs_oracle():
+    """ET-Net at 346x260 (pads to 352x264: 33 x 44 = 1452 tokens per scale, 23 key tiles with a ragged tail), two
+    different sequences advanced together, two frames."""
+    from evreal_amd import model, weights
+    from evreal_amd.voxel import Voxelizer
+    from oracle import model as omod, prepost as op, voxel as ov
+    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=27)
+    m = model.EITR({'num_bins': 5, 'norm': None}); m.load_state_dict(sd)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if np.asarray(v).dtype.kind == 'f'}
+    oracles = [omod.ETNetOracle(tsd), omod.ETNetOracle(tsd)]
+    H, W = 260, 346
+    crop = op.CropParams(W, H, 3)
+    vz = Voxelizer()
+    m.reset_states()
+    for f in range(2):
+        ev, cat, offs = _windows([95000 + 1000 * f + s for s in range(2)], 15000, W, H)
+        g = vz.voxelize(_d(cat[0]), _d(cat[1]), _d(cat[2]), _d(cat[3]), _d(offs), 5, (H, W))
+        img = m(g)['image'].cpu().numpy()
+        for s in range(2):
+            v = ov.events_to_voxel(*ev[s], 5, (H, W))[None]
+            with torch.no_grad():
+                want = crop.crop(oracles[s](torch.from_numpy(crop.pad(v))).numpy())
+            assert float(np.abs(img[s:s + 1] - want).max()) < IMG_ATOL, (f, s)
