@@ -821,6 +821,202 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Band kernel, 64 pixels per wave ("band2").
+//
+// conv3x3_band_kernel's wave tile is 32 pixels x 128 columns: per 16-k slab a wave reads 2 pixel fragments and 8
+// weight fragments (10 KiB) from LDS for 12 MFMAs (384 matrix-pipe cycles).  With two waves per SIMD the CU's LDS
+// moves 8 waves x 20 KiB of fragment reads plus 43 KiB of DMA writes per 1536 cycles = 132 B/clk -- above the 128 B/clk
+// the LDS delivers, which is what holds that kernel at ~75 % matrix-pipe occupancy (removing the DMA writes alone
+// buys 16 %, profiles/r02_ablate_layers.txt).  Here a wave owns TWO 32-pixel blocks (64 px x 128 columns, 8
+// accumulators): a weight fragment read once feeds both, 12 KiB of fragment reads per 24 MFMAs (-40 % LDS bytes per
+// matrix cycle).  To keep two blocks per CU with twice the pixels per block the K chunk is 16 channels: bands of
+// 272 rows x 64 B, weight tiles of 128 x 64 B in a 3-slot ring = 58 KiB; a step is still 24 MFMAs per wave between
+// barriers.  Otherwise the walk (chunk x dy x dx, counted vmcnt, validity masks) is conv3x3_band_kernel's.
+template <bool LSTM>
+__global__ __launch_bounds__(256, 2) void conv3x3_band2_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, MB = 2, NB = 4, SP = 4, RING = 3;
+    constexpr int TM = 32 * MB * WM;                // 256 output pixels per block
+    constexpr int A_ROWS = TM + 16;                 // TM + 2 source pixels needed; whole 16-row (1-KiB) DMA pieces
+    constexpr int A_PIECES = A_ROWS / 16;           // 17
+    constexpr int A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
+    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // 5 / 4 band pieces per wave
+    constexpr int NBW = (B_F4 / 64) / WM;           // 2 weight-tile pieces per wave
+    static_assert(NBW == 2 && NA_MIN == 4, "update the counted waits");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + RING * B_F4];   // [band 0 | band 1 | ring slots]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.win, H = a.hin;
+    const int hw = H * W;
+    const int M = a.n * hw;
+    const int ntiles = a.cout / (32 * NB);
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;       // band row 0 = source pixel m0 - 1 (+ dy*W)
+    const int c0 = a.c0, c1 = a.c1;
+    const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 16;
+    const int ktot = 9 * nchunks * 16;
+    const unsigned in_pix = (unsigned)M;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
+
+    // DMA pieces (piece j = wmi + jj*WM; lane -> row 16j + lane/4, 16-B slot lane%4, source slot swizzled)
+    int a_pix[NA_MAX]; unsigned a_q[NA_MAX];
+#pragma unroll
+    for (int jj = 0; jj < NA_MAX; ++jj) {
+        const int row = 16 * (wmi + jj * WM) + (lane >> 2);
+        a_pix[jj] = m0 - 1 + row;
+        a_q[jj] = (unsigned)((((lane & 3) ^ swz<16>(row)) * 4));
+    }
+    unsigned b_off[NBW];
+#pragma unroll
+    for (int jj = 0; jj < NBW; ++jj) {
+        const int row = 16 * (wmi + jj * WM) + (lane >> 2);
+        b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 3) ^ swz<16>(row)) * 4));
+    }
+    auto issue_band = [&](int cc, int dyi, int buf) {
+        int coff = cc * 16;
+        const bool second = coff >= c0;
+        const int csrc = second ? c1 : c0;
+        if (second) coff -= c0;
+        const int shift = (dyi - 1) * W;
+#pragma unroll
+        for (int jj = 0; jj < NA_MAX; ++jj) {
+            if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
+                const int pix = a_pix[jj] + shift;
+                unsigned voff = OOB_OFFSET;
+                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int t, int cc, int slot) {
+        const unsigned kofs = (unsigned)((t * nchunks + cc) * 16);
+#pragma unroll
+        for (int jj = 0; jj < NBW; ++jj) {
+            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + kofs) * 4u, 0, 0, 0);
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<16>(r);
+    f32x16 acc[MB][NB];
+    constexpr int PN = LSTM ? 1 : NB;
+    f32x16 pre[MB][PN];
+    EpiCtx ec[MB];
+    unsigned vmask[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m0 + wmi * 64 + mb * 32 + r;
+        epi_setup<NB, LSTM, false>(a, m, M, hw, n0, h, acc[mb], pre[mb], ec[mb]);
+        unsigned vm = 0;     // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
+        if (m < M) {
+            const int img = m / hw, rem = m - img * hw;
+            const int py = rem / W, px = rem - py * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vm |= 1u << t;
+            }
+        }
+        vmask[mb] = vm;
+    }
+
+    // prologue: band 0 and the first two weight tiles (bare s_barrier: __syncthreads() would drain the ring)
+    issue_band(0, 0, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            {   // weight tile of step s + 2
+                const int t2 = (t + 2) % 9;
+                int c2 = c + (t + 2) / 9;
+                if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into a free slot
+                issue_w(t2, c2, (t + 2) % 3);
+            }
+            if (t % 3 == 0) {   // the next band
+                const int d2 = (t / 3 + 1) % 3;
+                int c2 = c + (t / 3 + 1) / 3;
+                if (c2 >= nchunks) c2 = nchunks - 1;
+                issue_band(c2, d2, pa ^ ((t / 3 + 1) & 1));
+            }
+            const int ab = pa ^ ((t / 3) & 1);
+            const float4* lb = &lds[2 * A_F4 + (t % 3) * B_F4 + r * SP];
+            bf16x8 a_hi[MB], a_lo[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int i = wmi * 64 + mb * 32 + r + (t % 3);       // band row of the lane's dx neighbour
+                const int swi = swz<16>(i);
+                const float4* la = &lds[ab * A_F4 + i * SP];
+                u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * h) ^ swi]);
+                u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * h + 1) ^ swi]);
+                if (t != 4) {
+                    const bool keep = (vmask[mb] >> t) & 1u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ah[e] = keep ? ah[e] : 0u; al[e] = keep ? al[e] : 0u; }
+                }
+                a_hi[mb] = __builtin_bit_cast(bf16x8, ah); a_lo[mb] = __builtin_bit_cast(bf16x8, al);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * h) ^ sw)]);
+                const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * h + 1) ^ sw)]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+#ifdef EVR_MX8_TIMING   // timing experiment only (results are garbage): the instruction mix of an f16 + MX-fp8 split
+                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                    typedef int i32x8 __attribute__((ext_vector_type(8)));
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b_hi), __builtin_bit_cast(f16x8, a_hi[mb]), acc[mb][nb], 0, 0, 0);
+                    if (t & 1) {
+                        const u32x4_t p0 = __builtin_bit_cast(u32x4_t, b_hi), p1 = __builtin_bit_cast(u32x4_t, b_lo);
+                        const u32x4_t q0 = __builtin_bit_cast(u32x4_t, a_hi[mb]), q1 = __builtin_bit_cast(u32x4_t, a_lo[mb]);
+                        const i32x8 bb = {(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
+                        const i32x8 aa = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
+                        acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, acc[mb][nb], 0, 0, 0, 100 + h, 0, 90 + h);
+                    }
+#else
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo[mb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi[mb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi[mb], acc[mb][nb], 0, 0, 0);
+#endif
+                }
+            }
+            // the NEXT step's weight tile (and, before a band switch, the next band) must have landed; the tile
+            // requested in this step (and behind it the band pieces) may stay in flight -- loads complete in order
+            if (t % 3 == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) epi_finish<NB, LSTM, false, true>(a, ec[mb], n0, h, acc[mb], pre[mb], img_out);
+#endif
+}
+
+template <bool LSTM>
+static int launch_band2(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int M = a.n * a.hm * a.wm;
+    const int total = ((M + 255) / 256) * (a.cout / 128);
+    hipLaunchKernelGGL((conv3x3_band2_kernel<LSTM>), dim3(total), dim3(256), 0, stream, d_args, img);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Programmed band kernel: the k5 stride-2 encoder convolutions in split-bf16 on PACKED activations.
 //
 // Space-to-depth turns conv(k5, s2) into a 3x3 stride-1 convolution over 2x2 pixel blocks with 4*Cin channels
@@ -1038,7 +1234,9 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
         // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
         static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
+        static const int band2 = getenv("EVR_BAND2") ? atoi(getenv("EVR_BAND2")) : 1;
         if (a.epi == EPI_LSTM) {
+            if (band2 && a.c0 % 16 == 0 && a.c1 % 16 == 0) return launch_band2<true>(a, d_args, stream, img);
             if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);
             if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
             if (cfg == 82) return launch_band<8, 2, true>(a, d_args, stream, img);

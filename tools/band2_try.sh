@@ -1,0 +1,6 @@
+run() { python bench.py --sub --no-overlap --profile-filter '' --steps 6 --warmup 2 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$1', 'fps', d['value'], ' '.join(f\"{k}={v['us']:.0f}\" for k, v in d['roofline']['layers'].items()))"; }
+mkdir -p gpurun_out
+EVR_BAND2=1 run "$1" | tee -a gpurun_out/band2.txt
