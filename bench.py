@@ -11,7 +11,7 @@ torch.distributed.run, one process per GPU, RCCL); under a launcher the flag mus
 
 A step = one frame for each of S independent synthetic sequences per GPU (sequences shard across GPUs,
 SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
-forward (split-bf16 x3 MFMA, fp32 accumulate; EVR_FP32=1: exact fp32 MFMA) -> crop -> robust percentile
+forward (split f16 + MX-fp8 MFMA, fp32 accumulate; EVR_FP32=1: exact fp32 MFMA) -> crop -> robust percentile
 normalization -> clip -> MSE + SSIM + LPIPS against the reference frame (LPIPS = AlexNet v0.1 structure on
 synthetic weights unless EVREAL_LPIPS_WEIGHTS names a real state_dict: they cannot be downloaded here).
 The evaluation half of a frame (robust norm, MSE/SSIM, LPIPS) runs on a second HIP stream and overlaps the
@@ -361,10 +361,11 @@ def main():
         rl_ms = sum(p['ms'] for p in lstm)
         rl_launches = sum(p['launches'] for p in lstm)
         achieved = rl_flops / (rl_ms * 1e-3) / 1e12 if rl_ms > 0 else 0.0
-        # arithmetic mode of the 32-channel-chunk convolutions (model.cpp finish_conv): default split-bf16
-        # (x = hi + lo, three bf16 MFMA products, fp32 accumulate: fp32-equivalent to ~1e-6 relative);
-        # EVR_FP32=1 selects the exact fp32 MFMA.  `achieved` counts ALGORITHMIC (direct convolution) flops in
-        # both modes; in split mode the matrix cores execute 3x that, reported as mfma_issue_*.
+        # arithmetic mode of the 32-channel-chunk convolutions (model.cpp finish_conv): default split f16 + MX-fp8 (csrc/conv.h)
+        # (f16 main product + one MX-scaled fp8 MFMA for the two cross terms per 32 k, fp32 accumulate: ~2^-16 relative per
+        # product term); EVR_FP32=1 selects the exact fp32 MFMA.  `achieved` counts ALGORITHMIC (direct convolution)
+        # flops in both modes; in split mode the matrix pipe is busy for 2x that in f16-rate cycles (the fp8 MFMA covers
+        # its 64 k in the time of 32 f16 k), reported as mfma_issue_*; `peak` stays the f16/bf16 dense peak.
         x3 = not os.environ.get('EVR_FP32')
         peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_note = measured_traffic() if (x3 and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
@@ -372,7 +373,7 @@ def main():
             "metric": "reconstructed frames/sec + Mevents/sec voxelized, E2VID %dx%d B=5" % (W_, H_),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16x3" if x3 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16+mxfp8" if x3 else "f32", "data": "synthetic",
             "mevents_per_s": round(frames * K_EVENTS / elapsed / 1e6, 2),
             "model_tflops": round(flops_step * K * world / elapsed / 1e12, 2),
             "rccl_ranks": world if dist is not None else 0,
@@ -388,14 +389,15 @@ def main():
                                   "count": int(tot[0, 3])}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": ("conv3x3_band_kernel<WM=4,RING=2,LSTM=true> (ConvLSTM gate convolutions)" if x3 else
+                         "kernel": ("conv3x3_wide_kernel<LSTM=true> (ConvLSTM gate convolutions, 256 x 256 block tiles)" if x3 else
                                     "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=0> (ConvLSTM gate convolutions)"),
-                         "arithmetic": ("split bf16: x=hi+lo, w=hi+lo, acc += lo*hi + hi*lo + hi*hi on "
-                                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations stored PACKED (bf16 hi|lo "
-                                        "per 8 channels) by the producer" if x3 else
+                         "arithmetic": ("split: x = hi + lo8*2^-12, w = hi + wlo8*2^-(e+12) (f16 hi, fp8 e4m3 residuals); per 32 k "
+                                        "acc += hi_w*hi_x on 2 x v_mfma_f32_32x32x16_f16 + (w8*lo8 + wlo8*x8) on 1 x "
+                                        "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; activations stored PACKED (f16 hi | "
+                                        "fp8 lo8 | fp8 x8 per 16 channels) by the producer" if x3 else
                                         "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"),
-                         "mfma_issue_tflops": round(achieved * (3 if x3 else 1), 2),
-                         "mfma_issue_frac": round(achieved * (3 if x3 else 1) / peak, 4),
+                         "mfma_issue_tflops": round(achieved * (2 if x3 else 1), 2),
+                         "mfma_issue_frac": round(achieved * (2 if x3 else 1) / peak, 4),
                          "streams": ("2: reconstruction | evaluation (robust norm, MSE/SSIM, LPIPS of the previous frame) -- "
                                      "the timed launches share the chip with the evaluation kernels"
                                      if prof_single is not None else "1"),

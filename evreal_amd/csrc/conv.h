@@ -1,11 +1,17 @@
 // Convolution building blocks of the recurrent networks (NHWC activations on device).
 //
-// Activation formats.  PLAIN: fp32, pixel-major, channels contiguous.  PACKED (split-bf16 mode, tensors that feed
-// the matrix cores): same 4 bytes per channel, but every group of 8 channels (32 B) holds the bf16 'hi' halves of
-// its 8 values (16 B) followed by the 8 bf16 'lo' halves (16 B), value ~ hi + lo (both RNE, 16 significant bits).
-// A 16-B slot of a pixel row is then directly one MFMA operand (8 k-values), so the consumer's main loop has no
-// conversion work; the PRODUCER's epilogue does the split once per element instead of once per (tap, N tile).
-// Weight rows use the same layout per 8 k-values.
+// Activation formats.  PLAIN: fp32, pixel-major, channels contiguous.  PACKED (split mode, tensors that feed the
+// matrix cores): the same 4 bytes per channel, laid out per group of 16 channels (64 B) as
+//     16 x f16  hi  = RNE_f16(x)                                  (32 B)
+//     16 x fp8  lo8 = RNE_e4m3((x - hi) * 2^12)                   (16 B)   value ~ hi + lo8 * 2^-12
+//     16 x fp8  x8  = RNE_e4m3(x)                                 (16 B)   (only ever multiplied by a weight's low part)
+// (fp8 = OCP e4m3fn, saturating at +-448; hi saturates at +-65504).  A 16-B slot of a pixel row is then directly an
+// MFMA operand piece, so the consumer's main loop has no conversion work; the PRODUCER's epilogue does the split
+// once per element instead of once per (tap, N tile).  Weight rows use the same 64-B groups per 16 k-values with
+//     hi = RNE_f16(w),  w8 = RNE_e4m3(w * 2^e),  wlo8 = RNE_e4m3((w - hi) * 2^(e + 12)),  e chosen per tensor.
+// Arithmetic per 32 k (conv.hip): acc += hi_x . hi_w  (two v_mfma_f32_32x32x16_f16) + 2^-(12+e) * (lo8 . w8 + x8 . wlo8)
+// (one MX-scaled v_mfma_scale_f32_32x32x64_f8f6f4 whose K = 64 is [lo8 | x8] against [w8 | wlo8]; the block
+// scales 2^-12 and 2^-e are the instruction's E8M0 operands) -- 2/3 of the matrix cycles of three bf16 products.
 #pragma once
 #include "common.h"
 #include <cstdlib>
@@ -77,21 +83,22 @@ struct ConvArgs {
     // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
     const float* pred_w; float pred_b; int pred_sigmoid;
     int crop_h, crop_w, crop_y0, crop_x0;
-    int x3;                   // weights are in the split-bf16 layout (pack_x3); activations are split on the fly unless
-    int in_packed;            //   in0/in1 are PACKED tensors (then the main loop feeds LDS slots straight to the MFMAs)
+    int x3;                   // weights are in the split layout (pack_split_weights) and in0/in1 are PACKED tensors:
+    int in_packed;            //   the main loop feeds LDS slots straight to the MFMAs
+    int mx_sa, mx_sb;         // E8M0 block scales of the fp8 correction MFMA: 127 - 12 (activations), 127 - e (weights)
     int out_packed;           // write `out` PACKED (n_valid and cout_total multiples of 8)
     int res_packed, padd_packed, state_packed;   // format of residual / post_add / the ConvGRU hidden state
     // space-to-depth form of a k5 stride-2 convolution for the programmed band kernel (conv.hip): the input seen as
     // [n, hin/2, win/2, 4*c0] (2x2 pixel blocks -> channels, phase-major) makes it a 3x3 stride-1 convolution whose
     // unused (tap, phase) chunks are simply absent from the step program
-    const float* wgt2;        // [cout][9][4*c0] weights of that form (same split-bf16 packing), or null
+    const float* wgt2;        // [cout][9][4*c0] weights of that form (same split packing), or null
     const unsigned* prog;     // device: BAND_PROG_MAX packed entries (see above)
     int prog_steps;
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };
 
-// fp32 -> bf16 bits, round to nearest even
+// fp32 -> bf16 bits, round to nearest even (head_mfma_kernel's weight fragments)
 inline unsigned short bf16_rne(float f) {
     unsigned u; memcpy(&u, &f, 4);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
@@ -100,22 +107,107 @@ inline unsigned short bf16_rne(float f) {
 }
 inline float bf16_to_f32(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
-// Split-bf16 weight packing (host side, at model creation): every aligned group of 8 k-values of a row becomes
-// 8 bf16 'hi' followed by 8 bf16 'lo' (w ~ hi + lo, both RNE) in the same 32 bytes -- the PACKED layout above, so
-// the kernel's tile loader does not change.
-inline void pack_x3(std::vector<float>& w) {
-    for (size_t base = 0; base + 8 <= w.size(); base += 8) {
-        unsigned short hi[8], lo[8];
-        for (int k = 0; k < 8; ++k) {
-            hi[k] = bf16_rne(w[base + k]);
-            lo[k] = bf16_rne(w[base + k] - bf16_to_f32(hi[k]));
-        }
-        memcpy(&w[base], hi, 16);
-        memcpy(&w[base + 4], lo, 16);
+// fp32 -> IEEE half bits, round to nearest even, saturating at +-65504 (what v_cvt_f16_f32 gives after a clamp)
+inline unsigned short f16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned short sign = (unsigned short)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);                       // NaN
+    float af; memcpy(&af, &u, 4);
+    if (af >= 65504.0f) return (unsigned short)(sign | 0x7bffu);
+    if (u < 0x38800000u) {                                                             // below 2^-14: half subnormals, step 2^-24
+        const float scaled = af * 16777216.0f;
+        const float r = __builtin_nearbyintf(scaled);                                  // RNE in the default rounding mode
+        return (unsigned short)(sign | (unsigned)r);                                   // 1024 = smallest normal: still right
+    }
+    unsigned hbits = ((((u >> 23) - 112u) << 10) | ((u & 0x7fffffu) >> 13));
+    const unsigned rem = u & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (hbits & 1u))) ++hbits;
+    return (unsigned short)(sign | hbits);
+}
+inline float f16_to_f32(unsigned short hb) {
+    const unsigned sign = ((unsigned)hb & 0x8000u) << 16, e = (hb >> 10) & 31u, m = hb & 0x3ffu;
+    float f;
+    if (e == 0) { f = (float)m * (1.0f / 16777216.0f); unsigned u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+    const unsigned u = sign | (e == 31 ? 0x7f800000u : ((e + 112u) << 23)) | (m << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+// fp32 -> OCP e4m3fn bits (bias 7, 3 mantissa bits, no inf, max 448), round to nearest even, saturating
+inline unsigned char e4m3_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned char sign = (unsigned char)((u >> 24) & 0x80u);
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return (unsigned char)(sign | 0x7fu);                          // NaN
+    float af; memcpy(&af, &u, 4);
+    if (af >= 448.0f) return (unsigned char)(sign | 0x7eu);
+    if (af < 0.015625f) return (unsigned char)(sign | (unsigned)__builtin_nearbyintf(af * 512.0f));   // subnormals, step 2^-9
+    unsigned b = ((((u >> 23) - 120u) << 3) | ((u & 0x7fffffu) >> 20));
+    const unsigned rem = u & 0xfffffu;
+    if (rem > 0x80000u || (rem == 0x80000u && (b & 1u))) ++b;
+    if (b > 0x7eu) b = 0x7eu;
+    return (unsigned char)(sign | b);
+}
+inline float e4m3_to_f32(unsigned char b) {
+    const unsigned e = (b >> 3) & 15u, m = b & 7u;
+    float f = (e == 0) ? (float)m * (1.0f / 512.0f) : __builtin_ldexpf(1.0f + (float)m * 0.125f, (int)e - 7);
+    return (b & 0x80u) ? -f : f;
+}
+inline float clampf(float v, float lim) { return v > lim ? lim : (v < -lim ? -lim : v); }
+
+constexpr int MX_LO_EXP = 12;     // lo8 = (x - hi) * 2^12
+
+// One 16-value group -> the 64-B PACKED group.  `e8` scales the plain fp8 copy (activations: 0), `elo` the residual.
+inline void pack_group16(const float* v, int e8, int elo, unsigned char* dst) {
+    unsigned short hi[16]; unsigned char lo8[16], x8[16];
+    for (int k = 0; k < 16; ++k) {
+        const float c = clampf(v[k], 65504.0f);
+        hi[k] = f16_rne(c);
+        lo8[k] = e4m3_rne(clampf(__builtin_ldexpf(c - f16_to_f32(hi[k]), elo), 448.0f));
+        x8[k] = e4m3_rne(clampf(__builtin_ldexpf(v[k], e8), 448.0f));
+    }
+    memcpy(dst, hi, 32);
+    memcpy(dst + 32, lo8, 16);
+    memcpy(dst + 48, x8, 16);
+}
+// PACKED activation codec on the host (tests; the device twin is packed.h)
+inline void pack_split_act(std::vector<float>& x) {
+    for (size_t base = 0; base + 16 <= x.size(); base += 16) {
+        unsigned char g[64];
+        // activations: [hi | lo8 = (x - hi) 2^12 | x8 = x]
+        pack_group16(&x[base], 0, MX_LO_EXP, g);
+        memcpy(&x[base], g, 64);
     }
 }
-// arithmetic mode of the 32-channel-chunk convolutions: split-bf16 unless EVR_FP32=1 (exact fp32 MFMA)
-inline bool use_split_bf16() { return getenv("EVR_FP32") == nullptr; }
+inline void unpack_split_act(const float* src, float* dst, size_t n) {
+    for (size_t base = 0; base + 16 <= n; base += 16) {
+        unsigned char g[64]; memcpy(g, src + base, 64);
+        unsigned short hi[16]; memcpy(hi, g, 32);
+        for (int k = 0; k < 16; ++k) dst[base + k] = f16_to_f32(hi[k]) + __builtin_ldexpf(e4m3_to_f32(g[32 + k]), -MX_LO_EXP);
+    }
+}
+// Split weight packing (host side, at model creation): every aligned group of 16 k-values of a row becomes
+// [16 f16 hi | 16 fp8 w8 = w 2^e | 16 fp8 wlo8 = (w - hi) 2^(e+12)] -- note the fp8 pieces are in the order that pairs
+// them with the activation group's [lo8 | x8].  Returns e: the largest exponent that keeps both fp8 pieces in range
+// (|w| 2^e <= 224; |w - hi| <= |w| 2^-11 keeps the residual below 448 too).
+inline int pack_split_weights(std::vector<float>& w) {
+    float mx = 0.f;
+    for (float v : w) { const float a = v < 0 ? -v : v; if (a == a && a > mx) mx = a; }
+    int e = 0;
+    if (mx > 0.f) { int ex; (void)__builtin_frexpf(224.0f / mx, &ex); e = ex - 1; }    // 2^e <= 224/mx
+    if (e > 24) e = 24;
+    if (e < -24) e = -24;
+    for (size_t base = 0; base + 16 <= w.size(); base += 16) {
+        unsigned char g[64];
+        pack_group16(&w[base], e, e + MX_LO_EXP, g);
+        // pack_group16 wrote [hi | residual | plain]; weights want [hi | plain (w8) | residual (wlo8)]
+        unsigned char t[16]; memcpy(t, g + 32, 16); memcpy(g + 32, g + 48, 16); memcpy(g + 48, t, 16);
+        memcpy(&w[base], g, 64);
+    }
+    return e;
+}
+// arithmetic mode of the 32-channel-chunk convolutions: split (f16 + MX-fp8 corrections) unless EVR_FP32=1 (exact fp32 MFMA)
+inline bool use_split_mode() { return getenv("EVR_FP32") == nullptr; }
 
 // kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
@@ -168,11 +260,13 @@ int launch_dynamic_filter(const float* x, const float* coeff, const float* bases
                           int c, hipStream_t stream);
 
 // Bilinear x2 (align_corners=False) of (x + skip): NHWC [n,h,w,c] -> [n,2h,2w,c]  (submodules.py:88)
-// (x_packed / skip_packed: input formats; the output is PLAIN)
-int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, hipStream_t stream);
+// (x_packed / skip_packed / out_packed: tensor formats)
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, int out_packed, hipStream_t stream);
 // out = x + y (skip_sum, model_util.py:4-5) when it cannot be fused into a producer epilogue
 // (packed: all three tensors are PACKED)
 int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream);
+// PLAIN -> PACKED (in place allowed), n a multiple of 16: the output of a VALU kernel that feeds a matrix-core convolution
+int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream);
 // SPADE-E2VID helpers (spade.hip; model/spade_e2v.py of the reference)
 struct SpadePredArgs {
     const float* x; const float* head;   // NHWC [n,hp,wp,32]

@@ -1,5 +1,5 @@
 // Convolutions of the recurrent networks on the matrix cores of gfx950: an implicit GEMM (this header) and, for the
-// 3x3 stride-1 layers in split-bf16 mode, the band kernel further down (conv3x3_band_kernel).
+// 3x3 stride-1 layers in split mode, the band kernels further down (conv3x3_band_kernel, conv3x3_wide_kernel).
 //
 // Reference ops (model/submodules.py): ConvLayer :8-35, TransposedConvLayer :38-66,
 // UpsampleConvLayer :69-97, ResidualBlock :152-184, ConvLSTM :187-245, ConvGRU :248-287; wired by
@@ -12,12 +12,15 @@
 //   MFMA        two arithmetic modes on the same tiles (template X3):
 //               fp32   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (157 TF peak) -- FireNet (16-channel chunks)
 //                      and the reference mode (EVR_FP32=1);
-//               x3     split-bf16: x = hi + lo, w = hi + lo (bf16 each, RNE), acc += hi*hi + hi*lo + lo*hi on
-//                      v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 k instead of
-//                      8 x 64 cycles (5.3x fewer matrix-pipe cycles).  Dropped terms are 2^-16 relative; measured
-//                      through a 30-frame recurrence the image error is 2.5e-6 (gate 1e-4, plain bf16: 1.8e-3).
-//                      Weights are pre-split on the host into the same 128-B-per-row tile (32 hi | 32 lo), so the
-//                      loader is unchanged; activations are split in registers after the fragment read
+//               split  (conv.h) x = hi + lo8 2^-12, w = hi + wlo8 2^-(e+12) with f16 'hi' halves (RNE) and fp8 e4m3
+//                      residuals: acc += hi_w*hi_x on v_mfma_f32_32x32x16_f16, and the two cross terms w8*lo8 + wlo8*x8
+//                      (w8, x8 = fp8 copies of the values) on ONE MX-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per 32 k,
+//                      fp32 accumulation: 2 x 32 + 64 matrix cycles per 32 k instead of 16 x 64 (8x fewer), and 2/3 of
+//                      the three-bf16-product split this mode replaced.  Every product term carries a relative error
+//                      of ~2^-16; measured through a 60-frame recurrence the image error is 6e-5 of a range-3 image
+//                      (tools/split_scheme_sim.py; gate 1e-4; three bf16 products 1.7e-5, plain bf16 9e-3).
+//                      Weights are pre-split on the host, activations by the PRODUCING kernel's epilogue (PACKED
+//                      format): the main loop feeds 16-B LDS slots straight to the MFMAs
 //   tile        block = WM waves stacked along M; a wave owns 32 pixels x (NB*32) channels, i.e. NB
 //               accumulators of 16 VGPRs; for ConvLSTM NB = 4 and the weight rows are permuted so
 //               the four 32-column blocks are the in/remember/out/cell gates of the SAME 32 hidden
@@ -44,11 +47,44 @@ namespace evr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// Split arithmetic (conv.h), one 32 x 32 block x 32 k.  A PACKED row chunk of 32 k is 8 slots of 16 B:
+//   slots 0,1 = f16 hi of k 0-15, slot 2 = fp8 lo8 (w8) of k 0-15, slot 3 = fp8 x8 (wlo8) of k 0-15, slots 4-7 = k 16-31.
+// Lane half h takes slot 4s + h for the f16 MFMA of group s, and slots 2 + h, 6 + h for the fp8 MFMA: its 32 k-values
+// there are [lo8 of k 0-31] (h = 0) against [w8] or [x8 of k 0-31] (h = 1) against [wlo8].
+struct SplitFrag { u32x4_t h0, h1, f0, f1; };
+__device__ __forceinline__ SplitFrag ld_split(const float4* row, int h, int sw) {
+    SplitFrag f;
+    f.h0 = __builtin_bit_cast(u32x4_t, row[(h) ^ sw]);
+    f.h1 = __builtin_bit_cast(u32x4_t, row[(4 + h) ^ sw]);
+    f.f0 = __builtin_bit_cast(u32x4_t, row[(2 + h) ^ sw]);
+    f.f1 = __builtin_bit_cast(u32x4_t, row[(6 + h) ^ sw]);
+    return f;
+}
+__device__ __forceinline__ void zero_unless(SplitFrag& f, bool keep) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f.h0[e] = keep ? f.h0[e] : 0u; f.h1[e] = keep ? f.h1[e] : 0u; f.f0[e] = keep ? f.f0[e] : 0u; f.f1[e] = keep ? f.f1[e] : 0u; }
+}
+__device__ __forceinline__ i32x8 cat8(u32x4_t p, u32x4_t q) {
+    typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(i32x8, (u32x8_t)__builtin_shufflevector(p, q, 0, 1, 2, 3, 4, 5, 6, 7));   // a register sequence, no copies
+}
+// acc += W . X over the chunk; the weights are the instruction's first operand (acc holds C^T, see the epilogue)
+__device__ __forceinline__ f32x16 mma_split(f32x16 acc, const SplitFrag& w, const SplitFrag& x, int sc_w, int sc_x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(w.f0, w.f1), cat8(x.f0, x.f1), acc, 0, 0, 0, sc_w, 0, sc_x);
+#endif
+    return acc;
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// Gate activations.  FAST (split-bf16 mode): v_exp_f32 / v_rcp_f32 forms, absolute error ~2e-7 -- an order below the
-// mode's own 2^-17 input rounding; the exact-fp32 mode keeps the libm-grade functions.
+// Gate activations.  FAST (split mode): v_exp_f32 / v_rcp_f32 forms, absolute error ~2e-7 -- an order below the
+// mode's own 2^-16 input rounding; the exact-fp32 mode keeps the libm-grade functions.
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
     if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     else return 1.0f / (1.0f + expf(-x));
@@ -107,8 +143,11 @@ __device__ __forceinline__ void out_addr(const ConvArgs& a, const EpiCtx& ec, in
 }
 
 template <int NB, bool LSTM, bool GROUPED>
+__device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f32x16 (&pre)[LSTM ? 1 : NB], const EpiCtx& ec);
+
+template <int NB, bool LSTM, bool GROUPED>
 __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int hw, int n0, int h, f32x16 (&acc)[NB],
-                                          f32x16 (&pre)[LSTM ? 1 : NB], EpiCtx& ec, bool lane_ok = true) {
+                                          f32x16 (&pre)[LSTM ? 1 : NB], EpiCtx& ec, bool lane_ok = true, bool prefetch = true) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -117,7 +156,6 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[nb][4 * q + j] = b4[j];
         }
-    const int epi = a.epi;
     ec.m = m; ec.mvalid = lane_ok && m < M;
     ec.direct = (a.os == 1 && a.hout == a.hm && a.wout == a.wm);
     ec.e_img = 0; ec.e_my = 0; ec.e_mx = 0;
@@ -127,13 +165,20 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
         const int rem = mm - ec.e_img * hw;
         ec.e_my = rem / a.wm; ec.e_mx = rem - ec.e_my * a.wm;
     }
+    ec.lstm_o = (unsigned)(ec.mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
+    if (prefetch) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
+}
+
+// the epilogue's operand loads (cell state / residual / fused skip) into `pre`; see epi_setup
+template <int NB, bool LSTM, bool GROUPED>
+__device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f32x16 (&pre)[LSTM ? 1 : NB], const EpiCtx& ec) {
+    const int epi = a.epi;
     const unsigned ct = (unsigned)a.cout_total;
     const int nvalid = a.n_valid;
     const bool gru = (epi == EPI_GRU_ZR || epi == EPI_GRU_OUT);
     const bool res = (epi == EPI_RESIDUAL_RELU);
     constexpr int PN = LSTM ? 1 : NB;
     const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
-    ec.lstm_o = (unsigned)(ec.mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
     if (pre_ptr && !(a.debug_ablate & 16)) {   // (bit 4 of EVR_ABLATE: timing without the operand loads)
         // The loads are issued back to back and their RAW bits parked in `pre` (PACKED operands are decoded in
         // epi_finish): anything that consumes a value here, or a per-lane branch around a load, makes hipcc wait
@@ -154,7 +199,7 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
                     if (c4 - 4 * h < nvalid) {                        // wave-uniform (n_valid is a multiple of 8 or the run is whole)
                         if (pk) {
                             const float* qp = pre_ptr + pk_off(row, c4);
-                            const f4 hi_lo = {qp[0], qp[1], qp[4], qp[5]};   // 8-B hi piece, 8-B lo piece
+                            const f4 hi_lo = {qp[0], qp[1], pre_ptr[pk_lo_off(row, c4)], 0.f};   // 8-B hi piece, 4-B lo8 piece
                             v = hi_lo;
                         } else {
                             v = *(const f4*)(pre_ptr + row + (unsigned)c4);
@@ -288,8 +333,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     // the prefetched operand (raw bits from epi_setup), decoded if PACKED
                     f4 pv = {pre[nb][4 * q], pre[nb][4 * q + 1], pre[nb][4 * q + 2], pre[nb][4 * q + 3]};
                     if (has_pre && pre_pk) {
-                        const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])}, plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])};
-                        pv = unpack4(phi, plo);
+                        const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])};
+                        pv = unpack4(phi, __float_as_uint(pv[2]));
                     }
                     if (res) v += pv;
 #pragma unroll
@@ -329,7 +374,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
 
 // LSTM = true is the ConvLSTM gate convolution (its own kernel symbol: 65 % of E2VID's FLOPs, the kernel
 // bench.py's roofline block and profiles/ quote); LSTM = false carries every other epilogue.
-// X3: 0 = fp32 MFMA; 1 = split-bf16 MFMA, PLAIN activations split in registers; 2 = split-bf16 MFMA, PACKED activations
+// X3: 0 = fp32 MFMA; 2 = split arithmetic on PACKED activations (1, splitting PLAIN activations in registers, is gone:
+// VALU kernels that feed a matrix-core convolution write PACKED themselves)
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
 __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -472,6 +518,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     EpiCtx ec;
     epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
     issue(0);
     if constexpr (REGSTAGE) { store_staged(0); }
     for (int s = 0; s < nsteps; ++s) {
@@ -489,40 +536,17 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
         const float4* la = &lds[buf][(wmi * 32 + r) * SP];
         const float4* lb = &lds[buf][A_F4 + r * SP];
         if constexpr (X3 != 0) {
-            static_assert(X3 == 0 || KC == 32, "split-bf16 tiles are 32 k wide");
+            static_assert(X3 == 0 || (X3 == 2 && KC == 32), "split tiles are 32 k wide and take PACKED activations");
             // (every fragment is loaded AS float4, the LDS array's own type, and bit-cast: reads through a punned
             // pointer carry no alias with the LDS-DMA writes and hipcc then drops the vmcnt wait in front of them)
+            const SplitFrag xa = ld_split(la, h, sw);
 #pragma unroll
-            for (int slab = 0; slab < 2; ++slab) {           // two 16-k MFMA slabs per step
-                // this lane's 8 k-values = unit u of the 32-k chunk (slots 2u, 2u+1 of the row)
-                const int u = 2 * slab + h;
-                bf16x8 a_hi, a_lo;
-                if constexpr (X3 == 2) {     // PACKED activations: slot 2u = 8 hi, slot 2u+1 = 8 lo
-                    a_hi = __builtin_bit_cast(bf16x8, la[(2 * u) ^ sw]);
-                    a_lo = __builtin_bit_cast(bf16x8, la[(2 * u + 1) ^ sw]);
-                } else {                     // PLAIN activations: split x = hi + lo in registers
-                    const float4 x0 = la[(2 * u) ^ sw], x1 = la[(2 * u + 1) ^ sw];
-                    u32x4_t ah, al;
-                    ah[0] = cvt_pk_bf16(x0.x, x0.y); ah[1] = cvt_pk_bf16(x0.z, x0.w);
-                    ah[2] = cvt_pk_bf16(x1.x, x1.y); ah[3] = cvt_pk_bf16(x1.z, x1.w);
-                    al[0] = cvt_pk_bf16(x0.x - __uint_as_float(ah[0] << 16), x0.y - __uint_as_float(ah[0] & 0xffff0000u));
-                    al[1] = cvt_pk_bf16(x0.z - __uint_as_float(ah[1] << 16), x0.w - __uint_as_float(ah[1] & 0xffff0000u));
-                    al[2] = cvt_pk_bf16(x1.x - __uint_as_float(ah[2] << 16), x1.y - __uint_as_float(ah[2] & 0xffff0000u));
-                    al[3] = cvt_pk_bf16(x1.z - __uint_as_float(ah[3] << 16), x1.w - __uint_as_float(ah[3] & 0xffff0000u));
-                    a_hi = __builtin_bit_cast(bf16x8, ah); a_lo = __builtin_bit_cast(bf16x8, al);
+            for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (GROUPED) {
+                    if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
                 }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if constexpr (GROUPED) {
-                        if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
-                    }
-                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
-                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
-                    // weights are the A operand (rows), activations the B operand (columns): acc = C^T (see epilogue)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
-                }
+                const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+                acc[nb] = mma_split(acc[nb], wb, xa, mx_sb, mx_sa);
             }
         } else {
 #pragma unroll
@@ -552,11 +576,11 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 3x3 stride-1 'same' convolution (ConvLSTM gates, residual blocks) in split-bf16 on PACKED activations with the
+// 3x3 stride-1 'same' convolution (ConvLSTM gates, residual blocks) in split arithmetic on PACKED activations with the
 // input rows RESIDENT in LDS -- the "band" kernel.
 //
 // The implicit-GEMM kernel above re-fetches the A tile for each of the 9 taps (L2 -> LDS traffic 32 flop/B: at the
-// split-bf16 MFMA rate the L2 cannot keep up).  Here a block owns TM = 256 consecutive pixels (flattened n*H*W) and
+// split MFMA rate the L2 cannot keep up).  Here a block owns TM = 256 consecutive pixels (flattened n*H*W) and
 // 128 output columns, and walks K as  chunk (32 channels) x dy x dx:
 //   A   for (chunk, dy) the TM+2 source pixels [m0 + dy*W - 1, m0 + dy*W + TM + 1) are ONE contiguous run of pixel
 //       rows -> loaded once (double-buffered "band"), and the three dx taps read it at row offsets 0,1,2.  Pixels
@@ -571,7 +595,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
 // never dx = -1 -- are dropped at COMPILE time (no branches in the step): 1 = block nb is phase (nb >> 1, nb & 1)
 // [32 columns per phase], 2 = blocks {0,1} px = 0, {2,3} px = 1 [64 columns per phase; py is per tile], 0 = unknown.
 template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false, int PHASES = 0>
-__global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int NB = 4, SP = 8;
@@ -666,7 +690,9 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
     EpiCtx ec;
     const int idx = wmi * 32 + r;                          // lane's row of the tile; its output pixel is m0 + idx - SHIFT
     const bool lane_ok = !OVL || (idx >= 1 && idx <= TM - 2);
-    epi_setup<NB, LSTM, GROUPED>(a, m0 + idx - SHIFT, M, hw, n0, h, acc, pre, ec, lane_ok);
+    // (only the ConvLSTM cell state -- 16 registers -- is requested a main loop early; the 64 registers of a residual /
+    // skip operand are loaded in the epilogue: the split fragments of a step already take 80)
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + idx - SHIFT, M, hw, n0, h, acc, pre, ec, lane_ok, LSTM);
 
     // ConvTranspose2d(k5, s2) as a 3x3 conv whose N is phase-major (model.cpp prep_tconv): a (tap, phase) pair the
     // transposed kernel does not connect has a zero weight block.  tap_use[t] = phases of THIS N tile that use tap t:
@@ -702,6 +728,7 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
 #else
     constexpr int ablate = 0;
 #endif
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
     // prologue: band 0 and the first RING-1 weight tiles
     // (bare s_barrier below: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
     issue_band(0, 0, 0, band_use(0));
@@ -733,7 +760,7 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
                 if (c2 >= nchunks) c2 = nchunks - 1;
                 issue_band(c2, d2, (pa ^ ((t / 3 + 1) & 1)), band_use(d2));
             }
-            // ---- 24 MFMAs on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
+            // ---- 12 MFMAs (8 f16 + 4 fp8) on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
             const int ab = pa ^ ((t / 3) & 1);
             int i = idx + (t % 3) - SHIFT;                  // band row of the lane's (dx) neighbour
             if constexpr (OVL) i = i < 0 ? 0 : (i > TM - 1 ? TM - 1 : i);   // (only the two non-storing edge lanes clamp)
@@ -743,29 +770,17 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
             const bool keep = (vmask >> t) & 1u;
             const int use_t = tap_use(t);
             if (!GROUPED || use_t) {       // block-uniform: a tap no phase of this tile uses is skipped whole
-#pragma unroll
-            for (int slab = 0; slab < 2; ++slab) {
-                const int u = 2 * slab + h;
-                u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * u) ^ swi]);
-                u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * u + 1) ^ swi]);
-                if (t != 4 && !(ablate & 8)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ah[e] = keep ? ah[e] : 0u; al[e] = keep ? al[e] : 0u; }
-                }
-                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
+                SplitFrag xa = ld_split(la, h, swi);
+                if (t != 4 && !(ablate & 8)) zero_unless(xa, keep);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     // (without PHASES a tap used by only SOME phases of the tile still runs all four blocks: the unused
                     // ones multiply zero weights; RUNTIME per-block branches cut the step into 3-MFMA fragments)
                     if constexpr (PHASES == 1) { if ((t / 3 == 0 && (nb >> 1) == 1) || (t % 3 == 0 && (nb & 1) == 1)) continue; }
                     if constexpr (PHASES == 2) { if (t % 3 == 0 && (nb >> 1) == 1) continue; }
-                    const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
-                    const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
+                    const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+                    acc[nb] = mma_split(acc[nb], wb, xa, mx_sb, mx_sa);
                 }
-            }
             }
             // ---- the NEXT step's weight tile (and, before a band switch, the next band) must have landed; what was
             // requested after them may stay in flight (loads complete in order): NBW, plus >= NA_MIN band pieces
@@ -789,6 +804,7 @@ __global__ __launch_bounds__(64 * WM) void conv3x3_band_kernel(const ConvArgs* _
         }
     }
     if (ablate & 4) return;
+    if constexpr (!LSTM) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
     epi_finish<NB, LSTM, GROUPED, true>(a, ec, n0, h, acc, pre, img_out);
 #endif
 }
@@ -804,7 +820,7 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
     return EVR_OK;
 }
 
-// the band kernel takes: split-bf16 on PACKED inputs, 3x3 taps in row-major order, stride 1 on the input's own grid,
+// the band kernel takes: split arithmetic on PACKED inputs, 3x3 taps in row-major order, stride 1 on the input's own grid,
 // N a multiple of 128, and enough pixels to fill the chip with 256-pixel tiles
 static bool band_eligible(const ConvArgs& a, int kc) {
     static const bool off = getenv("EVR_NO_BAND") != nullptr;
@@ -821,37 +837,37 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Band kernel, 64 pixels per wave ("band2").
+// Band kernel, 256 pixels x 256 columns per block ("wide band").
 //
-// conv3x3_band_kernel's wave tile is 32 pixels x 128 columns: per 16-k slab a wave reads 2 pixel fragments and 8
-// weight fragments (10 KiB) from LDS for 12 MFMAs (384 matrix-pipe cycles).  With two waves per SIMD the CU's LDS
-// moves 8 waves x 20 KiB of fragment reads plus 43 KiB of DMA writes per 1536 cycles = 132 B/clk -- above the 128 B/clk
-// the LDS delivers, which is what holds that kernel at ~75 % matrix-pipe occupancy (removing the DMA writes alone
-// buys 16 %, profiles/r02_ablate_layers.txt).  Here a wave owns TWO 32-pixel blocks (64 px x 128 columns, 8
-// accumulators): a weight fragment read once feeds both, 12 KiB of fragment reads per 24 MFMAs (-40 % LDS bytes per
-// matrix cycle).  To keep two blocks per CU with twice the pixels per block the K chunk is 16 channels: bands of
-// 272 rows x 64 B, weight tiles of 128 x 64 B in a 3-slot ring = 58 KiB; a step is still 24 MFMAs per wave between
-// barriers.  Otherwise the walk (chunk x dy x dx, counted vmcnt, validity masks) is conv3x3_band_kernel's.
+// With the split arithmetic at 2/3 of the matrix cycles, conv3x3_band_kernel's 32-pixel x 128-column wave tile reads
+// 20 KiB of fragments from LDS per 512 matrix cycles.  Here a wave owns TWO 32-pixel blocks (64 px x 128 columns, 8
+// accumulators: a weight fragment read once feeds both -> 24 KiB per 1024 cycles), and the block is 4 (M) x 2 (N) waves
+// over ONE pixel band: 256 pixels x 256 columns, 2 bands of 264 rows x 128 B + a 2-slot ring of 256 x 128 B weight
+// tiles = 131 KiB, one block of 8 waves per CU (two waves per SIMD).  The band is fetched once for 256 columns instead
+// of 128.  The walk (chunk x dy x dx, counted vmcnt, validity masks) is conv3x3_band_kernel's.  Epilogue operands
+// (cell state / residual / fused skip) are loaded in the epilogue, one 32-pixel block at a time: with 128 accumulator
+// registers there is no room to park them during the main loop.
 template <bool LSTM>
-__global__ __launch_bounds__(256, 2) void conv3x3_band2_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
-    constexpr int WM = 4, MB = 2, NB = 4, SP = 4, RING = 3;
-    constexpr int TM = 32 * MB * WM;                // 256 output pixels per block
-    constexpr int A_ROWS = TM + 16;                 // TM + 2 source pixels needed; whole 16-row (1-KiB) DMA pieces
-    constexpr int A_PIECES = A_ROWS / 16;           // 17
-    constexpr int A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
-    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // 5 / 4 band pieces per wave
-    constexpr int NBW = (B_F4 / 64) / WM;           // 2 weight-tile pieces per wave
-    static_assert(NBW == 2 && NA_MIN == 4, "update the counted waits");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + RING * B_F4];   // [band 0 | band 1 | ring slots]
+    constexpr int WM = 4, WN = 2, NW = WM * WN, MB = 2, NB = 4, SP = 8;
+    constexpr int TM = 32 * MB * WM, TN = 32 * NB * WN;   // 256 x 256
+    constexpr int A_ROWS = TM + 8;                  // TM + 2 source pixels needed; whole 8-row (1-KiB) DMA pieces
+    constexpr int A_PIECES = A_ROWS / 8;            // 33
+    constexpr int A_F4 = A_ROWS * SP, B_F4 = TN * SP;
+    constexpr int NA_MAX = (A_PIECES + NW - 1) / NW, NA_MIN = A_PIECES / NW;   // 5 / 4 band pieces per wave
+    constexpr int NBW = (B_F4 / 64) / NW;           // 4 weight-tile pieces per wave
+    static_assert(NBW == 4 && NA_MIN == 4, "update the counted waits");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4];   // [band 0 | band 1 | weight slot 0 | 1]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wmi = wv & 3, wni = wv >> 2;
     const int W = a.win, H = a.hin;
     const int hw = H * W;
     const int M = a.n * hw;
-    const int ntiles = a.cout / (32 * NB);
+    const int ntiles = a.cout / TN;
     int lin;
     {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
         const int total = gridDim.x, bid = blockIdx.x;
@@ -859,68 +875,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_band2_kernel(const ConvArgs* _
         lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
     const int ntile = lin % ntiles, mtile = lin / ntiles;
-    const int m0 = mtile * TM, n0 = ntile * 32 * NB;       // band row 0 = source pixel m0 - 1 (+ dy*W)
+    const int m0 = mtile * TM, n0 = ntile * TN;            // band row 0 = source pixel m0 - 1 (+ dy*W)
+    const int n0w = n0 + wni * 32 * NB;                    // this wave's 128 columns
     const int c0 = a.c0, c1 = a.c1;
-    const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 16;
-    const int ktot = 9 * nchunks * 16;
+    const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 32;
+    const int ktot = 9 * nchunks * 32;
     const unsigned in_pix = (unsigned)M;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
 
-    // DMA pieces (piece j = wmi + jj*WM; lane -> row 16j + lane/4, 16-B slot lane%4, source slot swizzled)
-    int a_pix[NA_MAX]; unsigned a_q[NA_MAX];
-#pragma unroll
-    for (int jj = 0; jj < NA_MAX; ++jj) {
-        const int row = 16 * (wmi + jj * WM) + (lane >> 2);
-        a_pix[jj] = m0 - 1 + row;
-        a_q[jj] = (unsigned)((((lane & 3) ^ swz<16>(row)) * 4));
-    }
-    unsigned b_off[NBW];
-#pragma unroll
-    for (int jj = 0; jj < NBW; ++jj) {
-        const int row = 16 * (wmi + jj * WM) + (lane >> 2);
-        b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 3) ^ swz<16>(row)) * 4));
-    }
+    // DMA pieces (piece j = wv + jj*NW; lane -> row 8j + lane/8, 16-B slot lane%8, source slot swizzled).  Pieces of one
+    // wave are 64 rows apart, so their swizzle ((row >> 1) & 7) is the same and ONE pixel / offset register serves all
+    // of them (an array per piece costs 11 more registers, which this kernel does not have)
+    const int row0 = 8 * wv + (lane >> 3);
+    const int a_pix0 = m0 - 1 + row0;
+    const unsigned a_q0 = (unsigned)((((lane & 7) ^ swz<32>(row0)) * 4));
+    const unsigned b_off0 = (unsigned)((n0 + row0) * ktot) + a_q0;
     auto issue_band = [&](int cc, int dyi, int buf) {
-        int coff = cc * 16;
+        int coff = cc * 32;
         const bool second = coff >= c0;
         const int csrc = second ? c1 : c0;
         if (second) coff -= c0;
         const int shift = (dyi - 1) * W;
 #pragma unroll
         for (int jj = 0; jj < NA_MAX; ++jj) {
-            if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
-                const int pix = a_pix[jj] + shift;
+            if (jj < NA_MIN || wv + jj * NW < A_PIECES) {      // wave-uniform
+                const int pix = a_pix0 + 64 * jj + shift;
                 unsigned voff = OOB_OFFSET;
-                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
-                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
+                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q0) * 4u;
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wv + jj * NW) * 64];
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
             }
         }
     };
     auto issue_w = [&](int t, int cc, int slot) {
-        const unsigned kofs = (unsigned)((t * nchunks + cc) * 16);
+        const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
         for (int jj = 0; jj < NBW; ++jj) {
-            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + kofs) * 4u, 0, 0, 0);
+            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wv + jj * NW) * 64];
+            // (soffset carries the wave-uniform part: row block jj and the K offset of the step)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, b_off0 * 4u, (kofs + (unsigned)(64 * jj * ktot)) * 4u, 0, 0);
         }
     };
 
     const int r = lane & 31, h = lane >> 5;
-    const int sw = swz<16>(r);
-    f32x16 acc[MB][NB];
+    const int sw = swz<32>(r);
+    // (two named accumulator sets, not acc[MB][NB]: with the large plain epilogue hipcc leaves an array of arrays in scratch)
+    f32x16 acc0[NB], acc1[NB];
     constexpr int PN = LSTM ? 1 : NB;
-    f32x16 pre[MB][PN];
-    EpiCtx ec[MB];
-    unsigned vmask[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int m = m0 + wmi * 64 + mb * 32 + r;
-        epi_setup<NB, LSTM, false>(a, m, M, hw, n0, h, acc[mb], pre[mb], ec[mb]);
-        unsigned vm = 0;     // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
+    f32x16 late[PN];             // the epilogue's operands, loaded there
+    EpiCtx ec0, ec1;
+    const int mA = m0 + wmi * 64 + r, mB = mA + 32;
+    epi_setup<NB, LSTM, false>(a, mA, M, hw, n0w, h, acc0, late, ec0, true, false);   // prefetch = false: `late` untouched
+    epi_setup<NB, LSTM, false>(a, mB, M, hw, n0w, h, acc1, late, ec1, true, false);
+    auto neighbours = [&](int m) -> unsigned {   // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
+        unsigned vm = 0;
         if (m < M) {
             const int img = m / hw, rem = m - img * hw;
             const int py = rem / W, px = rem - py * W;
@@ -930,94 +941,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_band2_kernel(const ConvArgs* _
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vm |= 1u << t;
             }
         }
-        vmask[mb] = vm;
-    }
+        return vm;
+    };
+    const unsigned vmask0 = neighbours(mA), vmask1 = neighbours(mB);
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
 
-    // prologue: band 0 and the first two weight tiles (bare s_barrier: __syncthreads() would drain the ring)
+    // prologue: band 0 and the first weight tile (bare s_barrier: __syncthreads() carries a fence hipcc lowers to vmcnt(0))
     issue_band(0, 0, 0);
     issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     for (int c = 0; c < nchunks; ++c) {
-        const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1
+        const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1; ring slot of step 9c + t is (c + t) & 1
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            {   // weight tile of step s + 2
-                const int t2 = (t + 2) % 9;
-                int c2 = c + (t + 2) / 9;
-                if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into a free slot
-                issue_w(t2, c2, (t + 2) % 3);
-            }
-            if (t % 3 == 0) {   // the next band
-                const int d2 = (t / 3 + 1) % 3;
-                int c2 = c + (t / 3 + 1) / 3;
-                if (c2 >= nchunks) c2 = nchunks - 1;
-                issue_band(c2, d2, pa ^ ((t / 3 + 1) & 1));
-            }
+            // requests of this step, spread over its four MFMA groups (a DMA piece costs ~60-180 issue cycles: in one
+            // burst at the top of the step they hold up the wave's -- and its in-phase SIMD partner's -- first MFMAs):
+            // the weight tile of step s + 1 (NBW pieces) and, at the first tap of a band, the NEXT band
+            const int t2 = (t + 1) % 9;
+            int cw = c + (t + 1) / 9;
+            if (cw >= nchunks) cw = nchunks - 1;                     // tail: harmless re-load into the free slot
+            const int d2 = (t / 3 + 1) % 3;
+            int cb = c + (t / 3 + 1) / 3;
+            if (cb >= nchunks) cb = nchunks - 1;
             const int ab = pa ^ ((t / 3) & 1);
-            const float4* lb = &lds[2 * A_F4 + (t % 3) * B_F4 + r * SP];
-            bf16x8 a_hi[MB], a_lo[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int i = wmi * 64 + mb * 32 + r + (t % 3);       // band row of the lane's dx neighbour
-                const int swi = swz<16>(i);
-                const float4* la = &lds[ab * A_F4 + i * SP];
-                u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * h) ^ swi]);
-                u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * h + 1) ^ swi]);
-                if (t != 4) {
-                    const bool keep = (vmask[mb] >> t) & 1u;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ah[e] = keep ? ah[e] : 0u; al[e] = keep ? al[e] : 0u; }
-                }
-                a_hi[mb] = __builtin_bit_cast(bf16x8, ah); a_lo[mb] = __builtin_bit_cast(bf16x8, al);
-            }
+            const float4* lb = &lds[2 * A_F4 + (pa ^ (t & 1)) * B_F4 + (wni * 32 * NB + r) * SP];
+            int i0 = wmi * 64 + r + (t % 3);                           // band rows of the lane's dx neighbours
+            asm volatile("" : "+v"(i0));     // opaque: the 24 slot addresses of the unrolled taps are recomputed, not kept live
+            const int i1 = i0 + 32;
+            SplitFrag xa0 = ld_split(&lds[ab * A_F4 + i0 * SP], h, swz<32>(i0));
+            SplitFrag xa1 = ld_split(&lds[ab * A_F4 + i1 * SP], h, swz<32>(i1));
+            if (t != 4) { zero_unless(xa0, (vmask0 >> t) & 1u); zero_unless(xa1, (vmask1 >> t) & 1u); }
+            // one block's weight fragments at a time (the scheduler would otherwise hoist all four: +48 registers, spills;
+            // reading one block ahead measured no faster)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * h) ^ sw)]);
-                const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * h + 1) ^ sw)]);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-#ifdef EVR_MX8_TIMING   // timing experiment only (results are garbage): the instruction mix of an f16 + MX-fp8 split
-                    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                    typedef int i32x8 __attribute__((ext_vector_type(8)));
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b_hi), __builtin_bit_cast(f16x8, a_hi[mb]), acc[mb][nb], 0, 0, 0);
-                    if (t & 1) {
-                        const u32x4_t p0 = __builtin_bit_cast(u32x4_t, b_hi), p1 = __builtin_bit_cast(u32x4_t, b_lo);
-                        const u32x4_t q0 = __builtin_bit_cast(u32x4_t, a_hi[mb]), q1 = __builtin_bit_cast(u32x4_t, a_lo[mb]);
-                        const i32x8 bb = {(int)p0[0], (int)p0[1], (int)p0[2], (int)p0[3], (int)p1[0], (int)p1[1], (int)p1[2], (int)p1[3]};
-                        const i32x8 aa = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
-                        acc[mb][nb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, acc[mb][nb], 0, 0, 0, 100 + h, 0, 90 + h);
-                    }
-#else
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo[mb], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi[mb], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi[mb], acc[mb][nb], 0, 0, 0);
-#endif
-                }
+                const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+                acc0[nb] = mma_split(acc0[nb], wb, xa0, mx_sb, mx_sa);
+                acc1[nb] = mma_split(acc1[nb], wb, xa1, mx_sb, mx_sa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (nb == 0) issue_w(t2, cw, pa ^ ((t + 1) & 1));      // first, so that the counted wait below can leave the band in flight
+                if (nb == 1 && t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // the NEXT step's weight tile (and, before a band switch, the next band) must have landed; the tile
-            // requested in this step (and behind it the band pieces) may stay in flight -- loads complete in order
-            if (t % 3 == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in
+            // flight (loads complete in order).  lgkmcnt(0): this wave's fragment reads have left LDS before anyone
+            // overwrites the buffers
+            if (t % 3 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) epi_finish<NB, LSTM, false, true>(a, ec[mb], n0, h, acc[mb], pre[mb], img_out);
+    epi_prefetch<NB, LSTM, false>(a, n0w, h, late, ec0);
+    epi_finish<NB, LSTM, false, true>(a, ec0, n0w, h, acc0, late, img_out);
+    epi_prefetch<NB, LSTM, false>(a, n0w, h, late, ec1);
+    epi_finish<NB, LSTM, false, true>(a, ec1, n0w, h, acc1, late, img_out);
 #endif
 }
 
 template <bool LSTM>
-static int launch_band2(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+static int launch_wide(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
-    const int total = ((M + 255) / 256) * (a.cout / 128);
-    hipLaunchKernelGGL((conv3x3_band2_kernel<LSTM>), dim3(total), dim3(256), 0, stream, d_args, img);
+    const int total = ((M + 255) / 256) * (a.cout / 256);
+    hipLaunchKernelGGL((conv3x3_wide_kernel<LSTM>), dim3(total), dim3(512), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Programmed band kernel: the k5 stride-2 encoder convolutions in split-bf16 on PACKED activations.
+// Programmed band kernel: the k5 stride-2 encoder convolutions in split arithmetic on PACKED activations.
 //
 // Space-to-depth turns conv(k5, s2) into a 3x3 stride-1 convolution over 2x2 pixel blocks with 4*Cin channels
 // (phase-major): in(2y + ky - 2, 2x + kx - 2) = block(y + dy, x + dx), phase (py, px) with 2*dy + py = ky - 2.  Of the
@@ -1127,6 +1118,7 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
     }
 
     const int nsteps = a.prog_steps;
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
     auto kofs_of = [&](unsigned e) -> int { return (int)(((e & 15u) * (unsigned)nch2 + ((e >> 8) & 255u)) * 32u); };
     {
         const unsigned e0 = entry(0), e1 = entry(1);
@@ -1148,22 +1140,12 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
         const float4* la = &lds[abuf * A_F4 + i * SP];
         const float4* lb = &lds[2 * A_F4 + slot * B_F4 + r * SP];
         const bool keep = (vmask >> t) & 1u;
+        SplitFrag xa = ld_split(la, h, swi);
+        zero_unless(xa, keep);
 #pragma unroll
-        for (int slab = 0; slab < 2; ++slab) {
-            const int u = 2 * slab + h;
-            u32x4_t ah = __builtin_bit_cast(u32x4_t, la[(2 * u) ^ swi]);
-            u32x4_t al = __builtin_bit_cast(u32x4_t, la[(2 * u + 1) ^ swi]);
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) { ah[e4] = keep ? ah[e4] : 0u; al[e4] = keep ? al[e4] : 0u; }
-            const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u) ^ sw)]);
-                const bf16x8 b_lo = __builtin_bit_cast(bf16x8, lb[nb * 32 * SP + ((2 * u + 1) ^ sw)]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[nb], 0, 0, 0);
-            }
+        for (int nb = 0; nb < NB; ++nb) {
+            const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+            acc[nb] = mma_split(acc[nb], wb, xa, mx_sb, mx_sa);
         }
         // the next step's weight tile was requested first in this step: it must have landed; a band requested after it
         // may stay in flight only if this band has further steps (bit 6)
@@ -1217,15 +1199,17 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
-    EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split-bf16 path needs 32-channel chunks");
+    EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split path needs 32-channel chunks");
     EVR_REQUIRE(a.n_valid % 4 == 0 && a.cout_total % 4 == 0, "conv_igemm: output channels %d/%d not multiples of 4 (16-B epilogue accesses)", a.n_valid, a.cout_total);
     EVR_REQUIRE(a.epi != EPI_LSTM || (a.os == 1 && a.hout == a.hm && a.wout == a.wm && a.hidden % 32 == 0),
                 "conv_igemm: the ConvLSTM epilogue writes the state grid itself (stride 1, hidden %% 32 == 0)");
     EVR_REQUIRE((a.epi != EPI_GRU_ZR && a.epi != EPI_GRU_OUT) || a.hidden % 4 == 0, "conv_igemm: ConvGRU hidden %d not a multiple of 4", a.hidden);
     const bool packed_io = a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed;
-    EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split-bf16 mode");
+    EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split mode");
+    EVR_REQUIRE(!a.x3 || a.in_packed, "conv_igemm: the split kernels take PACKED inputs");
+    EVR_REQUIRE(!a.x3 || (a.mx_sa > 0 && a.mx_sb > 0), "conv_igemm: split mode without block scales");
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
-    const int mode = a.x3 ? (a.in_packed ? 2 : 1) : 0;
+    const int mode = a.x3 ? 2 : 0;
     if (band_prog_eligible(a, kc)) {
         if (a.cout % 128 == 0) return launch_band_prog<4>(a, d_args, stream, img);
         return launch_band_prog<2>(a, d_args, stream, img);
@@ -1234,13 +1218,16 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
         // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
         static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
-        static const int band2 = getenv("EVR_BAND2") ? atoi(getenv("EVR_BAND2")) : 1;
+        // 256 x 256 block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
+        static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
+        const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
+                             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= 1024;   // >= 4 rounds of 256 blocks
+        if (wide_ok && a.epi == EPI_LSTM) return launch_wide<true>(a, d_args, stream, img);
+        // (the plain-epilogue instance needs 10 registers more than two waves per SIMD leave: not instantiated)
         if (a.epi == EPI_LSTM) {
-            if (band2 && a.c0 % 16 == 0 && a.c1 % 16 == 0) return launch_band2<true>(a, d_args, stream, img);
             if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);
             if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
-            if (cfg == 82) return launch_band<8, 2, true>(a, d_args, stream, img);
-            return launch_band<8, 3, true>(a, d_args, stream, img);
+            return launch_band<4, 2, true>(a, d_args, stream, img);
         }
         if (a.tp.ngroups > 1) {
             static const int gcfg = getenv("EVR_BAND_GCFG") ? atoi(getenv("EVR_BAND_GCFG")) : 42;
@@ -1258,16 +1245,14 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
                 if (rule && a.tp.grp_cols == 64) return launch_band<4, 2, false, true, false, 2>(a, d_args, stream, img);
                 return launch_band<4, 2, false, true>(a, d_args, stream, img);
             }
-            return launch_band<8, 3, false, true>(a, d_args, stream, img);
+            return launch_band<4, 2, false, true>(a, d_args, stream, img);
         }
         if (cfg == 43) return launch_band<4, 3, false, false, true>(a, d_args, stream, img);
         if (cfg == 42) return launch_band<4, 2, false>(a, d_args, stream, img);
-        if (cfg == 82) return launch_band<8, 2, false>(a, d_args, stream, img);
-        return launch_band<8, 3, false>(a, d_args, stream, img);
+        return launch_band<4, 2, false>(a, d_args, stream, img);
     }
     if (a.epi == EPI_LSTM) {
         EVR_REQUIRE(kc == 32, "conv_igemm: ConvLSTM needs 32-channel chunks");
-        EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 ConvLSTM kernel takes PACKED inputs");
         if (mode == 2) {
             if (wm == 8) return launch_t<32, 8, 4, true, false, true, 2>(a, d_args, stream, img);
             if (wm == 4) return launch_t<32, 4, 4, true, false, true, 2>(a, d_args, stream, img);
@@ -1282,7 +1267,6 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
     }
     if (a.tp.ngroups > 1) {   // transposed conv: column groups = sub-pixel phases
-        EVR_REQUIRE(mode != 1, "conv_igemm: the split-bf16 transposed-conv kernel takes PACKED inputs");
 #define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { if (mode == 2) return launch_t<32, WM_, NB_, false, true, false, 2>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img); }
         EVR_CASEG(4, 4) EVR_CASEG(2, 4) EVR_CASEG(1, 4) EVR_CASEG(4, 2) EVR_CASEG(2, 2) EVR_CASEG(1, 2)
         EVR_CASEG(4, 1) EVR_CASEG(2, 1) EVR_CASEG(1, 1)
@@ -1291,7 +1275,7 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         return EVR_ERR_UNSUPPORTED;
     }
     if (mode != 0) {
-#define EVR_CASEX(WM_, NB_) if (wm == WM_ && nb == NB_) { if (mode == 2) return launch_t<32, WM_, NB_, false, false, false, 2>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, false, false, 1>(a, d_args, stream, img); }
+#define EVR_CASEX(WM_, NB_) if (wm == WM_ && nb == NB_) return launch_t<32, WM_, NB_, false, false, false, 2>(a, d_args, stream, img);
         EVR_CASEX(4, 4) EVR_CASEX(2, 4) EVR_CASEX(1, 4) EVR_CASEX(4, 2) EVR_CASEX(2, 2) EVR_CASEX(1, 2)
         EVR_CASEX(4, 1) EVR_CASEX(2, 1) EVR_CASEX(1, 1)
 #undef EVR_CASEX
@@ -1410,7 +1394,8 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Head convolution on the matrix cores (split-bf16 mode, k = 5, 32 output channels): GEMM M = pixels, N = 32,
+// Head convolution on the matrix cores (split mode, k = 5, 32 output channels; its K = 125 is too ragged for the f16 + fp8
+// chunks, so this kernel keeps three bf16 products: x = hi + lo, w = hi + lo, acc += hi*hi + hi*lo + lo*hi): GEMM M = pixels, N = 32,
 // K = (bin, ky, kx).  The direct VALU kernel above spends 4000 FMAs per pixel (0.65 ms per 64 frames, the HBM
 // floor of its 761-MB output is 0.15 ms); here a pixel costs ~5 instructions per lane.
 //   K order  chosen so the two lane halves of an MFMA operand differ by ONE LDS row: the 5 kernel rows are padded
@@ -1698,7 +1683,7 @@ int launch_dynamic_filter(const float* x, const float* coeff, const float* bases
 // F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) of (x + skip), NHWC.
 __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ x, const float* __restrict__ skip,
                                                               float* __restrict__ out, int n, int h, int w, int c,
-                                                              int x_packed, int skip_packed) {
+                                                              int x_packed, int skip_packed, int out_packed) {
     const int c4n = c / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)n * 2 * h * 2 * w * c4n;
@@ -1726,36 +1711,54 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
     o4.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
     o4.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
     o4.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-    *(float4*)(out + ((((int64_t)img * 2 * h + oy) * 2 * w + ox) * c + c4 * 4)) = o4;
+    st4_any(out + (((int64_t)img * 2 * h + oy) * 2 * w + ox) * c, c4 * 4, o4, out_packed);
 }
 
-int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, hipStream_t stream) {
+int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, int out_packed, hipStream_t stream) {
     EVR_REQUIRE(c % 4 == 0, "upsample: channels %d not a multiple of 4", c);
-    EVR_REQUIRE(!(x_packed || skip_packed) || c % 8 == 0, "upsample: PACKED inputs need channels %d to be a multiple of 8", c);
+    EVR_REQUIRE(!(x_packed || skip_packed || out_packed) || c % 16 == 0, "upsample: PACKED tensors need channels %d to be a multiple of 16", c);
     const int64_t total = (int64_t)n * 4 * h * w * (c / 4);
-    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c, x_packed, skip_packed);
+    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c, x_packed, skip_packed, out_packed);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, int64_t n4, int packed) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        // 4-channel run i: PACKED tensors are addressed per 8-channel unit (the row base is the unit, c4 = 0 or 4)
-        const int64_t base = packed ? (i >> 1) * 8 : i * 4;
-        const int c4 = packed ? (int)(i & 1) * 4 : 0;
+        // 4-channel run i: PACKED tensors are addressed per 16-channel group (the row base is the group, c4 = 0..12)
+        const int64_t base = packed ? (i >> 2) * 16 : i * 4;
+        const int c4 = packed ? (int)(i & 3) * 4 : 0;
         const float4 a = ld4_any(x + base, c4, packed), b = ld4_any(y + base, c4, packed);
         st4_any(o + base, c4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w), packed);
     }
 }
 
 int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream) {
-    EVR_REQUIRE(n % 8 == 0, "add: element count not a multiple of 8");
+    EVR_REQUIRE(n % 16 == 0, "add: element count not a multiple of 16");
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, out, n / 4, packed);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
+// PLAIN -> PACKED, one 16-channel group per thread (may run in place: a thread reads its 64 B before it writes them)
+__global__ __launch_bounds__(256) void to_packed_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t groups) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        const float4* sp = (const float4*)(src + g * 16);
+        const float4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+        float* d = dst + g * 16;
+        st4_any(d, 0, v0, 1); st4_any(d, 4, v1, 1); st4_any(d, 8, v2, 1); st4_any(d, 12, v3, 1);
+    }
+}
+int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream) {
+    EVR_REQUIRE(n % 16 == 0, "to_packed: element count not a multiple of 16");
+    int64_t blocks = (n / 16 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(to_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n / 16);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, int packed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1766,16 +1769,15 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     const int ch = (int)(p % c);
     const int img = (int)(p / c);
     const float* row = src + (((int64_t)img * h + y) * w + x) * c;
-    if (packed) {   // value = hi + lo, bf16 halves at 16-bit positions ch%8 of the unit's two 16-B pieces
-        const unsigned short* u16 = (const unsigned short*)(row + (ch & ~7));
-        dst[i] = __uint_as_float((unsigned)u16[ch & 7] << 16) + __uint_as_float((unsigned)u16[8 + (ch & 7)] << 16);
-    } else {
-        dst[i] = row[ch];
-    }
+    float v = row[ch];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (packed) v = load1_packed(row, ch);
+#endif
+    dst[i] = v;
 }
 
 int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream) {
-    EVR_REQUIRE(!packed || c % 8 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c);
+    EVR_REQUIRE(!packed || c % 16 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c);
     const int64_t total = (int64_t)n * h * w * c;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c, packed);
     EVR_LAUNCH_CHECK();

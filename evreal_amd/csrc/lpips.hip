@@ -9,7 +9,7 @@
 // the oracle restatement (oracle/lpips.py) on any weights, and with pyiqa only once its weights are supplied.
 //
 // Layers: conv1 (3->64, k11 s4 p2) is a direct VALU kernel on the gray input (the three input channels are affine
-// in the same gray value); conv2..conv5 run on the convolution kernels of conv.hip (split-bf16: conv2 on the implicit
+// in the same gray value); conv2..conv5 run on the convolution kernels of conv.hip (split arithmetic: conv2 on the implicit
 // GEMM, conv3..conv5 on the band kernel; pool1/feat1.. are then PACKED tensors, conv.h); 3x3/2 max pools and the
 // per-layer score are NHWC streaming kernels (one wave per pixel for the channel norms).
 #include <cstring>
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
     st4_any(out + (((int64_t)b * ho + oy) * wo + ox) * c, c4 * 4, m, out_packed);
 }
 
-// one channel of a pixel row, PLAIN or PACKED (value = hi + lo; bf16 halves at 16-bit positions ch % 8 of the
-// 8-channel unit's two 16-B pieces)
+// one channel of a pixel row, PLAIN or PACKED
 __device__ __forceinline__ float ld1_any(const float* row, int ch, int packed) {
-    if (!packed) return row[ch];
-    const unsigned short* u16 = (const unsigned short*)(row + (ch & ~7));
-    return __uint_as_float((unsigned)u16[ch & 7] << 16) + __uint_as_float((unsigned)u16[8 + (ch & 7)] << 16);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (packed) return load1_packed(row, ch);
+#endif
+    return row[ch];
 }
 
 // ---- per-layer score: one wave per pixel -------------------------------------------------------------------------
@@ -174,7 +174,7 @@ __global__ void lpips_final_kernel(const double* __restrict__ partials, double* 
 
 constexpr int SCORE_BLOCKS = 32;
 
-struct Layer { int cin, cout, k, pad; bool x3 = false; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
+struct Layer { int cin, cout, k, pad; bool x3 = false; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
 
 }  // namespace
 
@@ -265,8 +265,8 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
             L.w.assign((size_t)cout[l] * taps * cin[l], 0.f); L.b.assign(b->data_host, b->data_host + cout[l]);
             for (int co = 0; co < cout[l]; ++co) for (int ci = 0; ci < cin[l]; ++ci) for (int t = 0; t < taps; ++t)
                 L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
-            L.x3 = use_split_bf16();      // conv2..conv5 run on the same implicit-GEMM family as the networks
-            if (L.x3) pack_x3(L.w);
+            L.x3 = use_split_mode();      // conv2..conv5 run on the same implicit-GEMM family as the networks
+            if (L.x3) L.mx_e = pack_split_weights(L.w);
             if ((rc = up(L.w, &L.d_w))) break;
             if ((rc = up(L.b, &L.d_b))) break;
         }
@@ -316,7 +316,8 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
         a.epi = EPI_BIAS_RELU; a.x3 = L.x3 ? 1 : 0;
-        a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED in split-bf16 mode
+        a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED in split mode
+        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e;
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));

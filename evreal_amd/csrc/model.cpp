@@ -37,7 +37,7 @@ struct HostTensor {
 struct DevTensor {   // NHWC activation / state
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
-    bool packed = false;   // PACKED activation format (conv.h): bf16 hi|lo halves per 8 channels
+    bool packed = false;   // PACKED activation format (conv.h): f16 hi | fp8 lo8 | fp8 x8 per 16 channels
     int64_t numel() const { return (int64_t)n * h * w * c; }
 };
 
@@ -50,7 +50,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
     bool transposed = false;
     int epi = EPI_BIAS, hidden = 0;
     ConvTaps tp;
-    bool x3 = false;            // weights packed for the split-bf16 kernel
+    bool x3 = false;            // weights packed for the split kernels (pack_split_weights)
+    int mx_e = 0;               //   and the exponent of their fp8 pieces
     double useful_taps = 0;   // (tap, group) pairs that carry weights (direct-conv FLOP accounting)
     std::vector<float> w, b;    // host, prepared layout
     float* d_w = nullptr; float* d_b = nullptr;
@@ -64,7 +65,7 @@ struct Conv {   // one prepared implicit-GEMM convolution
     double flops = 0.0;
 };
 
-enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN,
+enum StepKind { ST_HEAD, ST_CONV, ST_UPSAMPLE, ST_ADD, ST_PRED, ST_CTX, ST_CTXCONV, ST_DYN, ST_TOPACKED,
                 ST_SP_NEAREST, ST_SP_SEG, ST_SP_APPLY,     // SPADE-E2VID (spade.hip)
                 ST_INORM,                                  // InstanceNorm2d of the norm='IN' residual blocks
                 ST_LN, ST_ATTN, ST_ADDPOS, ST_MEAN6 };     // ET-Net token kernels (etnet.hip)
@@ -91,7 +92,7 @@ struct evr_model {
     unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split-bf16 mode, k5 x 5 bins x 32 channels)
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
-    bool packed = false;   // split-bf16 mode: tensors between matrix-core convolutions use the PACKED format
+    bool packed = false;   // split mode: tensors between matrix-core convolutions use the PACKED format
     int pred_x_packed = 0, pred_skip_packed = 0;
     std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes)
     std::map<std::string, DevTensor> named[2];   // debug names -> tensor valid after a frame of parity p
@@ -338,16 +339,18 @@ void prep_s2d(Conv& c) {
 
 int finish_conv(evr_model* m, Conv& c) {
     int rc;
-    // arithmetic mode: split-bf16 (3 MFMA products) for the 32-channel-chunk convolutions unless EVR_FP32=1
-    c.x3 = (c.kc == 32) && use_split_bf16();
+    // arithmetic mode: split (f16 + MX-fp8 corrections, conv.h) for the 32-channel-chunk convolutions unless EVR_FP32=1
+    c.x3 = (c.kc == 32) && use_split_mode();
     if (c.x3 && c.k == 5 && c.stride == 2 && !c.transposed && c.cin1 == 0 && c.n_gemm % 64 == 0 && 25 * (c.cin0 / 32) < BAND_PROG_MAX - 2) {
         prep_s2d(c);
-        pack_x3(c.w2);
+        const int e2 = pack_split_weights(c.w2);      // (the same values rearranged: the same exponent as c.w below)
+        std::vector<float> probe(c.w);
+        EVR_REQUIRE(pack_split_weights(probe) == e2, "conv %s: the two weight layouts disagree on the fp8 exponent", c.name.c_str());
         if ((rc = upload(c.w2, &c.d_w2))) return rc;
         EVR_HIP(hipMalloc((void**)&c.d_prog, c.prog.size() * sizeof(unsigned)));
         EVR_HIP(hipMemcpy(c.d_prog, c.prog.data(), c.prog.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
-    if (c.x3) pack_x3(c.w);
+    if (c.x3) c.mx_e = pack_split_weights(c.w);
     if ((rc = upload(c.w, &c.d_w))) return rc;
     if ((rc = upload(c.b, &c.d_b))) return rc;
     m->convs.push_back(std::move(c));
@@ -457,7 +460,7 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
     if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
-    if (use_split_bf16() && B == 5 && k == 5 && C == 32) {
+    if (use_split_mode() && B == 5 && k == 5 && C == 32) {
         std::vector<unsigned> wf;
         head_pack_wfrag(m->head_w.data(), B, wf);
         EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -613,7 +616,7 @@ int build_spade(evr_model* m) {
         }
         if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
         if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
-        if (use_split_bf16()) {
+        if (use_split_mode()) {
             std::vector<unsigned> wf;
             head_pack_wfrag(m->head_w.data(), 5, wf);
             EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -763,7 +766,7 @@ int build_etnet(evr_model* m) {
 // shape-dependent planning
 int alloc(evr_model* m, DevTensor* t, int n, int h, int w, int c, hipStream_t stream, bool packed = false) {
     t->n = n; t->h = h; t->w = w; t->c = c; t->packed = packed;
-    EVR_REQUIRE(!packed || c % 8 == 0, "PACKED activation tensor with %d channels", c);
+    EVR_REQUIRE(!packed || c % 16 == 0, "PACKED activation tensor with %d channels", c);
     EVR_HIP(hipMalloc((void**)&t->p, (size_t)t->numel() * sizeof(float) + 256));
     m->allocs.push_back({t->p, (size_t)t->numel() * sizeof(float)});
     EVR_HIP(hipMemsetAsync(t->p, 0, (size_t)t->numel() * sizeof(float), stream));
@@ -794,6 +797,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
+        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e;
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;
@@ -834,7 +838,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
     const bool lstm = d.recurrent_block == EVR_REC_CONVLSTM;
     int rc;
-    const bool P = m->packed;   // every tensor that feeds a matrix-core convolution is PACKED in split-bf16 mode
+    const bool P = m->packed;   // every tensor that feeds a matrix-core convolution is PACKED in split mode
     DevTensor head;
     if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);
@@ -965,12 +969,13 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             { Step s; s.kind = ST_CTXCONV; m->steps.push_back(s); }
             const int b1 = conv_index(m, dn + ".bn1"), b2 = conv_index(m, dn + ".bn2");
             ConvIO a1{}, a2{}, a3{};
-            a1.in_packed = P; a1.out_packed = P; a2.in_packed = P;     // coeff and the filtered tensor stay PLAIN (VALU kernels)
-            a3.out_packed = P;
+            a1.in_packed = P; a1.out_packed = P; a2.in_packed = P;     // coeff stays PLAIN (VALU kernel); the filtered tensor is
+            a3.in_packed = P; a3.out_packed = P;                       // converted in place for the matrix-core conv
             for (int p = 0; p < 2; ++p) { a1.in0[p] = ctxf.p; a1.out[p] = t1.p; a2.in0[p] = t1.p; a2.out[p] = coef.p; a3.in0[p] = inter.p; }
             plan_conv(m, b1, n, h, w, a1, 64); push_conv(m, b1);
             plan_conv(m, b2, n, h, w, a2, 72); push_conv(m, b2);
             { Step s; s.kind = ST_DYN; s.a[0] = s.a[1] = up.p; s.b[0] = s.b[1] = coef.p; s.out = inter.p; s.h = h; s.w = w; s.c = cin; m->steps.push_back(s); }
+            if (P) { Step s; s.kind = ST_TOPACKED; s.out = inter.p; s.h = h; s.w = w; s.c = cin * 6; m->steps.push_back(s); }
             if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             for (int p = 0; p < 2; ++p) a3.out[p] = o.p;
             plan_conv(m, di, n, h, w, a3, cout); push_conv(m, di);
@@ -979,14 +984,14 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             last_plain = -1;   // the next decoder adds its skip itself
         } else if (d.use_upsample_conv) {
             DevTensor up;
-            if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
-            Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = P; s.b_packed = P;
+            if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream, P))) return rc;
+            Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = P; s.b_packed = P; s.out_packed = P;
             for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
             m->steps.push_back(s);
             h *= 2; w *= 2;
             if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             ConvIO a{};
-            a.out_packed = P;      // the upsampled tensor is PLAIN: this conv splits it on the fly
+            a.in_packed = P; a.out_packed = P;      // the upsample kernel writes the conv's operand format
             for (int p = 0; p < 2; ++p) { a.in0[p] = up.p; a.out[p] = o.p; }
             plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
         } else {
@@ -1354,14 +1359,14 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
     for (int i = 0; i < 3; ++i) {
         const int cin = 256 >> i, cout = 128 >> i;
         DevTensor up, o;
-        if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream))) return rc;
-        Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = ypk; s.b_packed = P;
+        if ((rc = alloc(m, &up, n, 2 * h, 2 * w, cin, stream, P))) return rc;
+        Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = ypk; s.b_packed = P; s.out_packed = P;
         for (int p = 0; p < 2; ++p) { s.a[p] = y[p]; s.b[p] = blk[2 - i][p].p; }
         m->steps.push_back(s);
         h *= 2; w *= 2;
         if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
         ConvIO a{};
-        a.out_packed = P;
+        a.in_packed = P; a.out_packed = P;
         for (int p = 0; p < 2; ++p) { a.in0[p] = up.p; a.out[p] = o.p; }
         const int di = conv_index(m, "dec" + std::to_string(i));
         plan_conv(m, di, n, h, w, a, cout); push_conv(m, di);
@@ -1487,7 +1492,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             }
             case ST_UPSAMPLE:
-                if ((rc = launch_upsample2x_sum(s.a[p], s.b[p], s.out, m->n_seq, s.h, s.w, s.c, s.a_packed, s.b_packed, stream))) return rc;
+                if ((rc = launch_upsample2x_sum(s.a[p], s.b[p], s.out, m->n_seq, s.h, s.w, s.c, s.a_packed, s.b_packed, s.out_packed, stream))) return rc;
                 break;
             case ST_ADD:
                 if ((rc = launch_add(s.a[p], s.b[p], s.out, (int64_t)m->n_seq * s.h * s.w * s.c, s.out_packed, stream))) return rc;
@@ -1500,6 +1505,9 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
             }
             case ST_CTXCONV:
                 if ((rc = launch_head_conv(m->ctxconv, stream))) return rc;
+                break;
+            case ST_TOPACKED:
+                if ((rc = launch_to_packed(s.out, s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream))) return rc;
                 break;
             case ST_DYN:
                 if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
@@ -1595,21 +1603,17 @@ extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names,
 }
 
 // ------------------------------------------------------------------------------------------------
-// the PACKED codec on the host (include/evreal_hip.h): the same pack_x3 the weights go through
-extern "C" int evr_split_bf16_pack(const float* src, float* dst, int64_t n) {
-    EVR_REQUIRE(src && dst && n >= 0 && n % 8 == 0, "evr_split_bf16_pack: n = %lld must be a multiple of 8", (long long)n);
+// the PACKED activation codec on the host (include/evreal_hip.h): conv.h's pack_split_act, the twin of packed.h
+extern "C" int evr_split_pack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_pack: n = %lld must be a multiple of 16", (long long)n);
     std::vector<float> w(src, src + n);
-    pack_x3(w);
+    pack_split_act(w);
     memcpy(dst, w.data(), (size_t)n * sizeof(float));
     return EVR_OK;
 }
 
-extern "C" int evr_split_bf16_unpack(const float* src, float* dst, int64_t n) {
-    EVR_REQUIRE(src && dst && n >= 0 && n % 8 == 0, "evr_split_bf16_unpack: n = %lld must be a multiple of 8", (long long)n);
-    for (int64_t base = 0; base < n; base += 8) {
-        unsigned short hl[16];
-        memcpy(hl, src + base, 32);
-        for (int k = 0; k < 8; ++k) dst[base + k] = bf16_to_f32(hl[k]) + bf16_to_f32(hl[8 + k]);
-    }
+extern "C" int evr_split_unpack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_unpack: n = %lld must be a multiple of 16", (long long)n);
+    unpack_split_act(src, dst, (size_t)n);
     return EVR_OK;
 }

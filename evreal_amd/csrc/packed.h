@@ -1,42 +1,65 @@
-// Device helpers for the PACKED activation format (conv.h): bf16 hi|lo halves per 8 channels.
+// Device helpers for the PACKED activation format (conv.h): per 16 channels 16 f16 'hi' | 16 fp8 'lo8' | 16 fp8 'x8'.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace evr {
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// two fp32 -> packed bf16 (RNE): `lo` lands in bits 15:0, `hi` in bits 31:16 (no builtin on gfx950)
+// two fp32 -> packed bf16 (RNE): `lo` lands in bits 15:0, `hi` in bits 31:16 (no builtin on gfx950); head_mfma_kernel only
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 typedef float f4 __attribute__((ext_vector_type(4)));
-// PACKED activation format (conv.h): 4 consecutive channels c4..c4+3 (c4 % 4 == 0) of a pixel row are an 8-B 'hi'
-// piece and, 16 B further, an 8-B 'lo' piece.  pk_off = float-element offset of the hi piece; lo = +4 floats.
-__device__ __forceinline__ unsigned pk_off(unsigned row_off, int c4) { return row_off + (unsigned)((c4 & ~7) + ((c4 & 4) >> 1)); }
-__device__ __forceinline__ f4 unpack4(uint2 hi, uint2 lo) {
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+constexpr float PK_LO_SCALE = 4096.0f, PK_LO_INV = 1.0f / 4096.0f;      // 2^12 (conv.h MX_LO_EXP)
+
+// 4 consecutive channels c4..c4+3 (c4 % 4 == 0) of a pixel row: an 8-B hi piece, a 4-B lo8 piece and a 4-B x8 piece
+// inside the row's 64-B group c4 / 16.  Offsets in float elements from the tensor base.
+__device__ __forceinline__ unsigned pk_off(unsigned row_off, int c4) { return row_off + (unsigned)((c4 & ~15) + ((c4 & 15) >> 1)); }
+__device__ __forceinline__ unsigned pk_lo_off(unsigned row_off, int c4) { return row_off + (unsigned)((c4 & ~15) + 8 + ((c4 & 15) >> 2)); }
+__device__ __forceinline__ f4 unpack4(uint2 hi, unsigned lo8) {
+    const h2_t h0 = __builtin_bit_cast(h2_t, hi.x), h1 = __builtin_bit_cast(h2_t, hi.y);
     f4 v;
-    v[0] = __uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16);
-    v[1] = __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u);
-    v[2] = __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16);
-    v[3] = __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u);
+    v[0] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)lo8, 0), PK_LO_INV, (float)h0[0]);
+    v[1] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)lo8, 1), PK_LO_INV, (float)h0[1]);
+    v[2] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)lo8, 2), PK_LO_INV, (float)h1[0]);
+    v[3] = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)lo8, 3), PK_LO_INV, (float)h1[1]);
     return v;
 }
-__device__ __forceinline__ void pack4(f4 v, uint2& hi, uint2& lo) {
-    hi.x = cvt_pk_bf16(v[0], v[1]); hi.y = cvt_pk_bf16(v[2], v[3]);
-    lo.x = cvt_pk_bf16(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
-    lo.y = cvt_pk_bf16(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+__device__ __forceinline__ void pack4(f4 v, uint2& hi, unsigned& lo8, unsigned& x8) {
+    float c[4], r[4], s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_fmed3f(v[j], -65504.0f, 65504.0f);
+    const h2_t h0 = {(_Float16)c[0], (_Float16)c[1]}, h1 = {(_Float16)c[2], (_Float16)c[3]};
+    hi.x = __builtin_bit_cast(unsigned, h0); hi.y = __builtin_bit_cast(unsigned, h1);
+    const float hf[4] = {(float)h0[0], (float)h0[1], (float)h1[0], (float)h1[1]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = __builtin_amdgcn_fmed3f((c[j] - hf[j]) * PK_LO_SCALE, -448.0f, 448.0f);
+        s[j] = __builtin_amdgcn_fmed3f(v[j], -448.0f, 448.0f);
+    }
+    int t = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], 0, false);
+    lo8 = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], t, true);
+    t = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], 0, false);
+    x8 = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], t, true);
 }
 __device__ __forceinline__ f4 load4_packed(const float* p, unsigned row_off, int c4) {
-    const float* q = p + pk_off(row_off, c4);
-    return unpack4(*(const uint2*)q, *(const uint2*)(q + 4));
+    return unpack4(*(const uint2*)(p + pk_off(row_off, c4)), *(const unsigned*)(p + pk_lo_off(row_off, c4)));
 }
 __device__ __forceinline__ void store4_packed(float* p, unsigned row_off, int c4, f4 v) {
-    uint2 hi, lo;
-    pack4(v, hi, lo);
-    float* q = p + pk_off(row_off, c4);
-    *(uint2*)q = hi; *(uint2*)(q + 4) = lo;
+    uint2 hi; unsigned lo8, x8;
+    pack4(v, hi, lo8, x8);
+    *(uint2*)(p + pk_off(row_off, c4)) = hi;
+    unsigned* q = (unsigned*)(p + pk_lo_off(row_off, c4));
+    q[0] = lo8; q[4] = x8;
+}
+// one channel of a PACKED pixel row
+__device__ __forceinline__ float load1_packed(const float* row, int ch) {
+    const unsigned char* g = (const unsigned char*)(row + (ch & ~15));
+    const int k = ch & 15;
+    return fmaf(__builtin_amdgcn_cvt_f32_fp8((int)g[32 + k], 0), PK_LO_INV, (float)((const _Float16*)g)[k]);
 }
 #endif
 

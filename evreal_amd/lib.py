@@ -68,8 +68,8 @@ SYMBOLS = {
     'evr_lpips_flops': (c_double, [c_void_p]),
     'evr_bayer_split': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'evr_color_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'evr_split_bf16_pack': (c_int, [c_void_p, c_void_p, c_int64]),
-    'evr_split_bf16_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_split_pack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_split_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
 }
 
 _lib = None

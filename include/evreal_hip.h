@@ -232,14 +232,15 @@ int evr_color_merge(const float* planes, const float* gray, int n, int H, int W,
                     evr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
- * Split-bf16 storage format (host utilities, no GPU): the default arithmetic mode keeps every tensor that feeds
- * the matrix cores -- weights and, inside the model, activations -- as bf16 hi|lo halves: each group of 8 values
- * (32 B) holds the 8 'hi' halves (round-to-nearest-even of the value, 16 B) then the 8 'lo' halves (RNE of
- * value - hi), value ~ hi + lo to 2^-17 relative.  evr_model_read_tensor decodes it; these two functions expose the
- * codec itself so the format can be checked on a CPU-only host.  n must be a multiple of 8; src/dst host pointers.
+ * Split storage format (host utilities, no GPU): the default arithmetic mode keeps every activation tensor that feeds
+ * the matrix cores in 64-byte groups of 16 values: 16 IEEE-half 'hi' (round-to-nearest-even of the value, saturating at
+ * +-65504), then 16 OCP e4m3 'lo8' = RNE((value - hi) * 2^12), then 16 OCP e4m3 'x8' = RNE(value) (both saturating at
+ * +-448); value ~ hi + lo8 * 2^-12 to 2^-16 relative.  A product is hi_x * hi_w on the f16 matrix path plus the
+ * MX-scaled fp8 corrections lo8_x * w8 + x8 * lo8_w (csrc/conv.h).  evr_model_read_tensor decodes the format; these two
+ * functions expose the codec itself so it can be checked on a CPU-only host.  n must be a multiple of 16; host pointers.
  */
-int evr_split_bf16_pack(const float* src, float* dst, int64_t n);
-int evr_split_bf16_unpack(const float* src, float* dst, int64_t n);
+int evr_split_pack(const float* src, float* dst, int64_t n);
+int evr_split_unpack(const float* src, float* dst, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -2,7 +2,7 @@
 
 * EVR_BAND_MIN=1 (+ EVR_BAND_PROG_ALL=1: the space-to-depth form for every encoder width) -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
   takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here.
-* EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split-bf16 / PACKED.
+* EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split (f16 + MX-fp8) / PACKED.
 The switches are read when the library plans its launches, hence one fresh interpreter per mode.
 """
 import os

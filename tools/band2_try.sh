@@ -3,4 +3,5 @@ import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
 print('$1', 'fps', d['value'], ' '.join(f\"{k}={v['us']:.0f}\" for k, v in d['roofline']['layers'].items()))"; }
 mkdir -p gpurun_out
-EVR_BAND2=1 run "$1" | tee -a gpurun_out/band2.txt
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/mx_tests.txt
+run "$1" | tee -a gpurun_out/mx_layers.txt
