@@ -859,7 +859,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
     constexpr int NA_MAX = (A_PIECES + NW - 1) / NW, NA_MIN = A_PIECES / NW;   // 5 / 4 band pieces per wave
     constexpr int NBW = (B_F4 / 64) / NW;           // 4 weight-tile pieces per wave
     static_assert(NBW == 4 && NA_MIN == 4, "update the counted waits");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4];   // [band 0 | band 1 | weight slot 0 | 1]
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4 + SP];   // [band 0 | band 1 | weight slot 0 | 1 | a zero row]
+    constexpr int ZROW = (2 * A_F4 + 2 * B_F4) / SP;     // row index of the zero row, counted from lds[0]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -947,41 +948,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
 
     // prologue: band 0 and the first weight tile (bare s_barrier: __syncthreads() carries a fence hipcc lowers to vmcnt(0))
+    if (tid < SP) lds[2 * A_F4 + 2 * B_F4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     issue_band(0, 0, 0);
     issue_w(0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     for (int c = 0; c < nchunks; ++c) {
         const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1; ring slot of step 9c + t is (c + t) & 1
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // requests of this step, spread over its four MFMA groups (a DMA piece costs ~60-180 issue cycles: in one
-            // burst at the top of the step they hold up the wave's -- and its in-phase SIMD partner's -- first MFMAs):
-            // the weight tile of step s + 1 (NBW pieces) and, at the first tap of a band, the NEXT band
+            // requests of this step: the weight tile of step s + 1 (NBW pieces) and, at the first tap of a band, the NEXT
+            // band (spreading them over the step's four MFMA groups measured no faster and costs registers)
             const int t2 = (t + 1) % 9;
             int cw = c + (t + 1) / 9;
             if (cw >= nchunks) cw = nchunks - 1;                     // tail: harmless re-load into the free slot
             const int d2 = (t / 3 + 1) % 3;
             int cb = c + (t / 3 + 1) / 3;
             if (cb >= nchunks) cb = nchunks - 1;
+            issue_w(t2, cw, pa ^ ((t + 1) & 1));       // first, so that the counted wait below can leave the band in flight
+            if (t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
+            __builtin_amdgcn_sched_barrier(0);
             const int ab = pa ^ ((t / 3) & 1);
             const float4* lb = &lds[2 * A_F4 + (pa ^ (t & 1)) * B_F4 + (wni * 32 * NB + r) * SP];
-            int i0 = wmi * 64 + r + (t % 3);                           // band rows of the lane's dx neighbours
-            asm volatile("" : "+v"(i0));     // opaque: the 24 slot addresses of the unrolled taps are recomputed, not kept live
-            const int i1 = i0 + 32;
-            SplitFrag xa0 = ld_split(&lds[ab * A_F4 + i0 * SP], h, swz<32>(i0));
-            SplitFrag xa1 = ld_split(&lds[ab * A_F4 + i1 * SP], h, swz<32>(i1));
-            if (t != 4) { zero_unless(xa0, (vmask0 >> t) & 1u); zero_unless(xa1, (vmask1 >> t) & 1u); }
+            // band rows of the lane's dx neighbours, counted from lds[0]; a pixel that is not a real neighbour (image
+            // border, neighbouring image of the batch) reads the zero row instead: one select per block, not 16 per fragment
+            int l0 = wmi * 64 + r + (t % 3);                           // row inside the band (its swizzle is the DMA's)
+            asm volatile("" : "+v"(l0));     // opaque: the slot addresses of the unrolled taps are recomputed, not kept live
+            const int l1 = l0 + 32;
+            int i0 = ab * A_ROWS + l0, i1 = ab * A_ROWS + l1;
+            if (t != 4) { i0 = ((vmask0 >> t) & 1u) ? i0 : ZROW; i1 = ((vmask1 >> t) & 1u) ? i1 : ZROW; }
+            const SplitFrag xa0 = ld_split(&lds[i0 * SP], h, swz<32>(l0));
+            const SplitFrag xa1 = ld_split(&lds[i1 * SP], h, swz<32>(l1));
             // one block's weight fragments at a time (the scheduler would otherwise hoist all four: +48 registers, spills;
-            // reading one block ahead measured no faster)
+            // reading one block ahead -- left to the scheduler or pinned with scheduling barriers -- measured no faster)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
                 acc0[nb] = mma_split(acc0[nb], wb, xa0, mx_sb, mx_sa);
                 acc1[nb] = mma_split(acc1[nb], wb, xa1, mx_sb, mx_sa);
-                __builtin_amdgcn_sched_barrier(0);
-                if (nb == 0) issue_w(t2, cw, pa ^ ((t + 1) & 1));      // first, so that the counted wait below can leave the band in flight
-                if (nb == 1 && t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in
@@ -1220,8 +1224,9 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
         // 256 x 256 block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
         static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
+        static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 1024;   // >= 4 rounds of 256 blocks; tests lower it
         const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
-                             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= 1024;   // >= 4 rounds of 256 blocks
+                             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= wide_min;
         if (wide_ok && a.epi == EPI_LSTM) return launch_wide<true>(a, d_args, stream, img);
         // (the plain-epilogue instance needs 10 registers more than two waves per SIMD leave: not instantiated)
         if (a.epi == EPI_LSTM) {

@@ -1,7 +1,8 @@
 """The model parity suite again under the kernel-selection switches the default run does not reach.
 
 * EVR_BAND_MIN=1 (+ EVR_BAND_PROG_ALL=1: the space-to-depth form for every encoder width) -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
-  takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here.
+  takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here, once with the
+  128 x 128-tile kernel for every layer (EVR_WIDE=0) and once with the 256 x 256-tile ConvLSTM kernel (EVR_WIDE_MIN=1).
 * EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split (f16 + MX-fp8) / PACKED.
 The switches are read when the library plans its launches, hence one fresh interpreter per mode.
 """
@@ -24,8 +25,22 @@ def _run(env_extra):
 
 
 def test_parity_with_band_kernel_on_small_shapes():
-    _run({'EVR_BAND_MIN': '1', 'EVR_BAND_PROG_ALL': '1'})
+    _run({'EVR_BAND_MIN': '1', 'EVR_BAND_PROG_ALL': '1', 'EVR_WIDE': '0'})
+
+
+def test_parity_with_wide_band_kernel_on_small_shapes():
+    # the 256 x 256-tile ConvLSTM kernel the 64-sequence bench runs (conv3x3_wide_kernel), on the golden sequences
+    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
 
 
 def test_parity_in_exact_fp32_mode():
     _run({'EVR_FP32': '1'})
+
+
+def test_drift_100_frames_with_wide_band_kernel():
+    """The 100-frame, 8-sequence, 346x260 drift gate again with the ConvLSTM gates on the kernel the 64-sequence bench
+    times (8 sequences alone stay below its 1024-block threshold)."""
+    env = dict(os.environ, EVR_WIDE_MIN='1')
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
