@@ -613,7 +613,8 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     static_assert((B_F4 / 64) % WM == 0, "weight tile pieces must divide over the waves");
     static_assert(RING == 2 || RING == 3, "weight ring: 2 slots (request 1 step ahead) or 3 (2 steps ahead)");
     static_assert(!GROUPED || !LSTM, "a transposed conv has no ConvLSTM epilogue");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + RING * B_F4];   // [band 0 | band 1 | ring slots]
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + RING * B_F4 + SP];   // [band 0 | band 1 | ring slots | a zero row]
+    constexpr int ZOFF = 2 * A_F4 + RING * B_F4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -729,15 +730,16 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     constexpr int ablate = 0;
 #endif
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
-    // prologue: band 0 and the first RING-1 weight tiles
+    // prologue: the zero row, band 0 and the first RING-1 weight tiles
     // (bare s_barrier below: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
+    if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     issue_band(0, 0, 0, band_use(0));
     issue_w(0, 0, 0, tap_use(0) != 0);
     if constexpr (RING == 3) {
         issue_w(1, 0, 1, tap_use(1) != 0);
-        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -765,13 +767,14 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
             int i = idx + (t % 3) - SHIFT;                  // band row of the lane's (dx) neighbour
             if constexpr (OVL) i = i < 0 ? 0 : (i > TM - 1 ? TM - 1 : i);   // (only the two non-storing edge lanes clamp)
             const int swi = swz<32>(i);
-            const float4* la = &lds[ab * A_F4 + i * SP];
-            const float4* lb = &lds[2 * A_F4 + ((RING == 3) ? (t % 3) : (pa ^ (t & 1))) * B_F4 + r * SP];
+            // a pixel that is not a real neighbour (image border, neighbouring image of the batch) reads the zero row: one
+            // select on the row offset instead of 16 on the fragment (these short-K layers are VALU-bound)
             const bool keep = (vmask >> t) & 1u;
+            const float4* la = &lds[(t == 4 || keep || (ablate & 8)) ? ab * A_F4 + i * SP : ZOFF];
+            const float4* lb = &lds[2 * A_F4 + ((RING == 3) ? (t % 3) : (pa ^ (t & 1))) * B_F4 + r * SP];
             const int use_t = tap_use(t);
             if (!GROUPED || use_t) {       // block-uniform: a tap no phase of this tile uses is skipped whole
-                SplitFrag xa = ld_split(la, h, swi);
-                if (t != 4 && !(ablate & 8)) zero_unless(xa, keep);
+                const SplitFrag xa = ld_split(la, h, swi);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     // (without PHASES a tap used by only SOME phases of the tile still runs all four blocks: the unused
@@ -847,24 +850,30 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 // of 128.  The walk (chunk x dy x dx, counted vmcnt, validity masks) is conv3x3_band_kernel's.  Epilogue operands
 // (cell state / residual / fused skip) are loaded in the epilogue, one 32-pixel block at a time: with 128 accumulator
 // registers there is no room to park them during the main loop.
-template <bool LSTM>
-__global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+// WN = 2: the 256 x 256 block described above.  WN = 1 ("twin"): 256 pixels x 128 columns, 4 waves, ONE band buffer
+// (33.8 KB + 2 x 16 KB of weight tiles = 66 KB): TWO independent blocks per CU, so a SIMD's two waves belong to
+// different blocks and do not stall at the same barrier; the price is the band switch every third step -- barrier,
+// request the next band, wait for it, barrier -- whose DMA latency the other block's MFMAs have to cover.
+template <bool LSTM, int WN>
+__global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
-    constexpr int WM = 4, WN = 2, NW = WM * WN, MB = 2, NB = 4, SP = 8;
+    constexpr int WM = 4, NW = WM * WN, MB = 2, NB = 4, SP = 8;
+    constexpr bool SINGLE = (WN == 1);              // one band buffer
+    constexpr int NBUF = SINGLE ? 1 : 2;
     constexpr int TM = 32 * MB * WM, TN = 32 * NB * WN;   // 256 x 256
     constexpr int A_ROWS = TM + 8;                  // TM + 2 source pixels needed; whole 8-row (1-KiB) DMA pieces
     constexpr int A_PIECES = A_ROWS / 8;            // 33
     constexpr int A_F4 = A_ROWS * SP, B_F4 = TN * SP;
-    constexpr int NA_MAX = (A_PIECES + NW - 1) / NW, NA_MIN = A_PIECES / NW;   // 5 / 4 band pieces per wave
+    constexpr int NA_MAX = (A_PIECES + NW - 1) / NW, NA_MIN = A_PIECES / NW;   // 5 / 4 (9 / 8) band pieces per wave
     constexpr int NBW = (B_F4 / 64) / NW;           // 4 weight-tile pieces per wave
-    static_assert(NBW == 4 && NA_MIN == 4, "update the counted waits");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4 + SP];   // [band 0 | band 1 | weight slot 0 | 1 | a zero row]
-    constexpr int ZROW = (2 * A_F4 + 2 * B_F4) / SP;     // row index of the zero row, counted from lds[0]
+    static_assert(NBW == 4 && (SINGLE || NA_MIN == 4), "update the counted waits");
+    __shared__ __attribute__((aligned(16))) float4 lds[NBUF * A_F4 + 2 * B_F4 + SP];   // [band 0 | band 1 | weight slot 0 | 1 | a zero row]
+    constexpr int ZROW = (NBUF * A_F4 + 2 * B_F4) / SP;     // row index of the zero row, counted from lds[0]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wmi = wv & 3, wni = wv >> 2;
+    const int wmi = wv & 3, wni = (WN == 1) ? 0 : (wv >> 2);
     const int W = a.win, H = a.hin;
     const int hw = H * W;
     const int M = a.n * hw;
@@ -887,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
 
     // DMA pieces (piece j = wv + jj*NW; lane -> row 8j + lane/8, 16-B slot lane%8, source slot swizzled).  Pieces of one
-    // wave are 64 rows apart, so their swizzle ((row >> 1) & 7) is the same and ONE pixel / offset register serves all
+    // wave are 64 (32) rows apart, so their swizzle ((row >> 1) & 7) is the same and ONE pixel / offset register serves all
     // of them (an array per piece costs 11 more registers, which this kernel does not have)
     const int row0 = 8 * wv + (lane >> 3);
     const int a_pix0 = m0 - 1 + row0;
@@ -902,7 +911,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
 #pragma unroll
         for (int jj = 0; jj < NA_MAX; ++jj) {
             if (jj < NA_MIN || wv + jj * NW < A_PIECES) {      // wave-uniform
-                const int pix = a_pix0 + 64 * jj + shift;
+                const int pix = a_pix0 + 8 * NW * jj + shift;
                 unsigned voff = OOB_OFFSET;
                 if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q0) * 4u;
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wv + jj * NW) * 64];
@@ -915,9 +924,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
         const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
         for (int jj = 0; jj < NBW; ++jj) {
-            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wv + jj * NW) * 64];
+            lds_ptr_t dst = (lds_ptr_t)&lds[NBUF * A_F4 + slot * B_F4 + (wv + jj * NW) * 64];
             // (soffset carries the wave-uniform part: row block jj and the K offset of the step)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, b_off0 * 4u, (kofs + (unsigned)(64 * jj * ktot)) * 4u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, b_off0 * 4u, (kofs + (unsigned)(8 * NW * jj * ktot)) * 4u, 0, 0);
         }
     };
 
@@ -948,7 +957,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
 
     // prologue: band 0 and the first weight tile (bare s_barrier: __syncthreads() carries a fence hipcc lowers to vmcnt(0))
-    if (tid < SP) lds[2 * A_F4 + 2 * B_F4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < SP) lds[NBUF * A_F4 + 2 * B_F4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     issue_band(0, 0, 0);
     issue_w(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -966,10 +975,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
             int cb = c + (t / 3 + 1) / 3;
             if (cb >= nchunks) cb = nchunks - 1;
             issue_w(t2, cw, pa ^ ((t + 1) & 1));       // first, so that the counted wait below can leave the band in flight
-            if (t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
+            if (!SINGLE && t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
             __builtin_amdgcn_sched_barrier(0);
-            const int ab = pa ^ ((t / 3) & 1);
-            const float4* lb = &lds[2 * A_F4 + (pa ^ (t & 1)) * B_F4 + (wni * 32 * NB + r) * SP];
+            const int ab = SINGLE ? 0 : (pa ^ ((t / 3) & 1));
+            const float4* lb = &lds[NBUF * A_F4 + (pa ^ (t & 1)) * B_F4 + (wni * 32 * NB + r) * SP];
             // band rows of the lane's dx neighbours, counted from lds[0]; a pixel that is not a real neighbour (image
             // border, neighbouring image of the batch) reads the zero row instead: one select per block, not 16 per fragment
             int l0 = wmi * 64 + r + (t % 3);                           // row inside the band (its swizzle is the DMA's)
@@ -991,8 +1000,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
             // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in
             // flight (loads complete in order).  lgkmcnt(0): this wave's fragment reads have left LDS before anyone
             // overwrites the buffers
-            if (t % 3 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (SINGLE) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t % 3 == 2 && !(t == 8 && c == nchunks - 1)) {   // everyone has left the band: fetch the next one into the same buffer
+                    issue_band(cb, d2, 0);
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+            } else {
+                if (t % 3 == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
     }
     epi_prefetch<NB, LSTM, false>(a, n0w, h, late, ec0);
@@ -1002,11 +1019,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wide_kernel(const ConvArgs* __
 #endif
 }
 
-template <bool LSTM>
+template <bool LSTM, int WN>
 static int launch_wide(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
-    const int total = ((M + 255) / 256) * (a.cout / 256);
-    hipLaunchKernelGGL((conv3x3_wide_kernel<LSTM>), dim3(total), dim3(512), 0, stream, d_args, img);
+    const int total = ((M + 255) / 256) * (a.cout / (128 * WN));
+    hipLaunchKernelGGL((conv3x3_wide_kernel<LSTM, WN>), dim3(total), dim3(256 * WN), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -1031,7 +1048,8 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
     constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;
     constexpr int NBW = (B_F4 / 64) / WM;
     static_assert(NA_MIN == 4 && (B_F4 / 64) % WM == 0, "tile bookkeeping");
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4];   // [band 0 | band 1 | weight slot 0 | 1]
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4 + SP];   // [band 0 | band 1 | weight slot 0 | 1 | a zero row]
+    constexpr int ZOFF = 2 * A_F4 + 2 * B_F4;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1126,9 +1144,10 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
     auto kofs_of = [&](unsigned e) -> int { return (int)(((e & 15u) * (unsigned)nch2 + ((e >> 8) & 255u)) * 32u); };
     {
         const unsigned e0 = entry(0), e1 = entry(1);
+        if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
         issue_band((int)((e0 >> 16) & 1023u), (int)((e0 >> 26) & 3u) - 1, 0);
         issue_w(kofs_of(e1), 0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     int abuf = 0;
     for (int s = 1; s <= nsteps; ++s) {
@@ -1141,11 +1160,10 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
         const int dxi = t - (t / 3) * 3;
         const int i = idx + dxi;
         const int swi = swz<32>(i);
-        const float4* la = &lds[abuf * A_F4 + i * SP];
-        const float4* lb = &lds[2 * A_F4 + slot * B_F4 + r * SP];
         const bool keep = (vmask >> t) & 1u;
-        SplitFrag xa = ld_split(la, h, swi);
-        zero_unless(xa, keep);
+        const float4* la = &lds[keep ? abuf * A_F4 + i * SP : ZOFF];      // invalid neighbour blocks read the zero row
+        const float4* lb = &lds[2 * A_F4 + slot * B_F4 + r * SP];
+        const SplitFrag xa = ld_split(la, h, swi);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
@@ -1222,12 +1240,17 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
         // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
         static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
-        // 256 x 256 block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
+        // 256-pixel block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
         static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
         static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 1024;   // >= 4 rounds of 256 blocks; tests lower it
         const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
                              (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= wide_min;
-        if (wide_ok && a.epi == EPI_LSTM) return launch_wide<true>(a, d_args, stream, img);
+        if (wide_ok && a.epi == EPI_LSTM) {
+            // two 256 x 128 blocks per CU (one band buffer each) while K is short, one 256 x 256 block otherwise: measured
+            // 1486 / 1449 / 1405 us against 1585 / 1489 / 1401 us for 128 / 256 / 512 input channels (EVR_WIDE=2 / 3 force one)
+            const bool twin = (wide == 2) || (wide == 1 && a.c0 + a.c1 <= 256);
+            return twin ? launch_wide<true, 1>(a, d_args, stream, img) : launch_wide<true, 2>(a, d_args, stream, img);
+        }
         // (the plain-epilogue instance needs 10 registers more than two waves per SIMD leave: not instantiated)
         if (a.epi == EPI_LSTM) {
             if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);

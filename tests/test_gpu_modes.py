@@ -30,7 +30,12 @@ def test_parity_with_band_kernel_on_small_shapes():
 
 def test_parity_with_wide_band_kernel_on_small_shapes():
     # the 256 x 256-tile ConvLSTM kernel the 64-sequence bench runs (conv3x3_wide_kernel), on the golden sequences
-    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
+    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '3'})
+
+
+def test_parity_with_twin_band_kernel_on_small_shapes():
+    # its two-blocks-per-CU form (256 x 128 tiles, one band buffer), the default for ConvLSTM layers of up to 256 input channels
+    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '2'})
 
 
 def test_parity_in_exact_fp32_mode():
