@@ -85,6 +85,7 @@ struct ConvArgs {
     int crop_h, crop_w, crop_y0, crop_x0;
     int x3;                   // weights are in the split layout (pack_split_weights) and in0/in1 are PACKED tensors:
     int in_packed;            //   the main loop feeds LDS slots straight to the MFMAs
+    int group_store;          // PACKED outputs as whole 64-B groups after a lane exchange (packed.h xchg16); 0: 4-channel pieces
     int mx_sa, mx_sb;         // E8M0 block scales of the fp8 correction MFMA: 127 - 12 (activations), 127 - e (weights)
     int out_packed;           // write `out` PACKED (n_valid and cout_total multiples of 8)
     int res_packed, padd_packed, state_packed;   // format of residual / post_add / the ConvGRU hidden state
@@ -208,6 +209,8 @@ inline int pack_split_weights(std::vector<float>& w) {
 }
 // arithmetic mode of the 32-channel-chunk convolutions: split (f16 + MX-fp8 corrections) unless EVR_FP32=1 (exact fp32 MFMA)
 inline bool use_split_mode() { return getenv("EVR_FP32") == nullptr; }
+// (A/B switch for the whole-group PACKED stores)
+inline int use_group_store() { const char* e = getenv("EVR_GROUP_STORE"); return e ? atoi(e) : 1; }
 
 // kc: K chunk (16 or 32 channels); wm: waves per block along M (1,2,4); nb: 32-column blocks per wave (1,2,4).
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
@@ -227,6 +230,7 @@ struct HeadArgs {
     float* out;
     int relu;
     int out_packed;      // write `out` in the PACKED activation format
+    int group_store;     //   as whole 64-B groups (see ConvArgs)
     const void* wfrag;   // k5/32-channel split-bf16 form: weights in MFMA-fragment order (head_mfma_kernel), or null
 };
 // weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B)

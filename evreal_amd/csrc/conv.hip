@@ -223,7 +223,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
         static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
         // N tile of 128 = 4 gates x 32 hidden channels (rows permuted at model creation); the conv is stride 1 on
         // the state's own grid, so the output pixel is the GEMM row.  submodules.py:227-245
-        if (!mvalid) return;
+        if (!mvalid) return;      // (both halves of a pixel leave together: the lane exchange below stays paired)
+        f32x16 hall;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f4 cn, hn;
@@ -235,10 +236,16 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 const float gc = tanh_t<FAST>(acc[3][4 * q + j]);
                 cn[j] = __fadd_rn(__fmul_rn(gf, pre[0][4 * q + j]), __fmul_rn(gi, gc));   // submodules.py:242
                 hn[j] = go * tanh_t<FAST>(cn[j]);                                          // submodules.py:243
+                hall[4 * q + j] = hn[j];
             }
             *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
-            if (a.out_packed) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
-            else *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
+            if (!a.out_packed) *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
+            else if (!a.group_store) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
+        }
+        if (a.out_packed && a.group_store) {       // the wave's 32 hidden channels of this pixel = two PACKED groups, one per lane of the pair
+            float w16[16];
+            xchg16(hall, w16);
+            store16_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 16 * h, w16);
         }
         return;
     } else {
@@ -318,10 +325,14 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
         f4 pwq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) pwq[q] = pw_shared ? *(const f4*)(pw + 4 * h + 8 * q) : f4{0.f, 0.f, 0.f, 0.f};
+        const bool group_store = a.out_packed && !pw && a.group_store;      // PACKED output: whole 64-B groups after a lane exchange
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             unsigned opx; int cgb, oy, ox;
             out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
+            f32x16 outv;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) outv[i] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c4 = cgb + 8 * q;                    // channel inside the column group
@@ -345,13 +356,23 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                         if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
                         else v += pv;
                     }
-                    if (!pw) st4(a.out, orow, c4, v, a.out_packed);
+                    if (group_store) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) outv[4 * q + j] = v[j];
+                    } else if (!pw) st4(a.out, orow, c4, v, a.out_packed);
                     else {
                         const f4 w4 = pw_shared ? pwq[q] : *(const f4*)(pw + c4);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pred_part = fmaf(v[j], w4[j], pred_part);
                     }
                 }
+            }
+            if (group_store) {      // (every lane takes part in the exchange; the two halves of a pixel share mvalid)
+                float w16[16];
+                xchg16(outv, w16);
+                const int cg = cgb - 4 * h + 16 * h;           // the lane's group inside the column group
+                if (mvalid && cg < nvalid) store16_packed(a.out, opx * ct, cg, w16);
+                __builtin_amdgcn_sched_barrier(0);             // one block's conversion temporaries at a time
             }
             // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
             // pixel; the channels of a pixel live in the two lanes r and r+32
@@ -377,7 +398,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
 // X3: 0 = fp32 MFMA; 2 = split arithmetic on PACKED activations (1, splitting PLAIN activations in registers, is gone:
 // VALU kernels that feed a matrix-core convolution write PACKED themselves)
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
-__global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(64 * WM, (X3 == 0 || WM > 4) ? 1 : (NB >= 2 ? 2 : 3)) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
     constexpr int SP = KC / 4;                 // 16-B slots per row
@@ -516,7 +537,9 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     constexpr int PN = LSTM ? 1 : NB;
     f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
     EpiCtx ec;
-    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec);
+    // (split mode: only the ConvLSTM cell state is requested a main loop early -- see conv3x3_band_kernel)
+    constexpr bool EARLY = LSTM || X3 == 0;
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec, true, EARLY);
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
     issue(0);
@@ -571,6 +594,7 @@ __global__ __launch_bounds__(64 * WM) void conv_igemm_kernel(const ConvArgs* __r
     }
 
     if (ablate & 4) return;   // timing ablation: no epilogue at all
+    if constexpr (!EARLY) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
     epi_finish<NB, LSTM, GROUPED, (X3 != 0)>(a, ec, n0, h, acc, pre, img_out);
 #endif   // __HIP_DEVICE_COMPILE__
 }
@@ -1040,7 +1064,7 @@ static int launch_wide(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
 // conv3x3_band_kernel; the implicit GEMM re-fetches the A tile for all 25 taps (2.4x the L2 -> LDS bytes).
 // Weight tiles: 2-slot ring, requested one step ahead; counted vmcnt + bare s_barrier.
 template <int NB>
-__global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int WM = 4, SP = 8, TM = 32 * WM;
@@ -1123,7 +1147,7 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
     f32x16 acc[NB];
     f32x16 pre[NB];
     EpiCtx ec;
-    epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec);
+    epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec, true, false);   // operands are loaded in the epilogue
 
     unsigned vmask = 0;      // validity of the 9 neighbour blocks of this lane's output pixel
     {
@@ -1174,6 +1198,7 @@ __global__ __launch_bounds__(256) void conv_band_prog_kernel(const ConvArgs* __r
         if (e & 64u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    epi_prefetch<NB, false, false>(a, n0, h, pre, ec);
     epi_finish<NB, false, false, true>(a, ec, n0, h, acc, pre, img_out);
 #endif
 }
@@ -1523,13 +1548,19 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc, 0, 0, 0);
             }
             const int oy = ty0 + ty, ox = tx0 + r;
-            if (oy < a.hp && ox < a.wp) {
-                float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
+            if (a.relu) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
+            }
+            float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
+            if (a.out_packed && a.group_store) {     // the lane pair of a pixel trades runs: each stores one whole 64-B PACKED group
+                float w16[16];
+                xchg16(acc, w16);
+                if (oy < a.hp && ox < a.wp) store16_packed(o, 0u, 16 * h, w16);
+            } else if (oy < a.hp && ox < a.wp) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = a.relu ? fmaxf(acc[4 * q + j], 0.f) : acc[4 * q + j];
+                    const f4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
                     if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
                     else *(f4*)(o + 8 * q + 4 * h) = v;
                 }

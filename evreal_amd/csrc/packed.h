@@ -55,6 +55,47 @@ __device__ __forceinline__ void store4_packed(float* p, unsigned row_off, int c4
     unsigned* q = (unsigned*)(p + pk_lo_off(row_off, c4));
     q[0] = lo8; q[4] = x8;
 }
+// ---- whole-group stores from the MFMA accumulator layout ----------------------------------------------------------
+// A lane of the 32x32 MFMA result holds, of a 32-channel block, v[4q + j] = channel 8q + 4h + j (h = lane >> 5, lanes l
+// and l ^ 32 = the two halves of one pixel).  xchg16 trades two 4-runs with the partner (v_permlane32_swap) so that the
+// lane owns the 16 CONSECUTIVE channels 16h .. 16h + 15 -- one whole PACKED group, stored as four contiguous 16-B
+// pieces instead of twelve scattered 8- and 4-B ones.  Partners must be both active or both inactive.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void xchg16(const f32x16_t& v, float (&w)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // swap(X, Y): X's upper-half lanes <-> Y's lower-half lanes.  (q0, q2): lower lanes end with own q0 | partner's q0,
+        // upper lanes with partner's q2 | own q2; (q1, q3) likewise
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[8 + j]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 + j]), __float_as_uint(v[12 + j]), false, false);
+        w[j] = __uint_as_float(a[0]); w[4 + j] = __uint_as_float(a[1]);
+        w[8 + j] = __uint_as_float(b[0]); w[12 + j] = __uint_as_float(b[1]);
+    }
+}
+// 16 consecutive channels (cg % 16 == 0) of the pixel row at float offset row_off -> one PACKED group
+__device__ __forceinline__ void store16_packed(float* p, unsigned row_off, int cg, const float (&w)[16]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    float c[16];
+    u4 hi0, hi1, lo, x8;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = __builtin_amdgcn_fmed3f(w[k], -65504.0f, 65504.0f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const h2_t a = {(_Float16)c[2 * k], (_Float16)c[2 * k + 1]}, b = {(_Float16)c[8 + 2 * k], (_Float16)c[8 + 2 * k + 1]};
+        hi0[k] = __builtin_bit_cast(unsigned, a); hi1[k] = __builtin_bit_cast(unsigned, b);
+        c[2 * k] = (c[2 * k] - (float)a[0]) * PK_LO_SCALE; c[2 * k + 1] = (c[2 * k + 1] - (float)a[1]) * PK_LO_SCALE;
+        c[8 + 2 * k] = (c[8 + 2 * k] - (float)b[0]) * PK_LO_SCALE; c[8 + 2 * k + 1] = (c[8 + 2 * k + 1] - (float)b[1]) * PK_LO_SCALE;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int t = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c[4 * k], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(c[4 * k + 1], -448.0f, 448.0f), 0, false);
+        lo[k] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c[4 * k + 2], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(c[4 * k + 3], -448.0f, 448.0f), t, true);
+        t = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(w[4 * k], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(w[4 * k + 1], -448.0f, 448.0f), 0, false);
+        x8[k] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(w[4 * k + 2], -448.0f, 448.0f), __builtin_amdgcn_fmed3f(w[4 * k + 3], -448.0f, 448.0f), t, true);
+    }
+    u4* q = (u4*)(p + row_off + (unsigned)cg);
+    q[0] = hi0; q[1] = hi1; q[2] = lo; q[3] = x8;
+}
 // one channel of a PACKED pixel row
 __device__ __forceinline__ float load1_packed(const float* row, int ch) {
     const unsigned char* g = (const unsigned char*)(row + (ch & ~15));

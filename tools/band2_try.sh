@@ -1,7 +1,16 @@
-run() { python bench.py --sub --no-overlap --profile-filter '' --steps 6 --warmup 2 2>/dev/null | python -c "
+run() { python bench.py --sub --no-overlap --profile-filter '' --steps 10 --warmup 3 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('$1', 'fps', d['value'], ' '.join(f\"{k}={v['us']:.0f}\" for k, v in d['roofline']['layers'].items()))"; }
+L = d['roofline']['layers']
+print('$1', 'fps', d['value'], 'sum_us', round(sum(v['us'] for v in L.values())), ' '.join(f\"{k}={v['us']:.0f}\" for k, v in L.items()))"; }
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_modes.py -x -q -m gpu 2>&1 | tail -3
-run "$1" | tee -a gpurun_out/mx_layers.txt
+for i in 1 2 3; do
+EVR_GROUP_STORE=1 run gs1 | tee -a gpurun_out/mx_layers.txt
+EVR_GROUP_STORE=0 run gs0 | tee -a gpurun_out/mx_layers.txt
+done
+EVR_GROUP_STORE=1 python bench.py --sub --steps 20 --warmup 5 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('gs1 overlap fps', d['value'])"
+EVR_GROUP_STORE=0 python bench.py --sub --steps 20 --warmup 5 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('gs0 overlap fps', d['value'])"
