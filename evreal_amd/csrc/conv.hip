@@ -189,6 +189,19 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
             unsigned opx; int cgb, oy, ox;
             out_addr<GROUPED>(a, ec, n0, h, nb, opx, cgb, oy, ox);
             const unsigned row = ec.mvalid ? opx * ct : 0u;
+            if constexpr (!LSTM) {
+                if (pk && a.group_store) {      // a PACKED operand: the lane's whole group (3 x 16 B), exchanged in epi_finish
+                    const int cg = cgb - 4 * h + 16 * h;
+                    f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
+                    if (cgb - 4 * h < nvalid) {      // wave-uniform: PACKED tensors have whole 32-channel blocks or none
+                        const f4* gp = (const f4*)(pre_ptr + row + (unsigned)cg);
+                        g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { pre[nb][j] = g0[j]; pre[nb][4 + j] = g1[j]; pre[nb][8 + j] = g2[j]; }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -333,6 +346,14 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
             f32x16 outv;
 #pragma unroll
             for (int i = 0; i < 16; ++i) outv[i] = 0.f;
+            const bool pre_group = has_pre && pre_pk && a.group_store;
+            f32x16 pvall = pre[nb];
+            if (pre_group) {      // whole-group operand (epi_prefetch): decode, back to the accumulator order (all lanes take part)
+                unsigned g[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) g[i] = __float_as_uint(pre[nb][i]);
+                unpack16_xchg(g, pvall);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c4 = cgb + 8 * q;                    // channel inside the column group
@@ -342,8 +363,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 if (mvalid && c4 < nvalid) {
                     const unsigned orow = opx * ct;
                     // the prefetched operand (raw bits from epi_setup), decoded if PACKED
-                    f4 pv = {pre[nb][4 * q], pre[nb][4 * q + 1], pre[nb][4 * q + 2], pre[nb][4 * q + 3]};
-                    if (has_pre && pre_pk) {
+                    f4 pv = {pvall[4 * q], pvall[4 * q + 1], pvall[4 * q + 2], pvall[4 * q + 3]};
+                    if (has_pre && pre_pk && !pre_group) {
                         const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])};
                         pv = unpack4(phi, __float_as_uint(pv[2]));
                     }

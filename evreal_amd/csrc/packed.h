@@ -96,6 +96,27 @@ __device__ __forceinline__ void store16_packed(float* p, unsigned row_off, int c
     u4* q = (u4*)(p + row_off + (unsigned)cg);
     q[0] = hi0; q[1] = hi1; q[2] = lo; q[3] = x8;
 }
+// the reverse: one PACKED group as loaded (hi 8 dwords | lo8 4 dwords) -> its 16 values -> the accumulator order of the
+// lane pair (the same swaps: v_permlane32_swap is its own inverse on a register pair)
+__device__ __forceinline__ void unpack16_xchg(const unsigned (&g)[12], f32x16_t& v) {
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {      // lo8 dword d = channels 4d .. 4d + 3 = hi dwords 2d, 2d + 1
+        const h2_t h0 = __builtin_bit_cast(h2_t, g[2 * d]), h1 = __builtin_bit_cast(h2_t, g[2 * d + 1]);
+        const int lo = (int)g[8 + d];
+        w[4 * d] = fmaf(__builtin_amdgcn_cvt_f32_fp8(lo, 0), PK_LO_INV, (float)h0[0]);
+        w[4 * d + 1] = fmaf(__builtin_amdgcn_cvt_f32_fp8(lo, 1), PK_LO_INV, (float)h0[1]);
+        w[4 * d + 2] = fmaf(__builtin_amdgcn_cvt_f32_fp8(lo, 2), PK_LO_INV, (float)h1[0]);
+        w[4 * d + 3] = fmaf(__builtin_amdgcn_cvt_f32_fp8(lo, 3), PK_LO_INV, (float)h1[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[j]), __float_as_uint(w[4 + j]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[8 + j]), __float_as_uint(w[12 + j]), false, false);
+        v[j] = __uint_as_float(a[0]); v[8 + j] = __uint_as_float(a[1]);
+        v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
+    }
+}
 // one channel of a PACKED pixel row
 __device__ __forceinline__ float load1_packed(const float* row, int ch) {
     const unsigned char* g = (const unsigned char*)(row + (ch & ~15));
