@@ -389,7 +389,7 @@ def main():
                                   "count": int(tot[0, 3])}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": ("conv3x3_wide_kernel<LSTM=true> (ConvLSTM gate convolutions, 256 x 256 block tiles)" if x3 else
+                         "kernel": ("conv3x3_wide_kernel<LSTM=true, WN> (ConvLSTM gate convolutions: 256 x 128 tiles, two blocks per CU, up to 256 input channels; 256 x 256 tiles above)" if x3 else
                                     "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=0> (ConvLSTM gate convolutions)"),
                          "arithmetic": ("split: x = hi + lo8*2^-12, w = hi + wlo8*2^-(e+12) (f16 hi, fp8 e4m3 residuals); per 32 k "
                                         "acc += hi_w*hi_x on 2 x v_mfma_f32_32x32x16_f16 + (w8*lo8 + wlo8*x8) on 1 x "

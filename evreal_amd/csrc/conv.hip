@@ -1239,9 +1239,10 @@ static bool band_prog_eligible(const ConvArgs& a, int kc) {
     if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ngroups == 1 && a.tp.ntaps == 25 && a.stride == 2 && a.os == 1)) return false;
     if (a.in_mode != IN_SINGLE || a.hin != 2 * a.hm || a.win != 2 * a.wm || a.hout != a.hm || a.wout != a.wm) return false;
     if (a.cout % 64 != 0 || a.pred_w) return false;
-    // measured (64 sequences of 352x264): 64 columns (enc0: 595 -> 510 us) wins; at 128/256 columns the implicit GEMM
-    // is as fast or faster (470/440 vs 480/480 us) -- EVR_BAND_PROG_ALL=1 forces the band form for every width
-    static const bool all = getenv("EVR_BAND_PROG_ALL") != nullptr;
+    // measured (64 sequences of 352x264): 64 columns (enc0) 595 -> 510 us with three bf16 products; at 128/256 columns the
+    // band form only tied the implicit GEMM then, but with 2/3 of the matrix cycles the implicit GEMM's 25-fold A re-fetch
+    // (64 B/clk/CU from L2) is the limit: 420/378 -> 395/360 us.  EVR_BAND_PROG_ALL=0 restores the implicit GEMM there.
+    static const bool all = getenv("EVR_BAND_PROG_ALL") ? atoi(getenv("EVR_BAND_PROG_ALL")) != 0 : true;
     if (a.cout % 128 == 0 && !all) return false;
     const int nb = (a.cout % 128 == 0) ? 4 : 2;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;

@@ -114,44 +114,53 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
     st4_any(out + (((int64_t)b * ho + oy) * wo + ox) * c, c4 * 4, m, out_packed);
 }
 
-// one channel of a pixel row, PLAIN or PACKED
-__device__ __forceinline__ float ld1_any(const float* row, int ch, int packed) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (packed) return load1_packed(row, ch);
-#endif
-    return row[ch];
-}
-
-// ---- per-layer score: one wave per pixel -------------------------------------------------------------------------
-// feat: NHWC [2n, h, w, C] (first n = img, last n = ref); out partial[n][blocks] of sum over pixels
+// ---- per-layer score ------------------------------------------------------------------------------------------------
+// feat: NHWC [2n, h, w, C] (first n = img, last n = ref); out partial[n][blocks] of sum over pixels.
+// A lane owns 4-channel runs (one 16-B access on PLAIN rows, 8 B + 4 B on PACKED ones): R = C / 4 runs per pixel.  With
+// R = 16 (relu1, C = 64) a wave takes four pixels at once (16-lane reductions); otherwise one pixel per wave and up to two
+// runs per lane (C <= 512).
 __global__ __launch_bounds__(256) void lpips_score_kernel(const float* __restrict__ feat, const float* __restrict__ lin, int n, int hw,
                                                            int C, double* __restrict__ partials, int blocks_per_img, int packed) {
     __shared__ double red[4];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* f0 = feat + (int64_t)b * hw * C;
     const float* f1 = feat + (int64_t)(b + n) * hw * C;
+    const int R = C >> 2;
+    const int P = (R <= 16) ? 4 : 1;                    // pixels per wave
+    const int sub = (P == 4) ? (lane >> 4) : 0;         // the lane's pixel inside the wave
+    const int run0 = (P == 4) ? (lane & 15) : lane;
     double acc = 0.0;
-    for (int p = blockIdx.x * 4 + wave; p < hw; p += blocks_per_img * 4) {
-        float a[6], c[6];                      // C <= 384
+    for (int p0 = (blockIdx.x * 4 + wave) * P; p0 < hw; p0 += blocks_per_img * 4 * P) {
+        const int p = p0 + sub;
+        const bool pok = p < hw;
+        float4 a[2], c[2];
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int ch = lane + 64 * k;
-            a[k] = (ch < C) ? ld1_any(f0 + (int64_t)p * C, ch, packed) : 0.f;
-            c[k] = (ch < C) ? ld1_any(f1 + (int64_t)p * C, ch, packed) : 0.f;
-            s0 = fmaf(a[k], a[k], s0); s1 = fmaf(c[k], c[k], s1);
+        for (int k = 0; k < 2; ++k) {
+            const int run = run0 + 64 * k;
+            a[k] = make_float4(0.f, 0.f, 0.f, 0.f); c[k] = a[k];
+            if (pok && run < R && (k == 0 || P == 1)) {
+                a[k] = ld4_any(f0 + (int64_t)p * C, run * 4, packed);
+                c[k] = ld4_any(f1 + (int64_t)p * C, run * 4, packed);
+            }
+            s0 += (a[k].x * a[k].x + a[k].y * a[k].y) + (a[k].z * a[k].z + a[k].w * a[k].w);
+            s1 += (c[k].x * c[k].x + c[k].y * c[k].y) + (c[k].z * c[k].z + c[k].w * c[k].w);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        const int top = (P == 4) ? 8 : 32;               // reduce over the lanes of one pixel
+        for (int o = top; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
         const float n0 = sqrtf(s0) + 1e-10f, n1 = sqrtf(s1) + 1e-10f;
         float d = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int ch = lane + 64 * k;
-            if (ch < C) { const float e = a[k] / n0 - c[k] / n1; d = fmaf(lin[ch], e * e, d); }
+        for (int k = 0; k < 2; ++k) {
+            const int run = run0 + 64 * k;
+            if (pok && run < R && (k == 0 || P == 1)) {
+                const float4 w = *(const float4*)(lin + run * 4);
+                const float e0 = a[k].x / n0 - c[k].x / n1, e1 = a[k].y / n0 - c[k].y / n1;
+                const float e2 = a[k].z / n0 - c[k].z / n1, e3 = a[k].w / n0 - c[k].w / n1;
+                d = fmaf(w.x, e0 * e0, d); d = fmaf(w.y, e1 * e1, d); d = fmaf(w.z, e2 * e2, d); d = fmaf(w.w, e3 * e3, d);
+            }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);      // all pixels of the wave together
         acc += (double)d;
     }
     if (lane == 0) red[wave] = acc;
