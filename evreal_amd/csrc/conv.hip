@@ -64,10 +64,6 @@ __device__ __forceinline__ SplitFrag ld_split(const float4* row, int h, int sw) 
     f.f1 = __builtin_bit_cast(u32x4_t, row[(6 + h) ^ sw]);
     return f;
 }
-__device__ __forceinline__ void zero_unless(SplitFrag& f, bool keep) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f.h0[e] = keep ? f.h0[e] : 0u; f.h1[e] = keep ? f.h1[e] : 0u; f.f0[e] = keep ? f.f0[e] : 0u; f.f1[e] = keep ? f.f1[e] : 0u; }
-}
 __device__ __forceinline__ i32x8 cat8(u32x4_t p, u32x4_t q) {
     typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(i32x8, (u32x8_t)__builtin_shufflevector(p, q, 0, 1, 2, 3, 4, 5, 6, 7));   // a register sequence, no copies
