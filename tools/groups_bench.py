@@ -16,6 +16,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 Wm = 3
+WS, HS = 346, 260
 dev = torch.device('cuda', 0)
 kw = dict(weights.E2VID_KWARGS)
 sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
@@ -25,9 +26,9 @@ for g in range(G):
     st = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(st):
         net = model.E2VIDRecurrent(kw); net.load_state_dict(sd)
-        xy, ts, pol, offs, refs, _ = bench.build_inputs(g, n, K + Wm, dev)
+        xy, ts, pol, offs, refs, _ = bench.build_inputs(g, n, K + Wm, dev, WS, HS)
         lp = LPIPS(weights.synth_lpips_state_dict(seed=0))
-        hp = HotPath(net, bench.BINS, (bench.H_, bench.W_), n, event_tensor_normalization=True, post_process_norm='robust',
+        hp = HotPath(net, bench.BINS, (HS, WS), n, event_tensor_normalization=True, post_process_norm='robust',
                      metrics=('mse', 'ssim', 'lpips'), device=str(dev), lpips=lp, overlap=True)
         scores = torch.zeros((K + Wm, n, 3), dtype=torch.float64, device=dev)
     groups.append((st, hp, xy, ts, pol, offs, refs, scores))
