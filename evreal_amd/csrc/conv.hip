@@ -189,7 +189,7 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
                 if (pk && a.group_store) {      // a PACKED operand: the lane's whole group (3 x 16 B), exchanged in epi_finish
                     const int cg = cgb - 4 * h + 16 * h;
                     f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
-                    if (cgb - 4 * h < nvalid) {      // wave-uniform: PACKED tensors have whole 32-channel blocks or none
+                    if (cg < nvalid) {               // (a 16-channel tail block: only the lower half of the lane pair loads)
                         const f4* gp = (const f4*)(pre_ptr + row + (unsigned)cg);
                         g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
                     }

@@ -1612,6 +1612,12 @@ extern "C" int evr_split_pack(const float* src, float* dst, int64_t n) {
     return EVR_OK;
 }
 
+// the device codec (packed.h through to_packed_kernel): src/dst device pointers, dst may equal src
+extern "C" int evr_split_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_pack_device: n = %lld must be a multiple of 16", (long long)n);
+    return launch_to_packed(src, dst, n, (hipStream_t)stream);
+}
+
 extern "C" int evr_split_unpack(const float* src, float* dst, int64_t n) {
     EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_unpack: n = %lld must be a multiple of 16", (long long)n);
     unpack_split_act(src, dst, (size_t)n);

@@ -70,6 +70,7 @@ SYMBOLS = {
     'evr_color_merge': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'evr_split_pack': (c_int, [c_void_p, c_void_p, c_int64]),
     'evr_split_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_split_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -241,6 +241,9 @@ int evr_color_merge(const float* planes, const float* gray, int n, int H, int W,
  */
 int evr_split_pack(const float* src, float* dst, int64_t n);
 int evr_split_unpack(const float* src, float* dst, int64_t n);
+/* the same packing done by the device code the kernels use (src / dst device pointers, in place allowed): lets a test pin the
+ * hardware conversions (f16 RNE, OCP e4m3 RNE, saturation) against the host codec bit for bit */
+int evr_split_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -106,3 +106,21 @@ def test_metrics_kernel_against_the_published_definition():
         x, y = z[m['name'] + '.x'], z[m['name'] + '.y']
         out = met(torch.from_numpy(x[None]).cuda(), torch.from_numpy(y[None]).cuda(), clip=False).cpu().numpy()[0]
         assert abs(out[0] - m['mse']) < 1e-9 and abs(out[1] - m['ssim']) < 5e-6, (m['name'], out)
+
+
+def test_device_split_codec_matches_host_bit_for_bit():
+    """The PACKED codec as the kernels' epilogues run it (v_cvt_f16_f32, v_cvt_pk_fp8_f32 after the clamps) against the host
+    codec, which tests/test_split_codec.py pins to numpy / torch dtypes: f16 RNE incl. subnormals, OCP e4m3 RNE, saturation."""
+    import ctypes
+    from evreal_amd import lib as _lib
+    L = _lib.load()
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.standard_normal(1 << 16) * 10.0 ** rng.integers(-9, 4, 1 << 16),
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 0.5, 255.0, 447.9, 448.0, 449.0, 65504.0, 65519.0, 7e4, 2.0 ** -14]]).astype(np.float32)
+    x = np.resize(x, (x.size // 16) * 16)
+    want = np.empty_like(x)
+    assert L.evr_split_pack(x.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), x.size) == 0
+    d = torch.from_numpy(x).cuda()
+    _lib.check(L.evr_split_pack_device(_lib.ptr(d), _lib.ptr(d), x.size, _lib.stream_ptr()), 'evr_split_pack_device')
+    got = d.cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
