@@ -680,12 +680,17 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
 
     // per-lane constants of the DMA pieces this wave issues (piece j = wmi + jj*WM; lane -> row 8j + lane/8, slot lane%8)
-    int a_pix[NA_MAX]; unsigned a_q[NA_MAX];
+    // per-lane byte offset of a piece's quad at shift 0 in either source ((pixel * channels + swizzled slot) * 4; may wrap
+    // for the pixel before the tensor, which the range test below excludes): the step adds a wave-uniform term only --
+    // no per-request multiply (v_mul_lo_u32 is quarter rate) in the loop
+    int a_pix[NA_MAX]; unsigned a_v0[NA_MAX], a_v1[NA_MAX];
 #pragma unroll
     for (int jj = 0; jj < NA_MAX; ++jj) {
         const int row = 8 * (wmi + jj * WM) + (lane >> 3);
         a_pix[jj] = m0 - 1 + row;
-        a_q[jj] = (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+        const unsigned q = (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+        a_v0[jj] = ((unsigned)(a_pix[jj] * c0) + q) * 4u;
+        a_v1[jj] = ((unsigned)(a_pix[jj] * c1) + q) * 4u;
     }
     unsigned b_off[NBW];
 #pragma unroll
@@ -702,12 +707,13 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
         const int csrc = second ? c1 : c0;
         if (second) coff -= c0;
         const int shift = (dyi - 1) * W;
+        const unsigned uni = (unsigned)((shift * csrc + coff) * 4);      // wave-uniform part of the byte offset
 #pragma unroll
         for (int jj = 0; jj < NA_MAX; ++jj) {
             if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
                 const int pix = a_pix[jj] + shift;
                 unsigned voff = OOB_OFFSET;
-                if (live && (unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q[jj]) * 4u;
+                if (live && (unsigned)pix < in_pix) voff = (second ? a_v1[jj] : a_v0[jj]) + uni;
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
@@ -943,6 +949,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
     const int a_pix0 = m0 - 1 + row0;
     const unsigned a_q0 = (unsigned)((((lane & 7) ^ swz<32>(row0)) * 4));
     const unsigned b_off0 = (unsigned)((n0 + row0) * ktot) + a_q0;
+    // byte offset of piece 0's quad at shift 0 in either source (may wrap before the tensor; the range test excludes it):
+    // a request adds wave-uniform terms only -- no per-request multiply in the loop
+    const unsigned a_v0 = ((unsigned)(a_pix0 * c0) + a_q0) * 4u, a_v1 = ((unsigned)(a_pix0 * c1) + a_q0) * 4u;
     auto issue_band = [&](int cc, int dyi, int buf) {
         int coff = cc * 32;
         const bool second = coff >= c0;
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
             if (jj < NA_MIN || wv + jj * NW < A_PIECES) {      // wave-uniform
                 const int pix = a_pix0 + 8 * NW * jj + shift;
                 unsigned voff = OOB_OFFSET;
-                if ((unsigned)pix < in_pix) voff = ((unsigned)pix * (unsigned)csrc + (unsigned)coff + a_q0) * 4u;
+                if ((unsigned)pix < in_pix) voff = (second ? a_v1 : a_v0) + (unsigned)(((8 * NW * jj + shift) * csrc + coff) * 4);
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wv + jj * NW) * 64];
                 if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
@@ -1128,7 +1137,9 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
         int rho = 0x20000000, x = 0;
         if (mb >= 0 && mb < M) { rho = mb / Wb; x = mb - rho * Wb; }
         a_rho[jj] = rho;
-        a_xq[jj] = (unsigned)x * pix_pitch + (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+        // byte offset at dy = 0, phase 0, chunk 0 (garbage for the sentinel row, which the range test excludes): a request
+        // adds a wave-uniform term only, no per-request multiply
+        a_xq[jj] = ((unsigned)rho * row_pitch + (unsigned)x * pix_pitch + (unsigned)((((lane & 7) ^ swz<32>(row)) * 4))) * 4u;
     }
     unsigned b_off[NBW];
 #pragma unroll
@@ -1144,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
             if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
                 const int rho = a_rho[jj] + dy;
                 unsigned voff = OOB_OFFSET;
-                if ((unsigned)rho < (unsigned)nrows) voff = ((unsigned)rho * row_pitch + a_xq[jj] + choff) * 4u;
+                if ((unsigned)rho < (unsigned)nrows) voff = a_xq[jj] + (unsigned)(dy * (int)row_pitch + (int)choff) * 4u;
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
             }
