@@ -85,6 +85,7 @@ struct ConvArgs {
     int crop_h, crop_w, crop_y0, crop_x0;
     int x3;                   // weights are in the split layout (pack_split_weights) and in0/in1 are PACKED tensors:
     int in_packed;            //   the main loop feeds LDS slots straight to the MFMAs
+    unsigned div_hw_mul, div_hw_sh, div_w_mul, div_w_sh;   // m / (hm*wm) and r / wm by multiply-high (set_fastdiv)
     int group_store;          // PACKED outputs as whole 64-B groups after a lane exchange (packed.h xchg16); 0: 4-channel pieces
     int mx_sa, mx_sb;         // E8M0 block scales of the fp8 correction MFMA: 127 - 12 (activations), 127 - e (weights)
     int out_packed;           // write `out` PACKED (n_valid and cout_total multiples of 8)
@@ -98,6 +99,21 @@ struct ConvArgs {
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
 };
+
+// Division of n < 2^31 by an invariant d >= 1 as (umulhi(n, mul) + n) >> sh (Granlund-Montgomery, round-up form):
+// sh = ceil(log2 d), mul = floor(2^32 (2^sh - d) / d) + 1 (0 for powers of two).  A run-time v_udiv costs ~35 VALU
+// instructions; the short-K kernels decode a pixel index per block with two of them.
+inline void fastdiv_magic(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = s;
+    *mul = (unsigned)((((1ull << s) - d) << 32) / d + 1ull);
+    if (((1ull << s) - d) == 0) *mul = 0;
+}
+inline void set_fastdiv(ConvArgs& a) {
+    fastdiv_magic((unsigned)(a.hm * a.wm), &a.div_hw_mul, &a.div_hw_sh);
+    fastdiv_magic((unsigned)a.wm, &a.div_w_mul, &a.div_w_sh);
+}
 
 // fp32 -> bf16 bits, round to nearest even (head_mfma_kernel's weight fragments)
 inline unsigned short bf16_rne(float f) {

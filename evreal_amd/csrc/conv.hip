@@ -79,6 +79,8 @@ __device__ __forceinline__ f32x16 mma_split(f32x16 acc, const SplitFrag& w, cons
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// n / d for n < 2^31 with the multiplier of conv.h fastdiv_magic
+__device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned sh) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> sh); }
 // Gate activations.  FAST (split mode): v_exp_f32 / v_rcp_f32 forms, absolute error ~2e-7 -- an order below the
 // mode's own 2^-16 input rounding; the exact-fp32 mode keeps the libm-grade functions.
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
@@ -157,9 +159,9 @@ __device__ __forceinline__ void epi_setup(const ConvArgs& a, int m, int M, int h
     ec.e_img = 0; ec.e_my = 0; ec.e_mx = 0;
     if (!ec.direct || a.pred_w) {
         const int mm = ec.mvalid ? m : 0;
-        ec.e_img = mm / hw;
+        ec.e_img = fdiv(mm, a.div_hw_mul, a.div_hw_sh);
         const int rem = mm - ec.e_img * hw;
-        ec.e_my = rem / a.wm; ec.e_mx = rem - ec.e_my * a.wm;
+        ec.e_my = fdiv(rem, a.div_w_mul, a.div_w_sh); ec.e_mx = rem - ec.e_my * a.wm;
     }
     ec.lstm_o = (unsigned)(ec.mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
     if (prefetch) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0 || WM > 4) ? 1 : (NB >= 2 ? 2 : 3
         a_q4[j] = (unsigned)(((idx % SP) ^ swz<KC>(row)) * 4);
         const int m = m0 + row;
         if (m < M) {
-            const int img = m / hw, rem = m - img * hw;
-            const int my = rem / a.wm, mx = rem - my * a.wm;
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;
+            const int my = fdiv(rem, a.div_w_mul, a.div_w_sh), mx = rem - my * a.wm;
             r_pix[j] = img * hin; r_iy[j] = my * a.stride; r_ix[j] = mx * a.stride;
         } else {
             r_pix[j] = 0; r_iy[j] = -(1 << 28); r_ix[j] = 0;
@@ -759,8 +761,8 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     {
         const int m = m0 + idx - SHIFT;
         if (lane_ok && m < M) {
-            const int img = m / hw, rem = m - img * hw;
-            const int py = rem / W, px = rem - py * W;
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;   // (W == a.wm: stride 1 on the input's grid)
+            const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * W;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
@@ -993,8 +995,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
     auto neighbours = [&](int m) -> unsigned {   // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
         unsigned vm = 0;
         if (m < M) {
-            const int img = m / hw, rem = m - img * hw;
-            const int py = rem / W, px = rem - py * W;
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;   // (W == a.wm: stride 1 on the input's grid)
+            const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * W;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
         const int row = 8 * (wmi + jj * WM) + (lane >> 3);
         const int mb = m0 - 1 + row;
         int rho = 0x20000000, x = 0;
-        if (mb >= 0 && mb < M) { rho = mb / Wb; x = mb - rho * Wb; }
+        if (mb >= 0 && mb < M) { rho = fdiv(mb, a.div_w_mul, a.div_w_sh); x = mb - rho * Wb; }
         a_rho[jj] = rho;
         // byte offset at dy = 0, phase 0, chunk 0 (garbage for the sentinel row, which the range test excludes): a request
         // adds a wave-uniform term only, no per-request multiply
@@ -1181,8 +1183,8 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
     {
         const int m = m0 + idx;
         if (m < M) {
-            const int img = m / hw, rem = m - img * hw;
-            const int py = rem / Wb, px = rem - py * Wb;
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;
+            const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * Wb;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
@@ -1284,6 +1286,8 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split mode");
     EVR_REQUIRE(!a.x3 || a.in_packed, "conv_igemm: the split kernels take PACKED inputs");
     EVR_REQUIRE(!a.x3 || (a.mx_sa > 0 && a.mx_sb > 0), "conv_igemm: split mode without block scales");
+    EVR_REQUIRE(a.div_hw_sh < 32 && a.div_w_sh < 32 && (a.div_hw_mul || (unsigned)(a.hm * a.wm) == (1u << a.div_hw_sh)) && (a.div_w_mul || (unsigned)a.wm == (1u << a.div_w_sh)),
+                "conv_igemm: plan without set_fastdiv()");
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
     const int mode = a.x3 ? 2 : 0;
     if (band_prog_eligible(a, kc)) {

@@ -326,7 +326,7 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
         a.epi = EPI_BIAS_RELU; a.x3 = L.x3 ? 1 : 0;
         a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED in split mode
-        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store();
+        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));

@@ -797,7 +797,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
-        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store();
+        a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;
