@@ -903,7 +903,9 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 // (33.8 KB + 2 x 16 KB of weight tiles = 66 KB): TWO independent blocks per CU, so a SIMD's two waves belong to
 // different blocks and do not stall at the same barrier; the price is the band switch every third step -- barrier,
 // request the next band, wait for it, barrier -- whose DMA latency the other block's MFMAs have to cover.
-template <bool LSTM, int WN>
+// GROUPED / PHASES: the transposed decoders, as in conv3x3_band_kernel (phase-major N, (tap, phase) pairs the transposed
+// kernel does not connect skipped: whole steps when no phase of the tile uses the tap, blocks at compile time via PHASES).
+template <bool LSTM, int WN, bool GROUPED = false, int PHASES = 0>
 __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -990,8 +992,14 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
     f32x16 late[PN];             // the epilogue's operands, loaded there
     EpiCtx ec0, ec1;
     const int mA = m0 + wmi * 64 + r, mB = mA + 32;
-    epi_setup<NB, LSTM, false>(a, mA, M, hw, n0w, h, acc0, late, ec0, true, false);   // prefetch = false: `late` untouched
-    epi_setup<NB, LSTM, false>(a, mB, M, hw, n0w, h, acc1, late, ec1, true, false);
+    epi_setup<NB, LSTM, GROUPED>(a, mA, M, hw, n0w, h, acc0, late, ec0, true, false);   // prefetch = false: `late` untouched
+    epi_setup<NB, LSTM, GROUPED>(a, mB, M, hw, n0w, h, acc1, late, ec1, true, false);
+    int tile_groups = 0;         // phases of this wave's 128 columns, and per tap those that use it (conv3x3_band_kernel)
+    if constexpr (GROUPED) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0w + nb * 32) / a.tp.grp_cols);
+    }
+    auto tap_use = [&](int t) -> int { return GROUPED ? (a.tp.tap_groups[t] & tile_groups) : 1; };
     auto neighbours = [&](int m) -> unsigned {   // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
         unsigned vm = 0;
         if (m < M) {
@@ -1042,12 +1050,16 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
             const SplitFrag xa1 = ld_split(&lds[i1 * SP], h, swz<32>(l1));
             // one block's weight fragments at a time (the scheduler would otherwise hoist all four: +48 registers, spills;
             // reading one block ahead -- left to the scheduler or pinned with scheduling barriers -- measured no faster)
+            if (!GROUPED || tap_use(t)) {      // wave-uniform: a tap no phase of these columns uses is skipped whole
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
+                if constexpr (PHASES == 1) { if ((t / 3 == 0 && (nb >> 1) == 1) || (t % 3 == 0 && (nb & 1) == 1)) continue; }
+                if constexpr (PHASES == 2) { if (t % 3 == 0 && (nb >> 1) == 1) continue; }
                 const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
                 acc0[nb] = mma_split(acc0[nb], wb, xa0, mx_sb, mx_sa);
                 acc1[nb] = mma_split(acc1[nb], wb, xa1, mx_sb, mx_sa);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in
             // flight (loads complete in order).  lgkmcnt(0): this wave's fragment reads have left LDS before anyone
@@ -1064,18 +1076,50 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
             }
         }
     }
-    epi_prefetch<NB, LSTM, false>(a, n0w, h, late, ec0);
-    epi_finish<NB, LSTM, false, true>(a, ec0, n0w, h, acc0, late, img_out);
-    epi_prefetch<NB, LSTM, false>(a, n0w, h, late, ec1);
-    epi_finish<NB, LSTM, false, true>(a, ec1, n0w, h, acc1, late, img_out);
+    if constexpr (LSTM) {      // the cell update needs the four gate blocks together
+        epi_prefetch<NB, true, false>(a, n0w, h, late, ec0);
+        epi_finish<NB, true, false, true>(a, ec0, n0w, h, acc0, late, img_out);
+        epi_prefetch<NB, true, false>(a, n0w, h, late, ec1);
+        epi_finish<NB, true, false, true>(a, ec1, n0w, h, acc1, late, img_out);
+    } else {
+        // plain epilogues: one 32-column block at a time, and the second pixel block's 64 accumulators wait in LDS (idle
+        // now: the last step ended with vmcnt(0) + barrier) -- 128 live accumulators plus the epilogue's operand /
+        // conversion registers do not fit in 256, and hipcc's own spill goes to scratch memory
+        float4* park = &lds[wv * 1024];        // 16 KB per wave
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                park[(nb * 4 + q) * 64 + lane] = make_float4(acc1[nb][4 * q], acc1[nb][4 * q + 1], acc1[nb][4 * q + 2], acc1[nb][4 * q + 3]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x16 one[1], op[1];
+            one[0] = acc0[nb];
+            epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec0);
+            epi_finish<1, false, GROUPED, true>(a, ec0, n0w + 32 * nb, h, one, op, img_out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x16 one[1], op[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = park[(nb * 4 + q) * 64 + lane];
+                one[0][4 * q] = v.x; one[0][4 * q + 1] = v.y; one[0][4 * q + 2] = v.z; one[0][4 * q + 3] = v.w;
+            }
+            epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec1);
+            epi_finish<1, false, GROUPED, true>(a, ec1, n0w + 32 * nb, h, one, op, img_out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #endif
 }
 
-template <bool LSTM, int WN>
+template <bool LSTM, int WN, bool GROUPED = false, int PHASES = 0>
 static int launch_wide(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int total = ((M + 255) / 256) * (a.cout / (128 * WN));
-    hipLaunchKernelGGL((conv3x3_wide_kernel<LSTM, WN>), dim3(total), dim3(256 * WN), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv3x3_wide_kernel<LSTM, WN, GROUPED, PHASES>), dim3(total), dim3(256 * WN), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
@@ -1327,6 +1371,15 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
                     rule = a.tp.tap_groups[t] == want;
                 }
                 for (int g = 0; g < 4 && rule; ++g) rule = a.tp.grp_ofy[g] == (g >> 1) && a.tp.grp_ofx[g] == (g & 1);
+                // 256 x 128 tiles, two blocks per CU (the twin form of conv3x3_wide_kernel), once there are enough of them:
+                // half the LDS-DMA bytes per MFMA cycle of the 128 x 128 tiles (EVR_WIDE_DEC=0: never)
+                static const int wide_dec = getenv("EVR_WIDE_DEC") ? atoi(getenv("EVR_WIDE_DEC")) : 1;
+                const bool twin_ok = wide_dec && rule && (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min &&
+                                     (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU) && (!a.pred_w || a.tp.grp_cols == 32);   // (a fused
+                // prediction must close inside one 32-column block: the epilogue runs block by block)
+                if (twin_ok && a.tp.grp_cols == 32) return launch_wide<false, 1, true, 1>(a, d_args, stream, img);
+                if (twin_ok && a.tp.grp_cols == 64) return launch_wide<false, 1, true, 2>(a, d_args, stream, img);
+                if (twin_ok && a.tp.grp_cols % 128 == 0) return launch_wide<false, 1, true, 0>(a, d_args, stream, img);
                 if (rule && a.tp.grp_cols == 32) return launch_band<4, 2, false, true, false, 1>(a, d_args, stream, img);
                 if (rule && a.tp.grp_cols == 64) return launch_band<4, 2, false, true, false, 2>(a, d_args, stream, img);
                 return launch_band<4, 2, false, true>(a, d_args, stream, img);
