@@ -1353,7 +1353,12 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
             const bool twin = (wide == 2) || (wide == 1 && a.c0 + a.c1 <= 256);
             return twin ? launch_wide<true, 1>(a, d_args, stream, img) : launch_wide<true, 2>(a, d_args, stream, img);
         }
-        // (the plain-epilogue instance needs 10 registers more than two waves per SIMD leave: not instantiated)
+        // plain 3x3 layers (residual blocks): the twin form once a launch has enough 256 x 128 tiles (not at 64 sequences of
+        // 346x260: 726 tiles for 512 slots; from 128 sequences or 640x480 up)
+        if (wide && a.tp.ngroups == 1 && a.cout % 128 == 0 && !a.pred_w &&
+            (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RESIDUAL_RELU) &&
+            (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min)
+            return launch_wide<false, 1>(a, d_args, stream, img);
         if (a.epi == EPI_LSTM) {
             if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);
             if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
