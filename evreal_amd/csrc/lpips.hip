@@ -39,6 +39,8 @@ struct Conv1Args {
     const float* bias;                     // [64]
     const float* bias_in;                  // [64] bias + sum_t wb[t]  (interior tiles)
     float* out;
+    const unsigned* wfrag;                 // matrix-core form: wg in MFMA-fragment order (conv1_pack_wfrag), bf16 hi / lo
+    const float* wbsum;                    // [12][12][64] prefix sums of wb over (ky, kx): the padding term of a border pixel
 };
 
 __global__ __launch_bounds__(256) void lpips_conv1_kernel(const Conv1Args a) {
@@ -93,6 +95,116 @@ __global__ __launch_bounds__(256) void lpips_conv1_kernel(const Conv1Args a) {
         for (int co = 0; co < 64; co += 4)
             *(float4*)(o + co) = make_float4(fmaxf(acc[co], 0.f), fmaxf(acc[co + 1], 0.f), fmaxf(acc[co + 2], 0.f), fmaxf(acc[co + 3], 0.f));
     }
+}
+
+// conv1 on the matrix cores (split mode): GEMM M = pixels, N = 64, K = 121 taps padded to 128, three bf16 products
+// (x = hi + lo, w = hi + lo) like the networks' head conv.  The gray tile sits in LDS; lane (pixel r, half h) gathers the 8
+// taps k = 16s + 8h + j of slab s at compile-time offsets from its pixel's window origin; the weight fragments (32 KB, packed
+// on the host) are copied to LDS once per block.  The padding term sum_t inside[t] * wb[t] is a rectangle sum over the
+// window's in-image taps: 4 look-ups in the prefix table for border pixels, the folded bias for the others.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void lpips_conv1_mfma_kernel(const Conv1Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TS = 16, K = 11, S = 4, P = 2, IS = (TS - 1) * S + K;   // 71
+    extern __shared__ float smem[];
+    float* tile = smem;                                   // [IS][IS] gray (0 outside the image)
+    const float4* wf = (const float4*)(smem + IS * IS + 3);   // [8 slabs][2 blocks][hi, lo][64 lanes] x 16 B (16-B aligned: 5041 + 3)
+    const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
+    const float* src = (b < a.n ? a.img + (int64_t)b * a.H * a.W : a.ref + (int64_t)(b - a.n) * a.H * a.W);
+    const int y_lo = ty0 * S - P, x_lo = tx0 * S - P;
+    for (int i = tid; i < IS * IS; i += 256) {
+        const int rr = i / IS, cc = i % IS;
+        const int y = y_lo + rr, x = x_lo + cc;
+        float g = 0.f;
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
+            g = src[(int64_t)y * a.W + x];
+            if (a.clip) g = fminf(fmaxf(g, 0.f), 1.f);
+        }
+        tile[i] = g;
+    }
+    {
+        float4* dst = (float4*)(smem + IS * IS + 3);
+        const float4* wsrc = (const float4*)a.wfrag;
+        for (int i = tid; i < 8 * 2 * 2 * 64; i += 256) dst[i] = wsrc[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nb][i] = 0.f;
+    int base[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ly = 2 * (2 * wv + mt) + (r >> 4), lx = r & 15;
+        base[mt] = ly * S * IS + lx * S;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        u32x4_t ah[2], al[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                constexpr int NT = K * K;
+                const int k0 = 16 * s8 + j, k1 = k0 + 8;                              // this lane's tap for h = 0 / 1
+                const int o0 = k0 < NT ? (k0 / K) * IS + k0 % K : 0, o1 = k1 < NT ? (k1 / K) * IS + k1 % K : 0;   // (padding taps: zero weights)
+                e[j] = tile[base[mt] + (h ? o1 : o0)];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                ah[mt][d] = cvt_pk_bf16(e[2 * d], e[2 * d + 1]);
+                al[mt][d] = cvt_pk_bf16(e[2 * d] - __uint_as_float(ah[mt][d] << 16), e[2 * d + 1] - __uint_as_float(ah[mt][d] & 0xffff0000u));
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const bf16x8 b_hi = __builtin_bit_cast(bf16x8, wf[((s8 * 2 + nb) * 2 + 0) * 64 + lane]);
+            const bf16x8 b_lo = __builtin_bit_cast(bf16x8, wf[((s8 * 2 + nb) * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah[mt]), a_lo = __builtin_bit_cast(bf16x8, al[mt]);
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc[mt][nb], 0, 0, 0);
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc[mt][nb], 0, 0, 0);
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc[mt][nb], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: lane = pixel r, registers = channels nb*32 + (i & 3) + 8 * (i >> 2) + 4h
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ly = 2 * (2 * wv + mt) + (r >> 4), lx = r & 15, oy = ty0 + ly, ox = tx0 + lx;
+        if (oy >= a.h1 || ox >= a.w1) continue;
+        // in-image taps of this pixel's window: ky in [ky0, ky1], kx in [kx0, kx1]
+        const int ky0 = max(0, P - oy * S), ky1 = min(K - 1, a.H - 1 - oy * S + P);
+        const int kx0 = max(0, P - ox * S), kx1 = min(K - 1, a.W - 1 - ox * S + P);
+        const bool inside = ky0 == 0 && kx0 == 0 && ky1 == K - 1 && kx1 == K - 1;
+        float* o = a.out + (((int64_t)b * a.h1 + oy) * a.w1 + ox) * 64;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = nb * 32 + 8 * q + 4 * h;
+                float4 add;
+                if (inside) add = *(const float4*)(a.bias_in + c4);
+                else {
+                    const float4 bb = *(const float4*)(a.bias + c4);
+                    const float4 p11 = *(const float4*)(a.wbsum + ((ky1 + 1) * 12 + kx1 + 1) * 64 + c4), p01 = *(const float4*)(a.wbsum + (ky0 * 12 + kx1 + 1) * 64 + c4);
+                    const float4 p10 = *(const float4*)(a.wbsum + ((ky1 + 1) * 12 + kx0) * 64 + c4), p00 = *(const float4*)(a.wbsum + (ky0 * 12 + kx0) * 64 + c4);
+                    add = make_float4(bb.x + ((p11.x - p01.x) - (p10.x - p00.x)), bb.y + ((p11.y - p01.y) - (p10.y - p00.y)),
+                                      bb.z + ((p11.z - p01.z) - (p10.z - p00.z)), bb.w + ((p11.w - p01.w) - (p10.w - p00.w)));
+                }
+                *(float4*)(o + c4) = make_float4(fmaxf(acc[mt][nb][4 * q] + add.x, 0.f), fmaxf(acc[mt][nb][4 * q + 1] + add.y, 0.f),
+                                                 fmaxf(acc[mt][nb][4 * q + 2] + add.z, 0.f), fmaxf(acc[mt][nb][4 * q + 3] + add.w, 0.f));
+            }
+    }
+#endif
 }
 
 // ---- max pool 3x3 stride 2 (no padding), NHWC --------------------------------------------------------------------
@@ -189,8 +301,9 @@ struct Layer { int cin, cout, k, pad; bool x3 = false; int mx_e = 0; std::vector
 
 struct evr_lpips {
     // conv1 (direct) + 4 igemm layers
-    std::vector<float> wg, wb, b1, b1in;
+    std::vector<float> wg, wb, b1, b1in, wfrag1, wbsum;
     float* d_wg = nullptr; float* d_wb = nullptr; float* d_b1 = nullptr; float* d_b1in = nullptr;
+    float* d_wfrag1 = nullptr; float* d_wbsum = nullptr;     // matrix-core form of conv1 (split mode)
     float* d_lin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Layer L[4];
     // shape-dependent
@@ -204,6 +317,7 @@ struct evr_lpips {
     ~evr_lpips() {
         release();
         if (d_wg) (void)hipFree(d_wg); if (d_wb) (void)hipFree(d_wb); if (d_b1) (void)hipFree(d_b1); if (d_b1in) (void)hipFree(d_b1in);
+        if (d_wfrag1) (void)hipFree(d_wfrag1); if (d_wbsum) (void)hipFree(d_wbsum);
         for (auto& p : d_lin) if (p) (void)hipFree(p);
         for (auto& l : L) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
     }
@@ -265,6 +379,35 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
         if ((rc = up(m->wb, &m->d_wb))) break;
         if ((rc = up(m->b1, &m->d_b1))) break;
         if ((rc = up(m->b1in, &m->d_b1in))) break;
+        if (use_split_mode()) {
+            // weight fragments of lpips_conv1_mfma_kernel: [slab s][block nb][hi, lo][lane] x 4 dwords, lane (r, h) holding the
+            // 8 taps k = 16s + 8h + j of output channel nb*32 + r as bf16 pairs (taps >= 121: zero)
+            m->wfrag1.assign((size_t)8 * 2 * 2 * 64 * 4, 0.f);
+            unsigned* wf = (unsigned*)m->wfrag1.data();
+            for (int s8 = 0; s8 < 8; ++s8) for (int nb = 0; nb < 2; ++nb) for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, hh = lane >> 5;
+                unsigned short hi[8], lo[8];
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s8 + 8 * hh + j;
+                    const float wv = k < 121 ? m->wg[(size_t)k * 64 + nb * 32 + r] : 0.f;
+                    hi[j] = bf16_rne(wv); lo[j] = bf16_rne(wv - bf16_to_f32(hi[j]));
+                }
+                for (int d = 0; d < 4; ++d) {
+                    wf[((((size_t)s8 * 2 + nb) * 2 + 0) * 64 + lane) * 4 + d] = (unsigned)hi[2 * d] | ((unsigned)hi[2 * d + 1] << 16);
+                    wf[((((size_t)s8 * 2 + nb) * 2 + 1) * 64 + lane) * 4 + d] = (unsigned)lo[2 * d] | ((unsigned)lo[2 * d + 1] << 16);
+                }
+            }
+            // prefix sums of wb over the window: P[i][j][co] = sum_{ky < i, kx < j} wb[ky][kx][co] (fp64, rounded once)
+            m->wbsum.assign((size_t)12 * 12 * 64, 0.f);
+            for (int co = 0; co < 64; ++co) {
+                double Pd[12][12] = {};
+                for (int i = 1; i < 12; ++i) for (int j = 1; j < 12; ++j)
+                    Pd[i][j] = Pd[i - 1][j] + Pd[i][j - 1] - Pd[i - 1][j - 1] + (double)m->wb[(size_t)((i - 1) * 11 + (j - 1)) * 64 + co];
+                for (int i = 0; i < 12; ++i) for (int j = 0; j < 12; ++j) m->wbsum[(size_t)(i * 12 + j) * 64 + co] = (float)Pd[i][j];
+            }
+            if ((rc = up(m->wfrag1, &m->d_wfrag1))) break;
+            if ((rc = up(m->wbsum, &m->d_wbsum))) break;
+        }
         for (int l = 1; l < 5 && !rc; ++l) {
             Layer& L = m->L[l - 1];
             L.cin = cin[l]; L.cout = cout[l]; L.k = ks[l]; L.pad = ks[l] / 2;
@@ -345,10 +488,21 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     Conv1Args c1{};
     c1.img = img; c1.ref = ref; c1.n = n; c1.H = H; c1.W = W; c1.h1 = m->h[0]; c1.w1 = m->w[0]; c1.clip = clip;
     c1.wg = m->d_wg; c1.wb = m->d_wb; c1.bias = m->d_b1; c1.bias_in = m->d_b1in; c1.out = m->feat[0];
+    c1.wfrag = (const unsigned*)m->d_wfrag1; c1.wbsum = m->d_wbsum;
     static bool attr = false;
-    const size_t lds1 = (size_t)(2 * 71 * 71) * sizeof(float);
-    if (!attr) { EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
+    if (!attr) {
+        EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    static const bool conv1_valu = getenv("EVR_LPIPS_CONV1_VALU") != nullptr;      // A/B switch: the direct VALU kernel in split mode too
+    if (m->d_wfrag1 && !conv1_valu) {
+        const size_t lds = (size_t)(71 * 71 + 3) * sizeof(float) + (size_t)8 * 2 * 2 * 64 * 16;
+        hipLaunchKernelGGL(lpips_conv1_mfma_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds, stream, c1);
+    } else {
+        const size_t lds1 = (size_t)(2 * 71 * 71) * sizeof(float);
+        hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
+    }
     EVR_LAUNCH_CHECK();
     const int pk = m->L[0].x3 ? 1 : 0;
     auto pool = [&](const float* in, float* o, int h, int w, int c, int ho, int wo, int in_pk) -> int {
