@@ -82,6 +82,7 @@ struct ConvArgs {
     // epilogue reduces (value [+ post_add]) . pred_w over the channels, adds pred_b, applies the final
     // activation and writes the centre-cropped pixel to the image passed at launch; `out` may then be null.
     const float* pred_w; float pred_b; int pred_sigmoid;
+    const float* pred_skip_dot;   // optional [n, hout, wout]: sum_c pred_w[c] * skip[c] computed by the skip's producer (then post_add is null)
     int crop_h, crop_w, crop_y0, crop_x0;
     int x3;                   // weights are in the split layout (pack_split_weights) and in0/in1 are PACKED tensors:
     int in_packed;            //   the main loop feeds LDS slots straight to the MFMAs
@@ -248,6 +249,9 @@ struct HeadArgs {
     int out_packed;      // write `out` in the PACKED activation format
     int group_store;     //   as whole 64-B groups (see ConvArgs)
     const void* wfrag;   // k5/32-channel split-bf16 form: weights in MFMA-fragment order (head_mfma_kernel), or null
+    // head_mfma_kernel only: the prediction layer's skip term of every pixel, sum_c pred_w[c] * out[c] (fp32, before the
+    // PACKED rounding), so the last decoder reads one float per pixel instead of the 32 channels (ConvArgs::pred_skip_dot)
+    const float* pred_w; float* pred_dot;   // [32] / [n, hp, wp], or null
 };
 // weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B)
 void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out);

@@ -400,6 +400,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 if (h == 0 && mvalid) {
                     const int y = oy - a.crop_y0, x = ox - a.crop_x0;
                     float sres = pred_part + a.pred_b;
+                    if (a.pred_skip_dot) sres += a.pred_skip_dot[opx];
                     if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
                     if (a.prev_rec) a.prev_rec[opx] = sres;
                     if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
@@ -1644,6 +1645,17 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
                 for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
             }
             float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
+            if (a.pred_dot) {       // skip term of the fused prediction layer (model/unet.py:136-138): sum_c w[c] * head[c]
+                float dot = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 w4 = *(const f4*)(a.pred_w + 8 * q + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dot = fmaf(acc[4 * q + j], w4[j], dot);
+                }
+                dot += __shfl_xor(dot, 32, 64);
+                if (h == 0 && oy < a.hp && ox < a.wp) a.pred_dot[((int64_t)n * a.hp + oy) * a.wp + ox] = dot;
+            }
             if (a.out_packed && a.group_store) {     // the lane pair of a pixel trades runs: each stores one whole 64-B PACKED group
                 float w16[16];
                 xchg16(acc, w16);

@@ -817,14 +817,20 @@ void name2(evr_model* m, const std::string& name, const DevTensor& t0, const Dev
 // Fold the 1x1 prediction conv (+ skip-sum with `skip`, final activation, centre crop) into conv `ci`'s epilogue
 // when its GEMM has a single N tile; otherwise the standalone pred kernel runs.  reserved[0] bit 0 (debug) keeps
 // the conv's own NHWC output for evr_model_read_tensor.
-void try_fuse_pred(evr_model* m, int ci, const float* skip, bool skip_packed) {
+void try_fuse_pred(evr_model* m, int ci, const float* skip, bool skip_packed, float* skip_dot = nullptr) {
     Conv& c = m->convs[ci];
     m->pred_fused_conv = -1;
+    m->head.pred_w = nullptr; m->head.pred_dot = nullptr;
     if (c.n_gemm != 32 * c.nb || c.n_gemm > 128) return;
     if (c.epi != EPI_BIAS_RELU && c.epi != EPI_RESIDUAL_RELU && c.epi != EPI_BIAS) return;
+    // the skip is the head tensor and the matrix-core head kernel runs: it also writes sum_c pred_w[c] * head[c] per pixel,
+    // and the decoder's epilogue adds that one float instead of loading and unpacking the 32 skip channels
+    const bool by_dot = skip_dot && m->head.wfrag && m->head.cout == 32 && getenv("EVR_NO_PRED_DOT") == nullptr;
+    if (by_dot) { m->head.pred_w = m->d_pred_w; m->head.pred_dot = skip_dot; }
     for (int p = 0; p < 2; ++p) {
         ConvArgs& a = c.args[p];
-        a.post_add = skip; a.padd_packed = skip_packed ? 1 : 0;
+        a.post_add = by_dot ? nullptr : skip; a.padd_packed = skip_packed ? 1 : 0;
+        a.pred_skip_dot = by_dot ? skip_dot : nullptr;
         a.pred_w = m->d_pred_w; a.pred_b = m->pred_b; a.pred_sigmoid = m->desc.final_activation == EVR_ACT_SIGMOID;
         a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
         a.prev_rec = m->prev_rec;
@@ -1021,7 +1027,9 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     m->pred_x[0] = x[0]; m->pred_x[1] = x[1];
     m->pred_skip[0] = m->pred_skip[1] = head.p;
     m->pred_c = base; m->pred_x_packed = P; m->pred_skip_packed = P;
-    try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p, P);
+    DevTensor hdot;      // sum_c pred_w[c] * head[c] per pixel, written by the matrix-core head kernel (try_fuse_pred)
+    if ((rc = alloc(m, &hdot, n, m->hp, m->wp, 1, stream))) return rc;
+    try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p, P, hdot.p);
     EVR_REQUIRE(!m->dynamic || m->pred_fused_conv >= 0, "dynamic decoder: the prediction layer could not be fused (prev_recs needs it)");
     return EVR_OK;
 }
@@ -1376,7 +1384,9 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
     m->pred_x[0] = y[0]; m->pred_x[1] = y[1];
     m->pred_skip[0] = m->pred_skip[1] = head.p;
     m->pred_c = 32; m->pred_x_packed = P; m->pred_skip_packed = P;
-    try_fuse_pred(m, conv_index(m, "dec2"), head.p, P);
+    DevTensor hdot;
+    if ((rc = alloc(m, &hdot, n, m->hp, m->wp, 1, stream))) return rc;
+    try_fuse_pred(m, conv_index(m, "dec2"), head.p, P, hdot.p);
     return EVR_OK;
 }
 
