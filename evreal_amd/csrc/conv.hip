@@ -418,7 +418,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
 // X3: 0 = fp32 MFMA; 2 = split arithmetic on PACKED activations (1, splitting PLAIN activations in registers, is gone:
 // VALU kernels that feed a matrix-core convolution write PACKED themselves)
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
-__global__ __launch_bounds__(64 * WM, (X3 == 0 || WM > 4) ? 1 : (NB >= 2 ? 2 : 3)) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(64 * WM, (X3 == 0 || WM != 4) ? 1 : (NB >= 2 ? 2 : 3)) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
     constexpr int SP = KC / 4;                 // 16-B slots per row
@@ -1340,9 +1340,9 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         return launch_band_prog<2>(a, d_args, stream, img);
     }
     if (band_eligible(a, kc)) {
-        // tile configuration: 4 waves (128 px) x 2-slot ring, two blocks per CU (default: one block's epilogue and
-        // barrier bubbles hide under the other's MFMAs, measured 5 % faster) | 8 waves (256 px) x 3- or 2-slot ring
-        static const int cfg = getenv("EVR_BAND_CFG") ? atoi(getenv("EVR_BAND_CFG")) : 42;
+        // 128 x 128 tiles: 4 waves x 2-slot ring, two blocks per CU (one block's epilogue and barrier bubbles hide under the
+        // other's MFMAs).  The 8-wave and overlapped-tile / 3-slot-ring configurations of earlier rounds measured slower
+        // (profiles/r02_tile_variants.txt) and are gone: with the zero row their 80 KiB no longer leave two blocks per CU.
         // 256-pixel block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
         static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
         static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 1024;   // >= 4 rounds of 256 blocks; tests lower it
@@ -1361,14 +1361,10 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min)
             return launch_wide<false, 1>(a, d_args, stream, img);
         if (a.epi == EPI_LSTM) {
-            if (cfg == 43) return launch_band<4, 3, true, false, true>(a, d_args, stream, img);
-            if (cfg == 42) return launch_band<4, 2, true>(a, d_args, stream, img);
             return launch_band<4, 2, true>(a, d_args, stream, img);
         }
         if (a.tp.ngroups > 1) {
-            static const int gcfg = getenv("EVR_BAND_GCFG") ? atoi(getenv("EVR_BAND_GCFG")) : 42;
-            if (gcfg == 43) return launch_band<4, 3, false, true, true>(a, d_args, stream, img);
-            if (gcfg == 42) {
+            {
                 // does the tap/phase connectivity follow the k5 s2 p2 rule the PHASES variants compile in?
                 bool rule = a.tp.ngroups == 4;
                 for (int t = 0; t < 9 && rule; ++t) {
@@ -1392,8 +1388,6 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
             }
             return launch_band<4, 2, false, true>(a, d_args, stream, img);
         }
-        if (cfg == 43) return launch_band<4, 3, false, false, true>(a, d_args, stream, img);
-        if (cfg == 42) return launch_band<4, 2, false>(a, d_args, stream, img);
         return launch_band<4, 2, false>(a, d_args, stream, img);
     }
     if (a.epi == EPI_LSTM) {

@@ -1,6 +1,6 @@
 # Per-layer HIP-event times (single stream, 64 sequences 346x260) for A/B comparisons of kernel-selection switches, pairs run
 # back to back on one box:   bash tools/layer_times.sh [repeats]   ->  appends to gpurun_out/layer_times.txt
-# (edit the pairs below; switches: EVR_WIDE=0|2|3, EVR_GROUP_STORE=0, EVR_BAND_PROG_ALL=0, EVR_BAND_CFG, EVR_BAND_GCFG)
+# (edit the pairs below; switches: EVR_WIDE=0|2|3, EVR_GROUP_STORE=0, EVR_BAND_PROG_ALL=0, EVR_WIDE_DEC=0, EVR_NO_PRED_DOT=1)
 run() { python bench.py --sub --no-overlap --profile-filter '' --steps 10 --warmup 3 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
