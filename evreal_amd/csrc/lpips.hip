@@ -231,9 +231,14 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
 // A lane owns 4-channel runs (one 16-B access on PLAIN rows, 8 B + 4 B on PACKED ones): R = C / 4 runs per pixel.  With
 // R = 16 (relu1, C = 64) a wave takes four pixels at once (16-lane reductions); otherwise one pixel per wave and up to two
 // runs per lane (C <= 512).
-__global__ __launch_bounds__(256) void lpips_score_kernel(const float* __restrict__ feat, const float* __restrict__ lin, int n, int hw,
-                                                           int C, double* __restrict__ partials, int blocks_per_img, int packed) {
+struct ScoreArgs { const float* feat[5]; const float* lin[5]; int hw[5], C[5], packed[5]; };
+// (one launch for the five layers -- grid.z = layer -- so their small grids share the chip instead of queueing one by one)
+__global__ __launch_bounds__(256) void lpips_score_kernel(const ScoreArgs sa, int n, double* __restrict__ partials_all, int blocks_per_img) {
     __shared__ double red[4];
+    const int layer = blockIdx.z;
+    const float* __restrict__ feat = sa.feat[layer]; const float* __restrict__ lin = sa.lin[layer];
+    const int hw = sa.hw[layer], C = sa.C[layer], packed = sa.packed[layer];
+    double* __restrict__ partials = partials_all + (size_t)layer * n * blocks_per_img;
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* f0 = feat + (int64_t)b * hw * C;
     const float* f1 = feat + (int64_t)(b + n) * hw * C;
@@ -517,11 +522,10 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     for (int i = 1; i < 4; ++i)
         if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
     const int C[5] = {64, 192, 384, 256, 256};
-    for (int l = 0; l < 5; ++l) {
-        hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n), dim3(256), 0, stream, m->feat[l], m->d_lin[l], n,
-                           m->h[l] * m->w[l], C[l], m->partials + (size_t)l * n * SCORE_BLOCKS, SCORE_BLOCKS, l > 0 ? pk : 0);
-        EVR_LAUNCH_CHECK();
-    }
+    ScoreArgs sa;
+    for (int l = 0; l < 5; ++l) { sa.feat[l] = m->feat[l]; sa.lin[l] = m->d_lin[l]; sa.hw[l] = m->h[l] * m->w[l]; sa.C[l] = C[l]; sa.packed[l] = l > 0 ? pk : 0; }
+    hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n, 5), dim3(256), 0, stream, sa, n, m->partials, SCORE_BLOCKS);
+    EVR_LAUNCH_CHECK();
     hipLaunchKernelGGL(lpips_final_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, m->partials, out, SCORE_BLOCKS, 5, n, m->d_hw);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
