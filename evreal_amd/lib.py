@@ -71,6 +71,8 @@ SYMBOLS = {
     'evr_split_pack': (c_int, [c_void_p, c_void_p, c_int64]),
     'evr_split_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
     'evr_split_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_split_pack_weights': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_fastdiv_magic': (c_int, [ctypes.c_uint, c_void_p, c_void_p]),
 }
 
 _lib = None

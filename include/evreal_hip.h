@@ -244,6 +244,11 @@ int evr_split_unpack(const float* src, float* dst, int64_t n);
 /* the same packing done by the device code the kernels use (src / dst device pointers, in place allowed): lets a test pin the
  * hardware conversions (f16 RNE, OCP e4m3 RNE, saturation) against the host codec bit for bit */
 int evr_split_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
+/* host-only hooks for the CPU test-suite: the weight form of the split format -- per 16 values f16 hi | e4m3 RNE(w * 2^e) |
+ * e4m3 RNE((w - hi) * 2^(e + 12)), e = the largest exponent with max|w| * 2^e <= 224, returned in *exponent -- and the
+ * constants of n / d = (umulhi(n, mul) + n) >> shift (n < 2^31) the launch plans carry for the kernels' pixel decode */
+int evr_split_pack_weights(const float* src, float* dst, int64_t n, int* exponent);
+int evr_fastdiv_magic(unsigned d, unsigned* mul, unsigned* shift);
 
 #ifdef __cplusplus
 }

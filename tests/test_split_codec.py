@@ -53,3 +53,39 @@ def test_roundtrip_keeps_15_significant_bits():
     # values a half holds survive exactly
     z = (rng.integers(-2048, 2048, 4096).astype(np.float32) * np.float32(2.0) ** rng.integers(-12, 4, 4096)).astype(np.float32)
     np.testing.assert_array_equal(_call('evr_split_unpack', _call('evr_split_pack', z)), z)
+
+
+def test_weight_packing_matches_numpy_and_keeps_both_fp8_pieces_in_range():
+    L = _lib.load()
+    rng = np.random.default_rng(2)
+    for scale in (1e-3, 0.05, 1.0, 7.0, 300.0):
+        w = (rng.uniform(-1, 1, 4096) * scale).astype(np.float32)
+        w[::97] = 0.0
+        got = np.empty_like(w); e = ctypes.c_int(0)
+        assert L.evr_split_pack_weights(w.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p), w.size, ctypes.byref(e)) == 0
+        ex = e.value
+        mx = float(np.abs(w).max())
+        assert mx * 2.0 ** ex <= 224.0 < mx * 2.0 ** (ex + 1)
+        g = w.reshape(-1, 16)
+        hi = g.astype(np.float16)
+        w8 = _e4m3_bits(g * np.float32(2.0 ** ex))
+        wlo8 = _e4m3_bits((g - hi.astype(np.float32)) * np.float32(2.0 ** (ex + 12)))
+        want = np.concatenate([hi.view(np.uint8).reshape(-1, 32), w8.reshape(-1, 16), wlo8.reshape(-1, 16)], axis=1).reshape(-1)
+        np.testing.assert_array_equal(got.view(np.uint8), want)
+        # neither fp8 piece saturates: decoding hi + wlo8 * 2^-(e+12) recovers w to 2^-15 of the tensor's largest weight
+        t8 = torch.from_numpy(wlo8.copy()).view(torch.float8_e4m3fn).float().numpy().reshape(-1, 16)
+        back = hi.astype(np.float32) + t8 * np.float32(2.0 ** -(ex + 12))
+        assert np.abs(back - g).max() <= mx * 2.0 ** -15
+
+
+def test_fastdiv_constants_divide_exactly():
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    ds = [1, 2, 3, 5, 7, 44, 88, 176, 346, 352, 1452, 5808, 23232, 92928, 307200, (1 << 20) + 1, (1 << 31) - 1] + [int(v) for v in rng.integers(1, 1 << 22, 500)]
+    for d in ds:
+        mul, sh = ctypes.c_uint(0), ctypes.c_uint(0)
+        assert L.evr_fastdiv_magic(d, ctypes.byref(mul), ctypes.byref(sh)) == 0
+        n = np.concatenate([[0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, (1 << 31) - 2], rng.integers(0, 1 << 31, 300)]).astype(np.uint64)
+        n = n[n < (1 << 31)]
+        q = (((n * np.uint64(mul.value)) >> np.uint64(32)) + n) >> np.uint64(sh.value)
+        np.testing.assert_array_equal(q, n // np.uint64(d), err_msg=str(d))
