@@ -299,3 +299,29 @@ def test_etnet_golden():
             want = z[f'h{i}_sub']
             h = m.read_tensor(f'h{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
             np.testing.assert_allclose(h[:1, ::4], want, rtol=1e-4, atol=2e-5, err_msg=f'h{i}')
+
+
+def test_large_activations_degrade_gracefully():
+    """The PACKED format's fp8 pieces saturate at +-448 (csrc/conv.h): beyond |x| ~ 224 a value keeps only its f16 half
+    (2^-12 relative).  Unnormalised inputs 30x the usual magnitude still pass the 1e-4 gate; at 300x (head activations in the
+    thousands) the image error grows to ~4e-4 -- finite, no overflow -- and EVR_FP32=1 is the mode for such data."""
+    from evreal_amd import model, weights
+    from oracle import model as omod
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=5)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    okeys = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size', 'norm', 'use_upsample_conv',
+             'recurrent_block_type', 'final_activation']
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **{k: kw[k] for k in okeys})
+    rng = np.random.default_rng(0)
+    for scale, gate in ((30.0, 1e-4), (300.0, 1e-3), (1e5, 5e-2)):      # (1e5: f16 halves themselves saturate at 65504; finite, bounded)
+        m.reset_states(); o.reset_states()
+        for f in range(3):
+            v = np.zeros((1, 5, 64, 96), np.float32)
+            mk = rng.random(v.shape) < 0.2
+            v[mk] = rng.normal(0, 1.5, mk.sum()) * scale
+            img = m(torch.from_numpy(v).cuda())['image'].cpu().numpy()
+            with torch.no_grad():
+                want = o(torch.from_numpy(v)).numpy()
+            assert np.isfinite(img).all()
+            assert np.abs(img - want).max() < gate, (scale, f, float(np.abs(img - want).max()))
