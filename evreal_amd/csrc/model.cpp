@@ -94,7 +94,8 @@ struct evr_model {
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
     bool packed = false;   // split mode: tensors between matrix-core convolutions use the PACKED format
     int pred_x_packed = 0, pred_skip_packed = 0;
-    std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes)
+    std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes): state and activations, zeroed by every reset
+    std::vector<float*> shape_consts;                // per-shape constant tables (ET-Net sine table): freed with the shape, never zeroed
     std::map<std::string, DevTensor> named[2];   // debug names -> tensor valid after a frame of parity p
     std::vector<Step> steps;
     ConvArgs* d_args = nullptr;
@@ -143,6 +144,8 @@ struct evr_model {
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
         allocs.clear();
+        for (float* q : shape_consts) (void)hipFree(q);
+        shape_consts.clear();
         if (d_args) { (void)hipFree(d_args); d_args = nullptr; }
         steps.clear(); named[0].clear(); named[1].clear();
         n_seq = 0; prev_rec = nullptr; sp_xpad = sp_xorg = sp_xorg_half = nullptr; et_pos = nullptr; et_attn.clear();
@@ -1265,11 +1268,14 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
                 const double ang = (double)l / std::pow(10000.0, 2.0 * (j / 2) / 256.0);
                 pos[(size_t)l * 256 + j] = (float)((j & 1) ? std::cos(ang) : std::sin(ang));
             }
-        DevTensor pt;
-        if ((rc = alloc(m, &pt, 1, L, 1, 256, stream))) return rc;
-        EVR_HIP(hipMemcpyAsync(pt.p, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+        // (its own allocation, NOT alloc(): the same-shape path of evr_model_reset_states zeroes every entry of m->allocs,
+        // and a zeroed table would silently drop the position term from the second sequence of a dataset on)
+        float* pt = nullptr;
+        EVR_HIP(hipMalloc((void**)&pt, pos.size() * sizeof(float)));
+        m->shape_consts.push_back(pt);
+        EVR_HIP(hipMemcpyAsync(pt, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice, stream));
         EVR_HIP(hipStreamSynchronize(stream));       // `pos` is a local
-        m->et_pos = pt.p;
+        m->et_pos = pt;
     }
     auto tok = [&](DevTensor* t, int c, bool packed) { return alloc(m, t, n, L, 1, c, stream, packed); };
     DevTensor Wd[3], HS[3], HC[3], Ta, Tb, Tm, Tm2, XA, MEMN, QKV, CQ, CKV, AO, FF, SP;

@@ -53,6 +53,7 @@ constexpr int MAX_G = 4096;
 struct VoxHeader {           // first 256 B of the workspace; must be zero before the workspace is used for the first time
     unsigned long long dropped_acc;    // out-of-sensor events counted by the running call (K1 adds, K2 folds and clears)
     unsigned long long dropped_last;   // ... of the last completed call (evr_voxelize_dropped reads this)
+    unsigned long long dropped_total;  // ... of every call since the header was zeroed (evr_voxelize_dropped_total)
 };
 
 // torch.linspace(0, B-1, n)[i], ATen scalar formula (oracle/voxel.py:linspace_f32)
@@ -242,14 +243,15 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.x == 0 && threadIdx.x == 0) {       // K1 has finished (kernel boundary): publish its count, re-arm the counter
         hdr->dropped_last = hdr->dropped_acc;
+        hdr->dropped_total += hdr->dropped_acc;
         hdr->dropped_acc = 0;
     }
     float* acc = lds;                                          // [B][Rp]   Rp = rows * W rounded up to 4
     unsigned* tags = (unsigned*)(acc + (size_t)B * Rp);        // [NTAG] ticket slots (hashed by pixel)
     int* seg_pre = (int*)(tags + NTAG);                        // [MAXSEG + 1] records of this range before segment s
     int* seg_at = seg_pre + MAXSEG + 1;                        // [MAXSEG]     where they start inside the segment
-    int* more = seg_at + MAXSEG;                               // [3] "another ticket round is needed" flags (+1 pad)
-    double* red = (double*)(more + 4);                         // [K2W][3]
+    int* more = seg_at + MAXSEG;                               // [3] "another ticket round is needed" flags (+2 pad: `red` is 8-B aligned)
+    double* red = (double*)(more + 5);                         // [K2W][3]  byte offset 4*(B*Rp + NTAG + 2*MAXSEG + 1 + 5): B*Rp % 4 == 0 -> a multiple of 8
 
     const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;
     int w, g;
@@ -430,7 +432,7 @@ bool make_plan(int64_t n_events_total, int n_windows, int B, int H, int W, VoxPl
     p.rows = rows; p.G = G;
     p.Rp = (int)(((int64_t)rows * W + 3) & ~3LL);
     p.lds1 = (size_t)(K1W * G + G + 1 + K1W) * sizeof(int);
-    p.lds2 = (size_t)B * p.Rp * 4 + (size_t)NTAG * 4 + (size_t)(2 * MAXSEG + 1 + 4) * 4 + K2W * 3 * 8 + 8;
+    p.lds2 = (size_t)B * p.Rp * 4 + (size_t)NTAG * 4 + (size_t)(2 * MAXSEG + 1 + 5) * 4 + K2W * 3 * 8 + 8;
     size_t off = 256;
     p.off_rec = off; off += evr::align_up((size_t)(n_events_total > 0 ? n_events_total : 1) * sizeof(float4), 256);
     const size_t n_rows = (size_t)(n_events_total / SEG) + n_windows + 2;
@@ -551,6 +553,16 @@ extern "C" int evr_voxelize_dropped(const void* workspace, int64_t* n_dropped_ho
     EVR_REQUIRE(workspace && n_dropped_host, "evr_voxelize_dropped: null pointer");
     unsigned long long v = 0;
     EVR_HIP(hipMemcpyAsync(&v, (const char*)workspace + offsetof(VoxHeader, dropped_last), sizeof(v), hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+    EVR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *n_dropped_host = (int64_t)v;
+    return EVR_OK;
+}
+
+extern "C" int evr_voxelize_dropped_total(const void* workspace, int64_t* n_dropped_host, evr_stream_t stream) {
+    EVR_REQUIRE(workspace && n_dropped_host, "evr_voxelize_dropped_total: null pointer");
+    unsigned long long v = 0;
+    EVR_HIP(hipMemcpyAsync(&v, (const char*)workspace + offsetof(VoxHeader, dropped_total), sizeof(v), hipMemcpyDeviceToHost,
                            (hipStream_t)stream));
     EVR_HIP(hipStreamSynchronize((hipStream_t)stream));
     *n_dropped_host = (int64_t)v;

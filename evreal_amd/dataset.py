@@ -48,14 +48,14 @@ class SequenceFiles:
 class MemMapDataset:
     def __init__(self, data_path, sensor_resolution=None, num_bins=5, voxel_method=None, max_length=None,
                  keep_ratio=1, device=None):
-        _lib.require_gpu()
+        # (no GPU is touched until upload(): the window tables and the rank-assignment weights are host work)
         self.num_bins = num_bins
         self.data_path = data_path
         self.keep_ratio = keep_ratio
         self.sensor_resolution = sensor_resolution
         self.has_images = True
         self.channels = num_bins
-        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._device = torch.device(device) if device is not None else None
         self.load_data(data_path)
         if voxel_method is None:
             voxel_method = {'method': 'between_frames'}
@@ -66,6 +66,13 @@ class MemMapDataset:
         self._vox = None
         self._dev = None
         self._table = None
+
+    @property
+    def device(self):
+        if self._device is None:
+            _lib.require_gpu()
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        return self._device
 
     # -- loading: what dataset.py:230-281 establishes, organised around the GPU path ------------
     def load_data(self, data_path):
@@ -81,7 +88,12 @@ class MemMapDataset:
         self.num_events = seq.num_events
         self.t0, self.tk = seq.t[0], seq.t[-1]
         self.num_frames = 0 if seq.images is None else len(seq.images)
-        self.frame_ts = [] if seq.images is None else [float(v) for v in seq.frame_stamps.reshape(len(seq.frame_stamps), -1)[:, 0]]
+        # dataset.py:262: [ts.item() for ts in frame_stamps] -- one stamp per row; an images.npy with zero frames yields []
+        # there and falls through to the max(xy)+1 resolution
+        stamps = [] if seq.images is None else np.asarray(seq.frame_stamps)
+        self.frame_ts = [float(np.asarray(r).reshape(-1)[0]) for r in stamps]
+        if self.num_frames == 0:
+            self.has_images = False      # (the reference would go on to index frame_ts[0] in get_min_max_t and raise)
         if len(self.frame_ts) != self.num_frames:
             raise AssertionError("Number of frames and timestamps do not match")
         res = self.sensor_resolution
@@ -221,12 +233,20 @@ class MemMapDataset:
         # ones cannot be represented in the resident int16 form and are refused outright.
         if xy.size and (xy.min() < 0 or xy.max() >= 32768):
             raise ValueError(f"{self.data_path}: pixel coordinates outside [0, 32767] (min {xy.min()}, max {xy.max()})")
+        # ... and a coordinate beyond sensor_resolution (a wrong constructor argument / metadata.json) would give plausible
+        # but wrong voxel grids: fail here, once per sequence, the way the reference fails on the first such window
+        H, W = self.sensor_resolution
+        if xy.size and (int(xy[:, 0].max()) >= W or int(xy[:, 1].max()) >= H):
+            raise IndexError(f"{self.data_path}: event coordinates up to x={int(xy[:, 0].max())}, y={int(xy[:, 1].max())} "
+                             f"lie outside the {W}x{H} sensor (sensor_resolution is [H, W]): index out of range in the "
+                             "voxel grid")
         pol = np.ascontiguousarray(fh["p"])
         # dataset.py:227 computes p*2-1 from {0,1}; a file that stores -1/+1 (or anything else) would silently become
         # 255 -> weight 509 after a uint8 cast
         if pol.size and not np.isin(pol, (0, 1)).all():
             raise ValueError(f"{self.data_path}: events_p.npy must hold 0/1 (or bool) polarities, found values "
                              f"{np.unique(pol)[:6].tolist()}")
+        _lib.require_gpu()
         d = {'xy': torch.from_numpy(xy.astype(np.int16)).to(self.device),
              'ts': torch.from_numpy(np.array(fh["t"], dtype=np.float64)).to(self.device),
              'p': torch.from_numpy(pol.astype(np.uint8)).to(self.device)}
@@ -254,6 +274,17 @@ class MemMapDataset:
         grid = self._vox.voxelize_raw_windows(d['xy'], d['ts'], d['p'], dev(b), dev(e), dev(base), int(lens.sum()),
                                               self.num_bins, (H, W), out=out, stats=stats)
         return grid, stats
+
+    def raise_if_dropped(self):
+        """Poll the tensorizer's cumulative out-of-sensor counter (one synchronisation; call once per sequence)."""
+        if self._vox is not None:
+            self._vox.raise_if_dropped(f"events of {self.data_path}")
+
+    def window_cost(self):
+        """Work of this sequence for the rank assignment: windows x padded pixels of the largest crop the
+        methods use (a multiple of 16 covers every method's num_encoders)."""
+        H, W = self.sensor_resolution
+        return int(max(self.length, 1)) * (-(-H // 16) * 16) * (-(-W // 16) * 16)
 
     def frames(self, frame_indices):
         """Reference frames [n,1,H,W] fp32 in [0,1] (dataset.py:80-85: images[i][:,:,0] / 255)."""

@@ -209,6 +209,7 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
             cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
             tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
     tracker.finalize(idx)
+    ds.raise_if_dropped()       # once per sequence: out-of-sensor events the kernel dropped (the reference raises)
     if bad is not None:
         raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
             int(tb['idx0'][bad]), int(tb['idx1'][bad]), ds.num_events))
@@ -270,6 +271,7 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
         trackers[j].finalize(plans[j][2])
         out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
     for j in range(S):      # the reference raises inside the sequence loop: same message, after the files are written
+        dss[j].raise_if_dropped()
         bad = plans[j][1]
         if bad is not None:
             raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
@@ -277,17 +279,36 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     return out
 
 
+def sequence_costs(seqs):
+    """Longest-processing-time weights of SURVEY 8e: number of windows x padded pixels per sequence.  Needs only the
+    .npy headers and the small per-frame tables (the event columns stay memory-mapped), so every rank can afford it for
+    the whole dataset; a sequence whose reader fails weighs 1 and fails again, loudly, on the rank that owns it."""
+    d = _dist()
+    if d is None or d.get_world_size() <= 1 or len(seqs) <= 1:
+        return [1] * len(seqs)          # one rank takes everything: nothing to balance
+    costs = []
+    for s in seqs:
+        try:
+            costs.append(MemMapDataset(s['sequence_path'], **s['dataset_kwargs']).window_cost())
+        except Exception:
+            costs.append(1)
+    return costs
+
+
 def fold_dataset_metrics(dataset_metrics, metric_names, dist, device=None):
     """Fold one dataset's MetricTracker over the ranks: ONE all-reduce(SUM) of [total, count] per requested metric
     (what MetricTracker.update accumulates, eval.py:259-266).  The column set is the REQUESTED metric list -- identical
     on every rank, including ranks that own no sequence of this dataset -- so every tracked metric (mse, ssim, lpips,
     plug-ins) survives the fold; metrics nobody scored (count 0 everywhere) stay absent, as in a single-rank run."""
-    names = list(dict.fromkeys(metric_names))
+    # the trackers key their scores by metric.get_name(), which for pyiqa plug-ins is the requested name lower-cased
+    # (eval_metrics.PyIqaMetricFactory.get_metric): fold under the same normalised names on every rank
+    names = list(dict.fromkeys(str(nm).lower() for nm in metric_names))
+    by_lower = {str(k).lower(): v for k, v in dataset_metrics.data_dict.items()}
     if device is None:
         device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     sums = torch.zeros((len(names), 2), dtype=torch.float64, device=device)
     for i, nm in enumerate(names):
-        d = dataset_metrics.data_dict.get(nm)
+        d = by_lower.get(nm)
         if d is not None:
             sums[i, 0], sums[i, 1] = d['total'], d['count']
     tot = reduce_metric_sums(sums, dist)
@@ -322,9 +343,7 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
         dataset_metrics = MetricTracker()
         seqs = dataset['sequences']
         try:
-            costs = [max(os.path.getsize(os.path.join(s['sequence_path'], 'events_ts.npy')), 1)
-                     if os.path.isdir(s['sequence_path']) else 1 for s in seqs]
-            mine = [seqs[i] for i in assign_sequences(costs, world)[rank]]
+            mine = [seqs[i] for i in assign_sequences(sequence_costs(seqs), world)[rank]]
             S = int(eval_config.get('batch_sequences', os.environ.get('EVREAL_BATCH_SEQUENCES', '1')))
             k = 0
             while k < len(mine):

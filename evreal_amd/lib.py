@@ -38,6 +38,7 @@ SYMBOLS = {
     'evr_voxelize': (c_int, [c_void_p] * 5 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
     'evr_voxelize_dropped': (c_int, [c_void_p, ctypes.POINTER(c_int64), c_void_p]),
+    'evr_voxelize_dropped_total': (c_int, [c_void_p, ctypes.POINTER(c_int64), c_void_p]),
     'evr_voxelize_raw': (c_int, [c_void_p] * 4 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     'evr_voxelize_raw_windows': (c_int, [c_void_p] * 6 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -53,6 +53,11 @@ class HotPath:
         ev[-1][1].synchronize()
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
+    def check_dropped(self):
+        """Raise if any event of any step so far fell outside the sensor (the reference raises from index_put_; the
+        kernel drops and counts).  Synchronises: call it once per sequence / batch, not per step."""
+        self.vox.raise_if_dropped()
+
     def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
         """One frame for every sequence.  xy/ts/pol: resident raw event arrays; win_offsets: int64
         [n_seq+1] device tensor delimiting this step's n_seq windows.  ref: [n_seq,H,W] reference

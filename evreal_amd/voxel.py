@@ -14,11 +14,20 @@ class Voxelizer:
         self.device = torch.device(device)
         self.ws = None
 
-    def _workspace(self, n_events, n_windows, B, H, W):
+    def _workspace(self, n_events, n_windows, B, H, W, stream=None):
         need = self.lib.evr_voxelize_workspace_bytes(n_events, n_windows, B, H, W)
         if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
-            self.ws[:256].zero_()          # the header (drop counters) must start at zero; the rest is scratch
+            old = self.ws
+            new = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            # the 256-B header (drop counters) starts at zero and SURVIVES a regrow; both on the stream the kernels are
+            # launched on, so neither can race with them.  The rest of the workspace is scratch.
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+                if old is None:
+                    new[:256].zero_()
+                else:
+                    new[:256].copy_(old[:256])
+                    old.record_stream(torch.cuda.current_stream(self.device))
+            self.ws = new
         return self.ws
 
     def voxelize(self, x, y, t, p, win_offsets, num_bins, sensor_size, out=None, stats=None, stream=None):
@@ -31,7 +40,7 @@ class Voxelizer:
         assert win_offsets.is_cuda and win_offsets.dtype == torch.int64
         if out is None:
             out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=x.device)
-        ws = self._workspace(n, nw, num_bins, H, W)
+        ws = self._workspace(n, nw, num_bins, H, W, stream)
         rc = self.lib.evr_voxelize(_lib.ptr(x), _lib.ptr(y), _lib.ptr(t), _lib.ptr(p), _lib.ptr(win_offsets),
                                    nw, n, num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws),
                                    ws.numel(), _lib.stream_ptr(stream))
@@ -46,7 +55,7 @@ class Voxelizer:
         assert xy.is_contiguous() and ts.is_contiguous() and pol.is_contiguous()
         if out is None:
             out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=ts.device)
-        ws = self._workspace(n, nw, num_bins, H, W)
+        ws = self._workspace(n, nw, num_bins, H, W, stream)
         rc = self.lib.evr_voxelize_raw(_lib.ptr(xy), _lib.ptr(ts), _lib.ptr(pol), _lib.ptr(win_offsets), nw, n,
                                        num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws), ws.numel(),
                                        _lib.stream_ptr(stream))
@@ -60,7 +69,7 @@ class Voxelizer:
         nw = int(win_begin.numel())
         if out is None:
             out = torch.empty((nw, num_bins, H, W), dtype=torch.float32, device=ts.device)
-        ws = self._workspace(int(n_window_events), nw, num_bins, H, W)
+        ws = self._workspace(int(n_window_events), nw, num_bins, H, W, stream)
         rc = self.lib.evr_voxelize_raw_windows(_lib.ptr(xy), _lib.ptr(ts), _lib.ptr(pol), _lib.ptr(win_begin),
                                                _lib.ptr(win_end), _lib.ptr(rec_base), nw, int(n_window_events),
                                                num_bins, H, W, _lib.ptr(out), _lib.ptr(stats), _lib.ptr(ws),
@@ -69,11 +78,31 @@ class Voxelizer:
         return out
 
     def dropped(self):
+        """Out-of-sensor events of the LAST call (synchronises)."""
         import ctypes
         v = ctypes.c_int64(0)
         _lib.check(self.lib.evr_voxelize_dropped(_lib.ptr(self.ws), ctypes.byref(v), _lib.stream_ptr()),
                    'evr_voxelize_dropped')
         return v.value
+
+    def dropped_total(self):
+        """Out-of-sensor events of EVERY call of this Voxelizer so far (synchronises): what a frame loop polls once per
+        sequence or batch."""
+        import ctypes
+        if self.ws is None:
+            return 0
+        v = ctypes.c_int64(0)
+        _lib.check(self.lib.evr_voxelize_dropped_total(_lib.ptr(self.ws), ctypes.byref(v), _lib.stream_ptr()),
+                   'evr_voxelize_dropped_total')
+        return v.value
+
+    def raise_if_dropped(self, what='events'):
+        """The reference raises from index_put_ when a pixel lies outside the sensor; here such events
+        are dropped by the kernel, so the host loop turns a non-zero count into the same failure."""
+        n = self.dropped_total()
+        if n:
+            raise IndexError(f"{n} {what} fall outside the sensor (wrong sensor_resolution / metadata.json?): "
+                             "index out of range in the voxel grid, as events_to_image_torch's index_put_ would report")
 
 
 _default = None

@@ -68,6 +68,9 @@ int evr_voxelize(const float* x, const float* y, const float* t, const float* p,
 /* Reads (synchronously) the out-of-range-event counter the last evr_voxelize on this workspace
  * left behind.  The reference raises from index_put_ in that case. */
 int evr_voxelize_dropped(const void* workspace, int64_t* n_dropped_host, evr_stream_t stream);
+/* The same counter accumulated over EVERY call since the workspace header was zeroed: a host loop polls it once per
+ * sequence / batch instead of once per launch (evreal_amd raises when it is non-zero, like index_put_ would). */
+int evr_voxelize_dropped_total(const void* workspace, int64_t* n_dropped_host, evr_stream_t stream);
 
 /* Raw-format variant: events straight from the memmaps (dataset.py:222-228 + :53-57 fused):
  * xy int16 [n,2], ts float64 [n] (absolute seconds), pol uint8 {0,1}.  Same output. */

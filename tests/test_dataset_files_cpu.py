@@ -23,3 +23,44 @@ def test_sequence_files_length_mismatch(tmp_path):
     np.save(tmp_path / 'c' / 'events_p.npy', np.zeros(999, np.uint8))
     with pytest.raises(AssertionError, match='do not match'):
         SequenceFiles.open(str(tmp_path / 'c'))
+
+
+def test_window_tables_and_cost_without_a_gpu(tmp_path):
+    """MemMapDataset needs no GPU until upload(): the window tables (dataset.py:104-130,168-186) and the rank-assignment
+    weight of SURVEY 8e (windows x padded pixels) are host work."""
+    from evreal_amd.dataset import MemMapDataset
+    synth.write_sequence(str(tmp_path / 'a'), 1, 5000, 1.0e5, 32, 24, 100.0)
+    ds = MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method={'method': 'k_events', 'k': 500, 'sliding_window_w': 0})
+    assert len(ds) == 10 and ds.sensor_resolution == [24, 32]
+    tb = ds.table()
+    assert tb['idx0'].tolist() == list(range(0, 5000, 500)) and tb['valid'].all()
+    assert ds.window_cost() == 10 * 32 * 32                       # 24 x 32 pads to 32 x 32
+    ds2 = MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method={'method': 'between_frames'})
+    assert ds2.window_cost() == (ds2.num_frames - 1) * 32 * 32
+
+
+def test_zero_reference_frames_fall_through(tmp_path):
+    """images.npy / images_ts.npy with zero frames: the reference's `[ts.item() for ts in frame_stamps]` yields [] and the
+    resolution comes from max(xy) + 1 (dataset.py:262,270-281)."""
+    from evreal_amd.dataset import MemMapDataset
+    w = synth.write_sequence(str(tmp_path / 'z'), 4, 2000, 1.0e5, 32, 24, with_images=False)
+    np.save(tmp_path / 'z' / 'images.npy', np.zeros((0, 24, 32, 1), np.uint8))
+    np.save(tmp_path / 'z' / 'images_ts.npy', np.zeros((0, 1), np.float64))
+    np.save(tmp_path / 'z' / 'image_event_indices.npy', np.zeros((0, 1), np.int64))
+    import os
+    if os.path.exists(tmp_path / 'z' / 'metadata.json'):
+        os.remove(tmp_path / 'z' / 'metadata.json')
+    ds = MemMapDataset(str(tmp_path / 'z'), num_bins=5, voxel_method={'method': 'k_events', 'k': 500, 'sliding_window_w': 0})
+    assert ds.num_frames == 0 and ds.frame_ts == []
+    assert ds.sensor_resolution == [int(w['xy'][:, 1].max()) + 1, int(w['xy'][:, 0].max()) + 1]
+
+
+def test_out_of_sensor_coordinates_raise_before_upload(tmp_path):
+    """A sensor_resolution smaller than the coordinates: the reference raises from index_put_ on the first such window
+    (SURVEY 8a quirk 6); here the sequence is refused before anything reaches the GPU."""
+    from evreal_amd.dataset import MemMapDataset
+    synth.write_sequence(str(tmp_path / 'a'), 1, 5000, 1.0e5, 32, 24, 100.0)
+    ds = MemMapDataset(str(tmp_path / 'a'), sensor_resolution=[20, 32], num_bins=5,
+                       voxel_method={'method': 'k_events', 'k': 500, 'sliding_window_w': 0})
+    with pytest.raises(IndexError, match='outside the 32x20 sensor'):
+        ds.upload()

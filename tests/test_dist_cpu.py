@@ -81,7 +81,7 @@ def _fold_worker(rank, world, port, q):
     if rank == 0:       # rank 1 owns no sequence of this dataset: its tracker stays empty
         dm.update('mse', 0.05, 10); dm.update('ssim', 0.61, 10); dm.update('lpips', 0.33, 10)
         dm.update('mse', 0.10, 30); dm.update('ssim', 0.40, 30); dm.update('lpips', 0.20, 30)
-    out = fold_dataset_metrics(dm, ['mse', 'ssim', 'lpips', 'niqe'], dist)
+    out = fold_dataset_metrics(dm, ['mse', 'ssim', 'LPIPS', 'niqe'], dist)      # (a mixed-case -qm name: trackers key it lower-cased)
     q.put((rank, {k: (v['total'], v['count'], v['average']) for k, v in out.data_dict.items()}))
     dist.barrier()
     dist.destroy_process_group()

@@ -299,6 +299,14 @@ def test_etnet_golden():
             want = z[f'h{i}_sub']
             h = m.read_tensor(f'h{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
             np.testing.assert_allclose(h[:1, ::4], want, rtol=1e-4, atol=2e-5, err_msg=f'h{i}')
+    # eval.py:197 resets the states before EVERY sequence of a dataset; at an unchanged (n, H, W) the library only zeroes its
+    # buffers -- the sine position table must survive that (it once sat among them and every later sequence lost the term)
+    for rep in range(2):
+        m.reset_states()
+        for f in range(F):
+            x = torch.from_numpy(vox[f:f + 1]).cuda().repeat(2, 1, 1, 1)
+            img = m(x)['image'].cpu().numpy()
+            np.testing.assert_allclose(img[:1], z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'after same-shape reset {rep}, frame {f}')
 
 
 def test_large_activations_degrade_gracefully():

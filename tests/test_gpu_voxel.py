@@ -100,6 +100,29 @@ def test_out_of_range_events_are_dropped_and_counted(vox):
     assert v[0, 0, 1, 1] == 1.0 and np.count_nonzero(v) == 1
 
 
+def test_dropped_events_accumulate_across_calls_and_regrows():
+    """The cumulative counter a frame loop polls once per sequence (evr_voxelize_dropped_total): it survives later clean
+    calls and a workspace regrow, and raise_if_dropped() turns it into the reference's failure (index_put_ raises)."""
+    from evreal_amd.voxel import Voxelizer
+    vz = Voxelizer()
+    assert vz.dropped_total() == 0
+    x = np.array([1, 400, 3, -2], np.float32); y = np.array([1, 2, 300, 5], np.float32)
+    t = np.array([0, 1e-3, 2e-3, 3e-3], np.float32); p = np.ones(4, np.float32)
+    run(vz, x, y, t, p, [0, 4], 5, 260, 346)
+    run(vz, x, y, t, p, [0, 4], 5, 260, 346)
+    assert vz.dropped() == 3 and vz.dropped_total() == 6
+    n = 200000                                            # a clean, much larger call: the workspace regrows
+    rng = np.random.default_rng(0)
+    xs = rng.integers(0, 346, n).astype(np.float32); ys = rng.integers(0, 260, n).astype(np.float32)
+    ts = np.sort(rng.uniform(0, 1e-2, n)).astype(np.float32)
+    old = vz.ws.data_ptr()
+    run(vz, xs, ys, ts, np.ones(n, np.float32), [0, n], 5, 260, 346)
+    assert vz.ws.data_ptr() != old
+    assert vz.dropped() == 0 and vz.dropped_total() == 6
+    with pytest.raises(IndexError, match='outside the sensor'):
+        vz.raise_if_dropped()
+
+
 def test_full_size_properties(vox):
     """BASELINE config size (346x260, 15k events, 5 bins), 256 windows: size-independent properties --
     linearity in p, per-window sum == sum(p), empty windows stay zero, determinism."""

@@ -95,3 +95,48 @@ def test_e2vid_gru_tiny():
 
 def test_e2vid_hyper_dynamic_decoder():
     _run_e2vid('e2vid_hyper')
+
+
+def test_e2vid_instance_norm_layout():
+    """norm='IN' branch of the oracle (running-statistics InstanceNorm in the conv layers, a true InstanceNorm2d in the
+    residual blocks; model/submodules.py:22-23,160-162) against the reference class's golden."""
+    _run_e2vid('e2vid_in')
+
+
+def test_spade_e2vid_oracle_golden():
+    """SpadeE2vidOracle against the reference class SpadeE2vid (model/spade_e2v.py:113-179): images, the 3-channel
+    prev_recs and every ConvLSTM state of the 4-frame golden."""
+    z = load_npz('spade_seq.npz')
+    sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=int(z['seed']))
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    m = omod.SpadeE2vidOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W, density=0.15)
+    assert sha(vox) == str(z['voxel_sha'])
+    torch.set_num_threads(1)
+    for f in range(F):
+        img = m(torch.from_numpy(vox[f:f + 1])).numpy()
+        np.testing.assert_allclose(img, z['images'][f:f + 1], **TOL, err_msg=f'frame {f}')
+    np.testing.assert_allclose(m.prev_recs.numpy(), z['prev_recs'], **TOL)
+    for i, (h, c) in enumerate(m.states):
+        np.testing.assert_allclose(h.numpy()[:, ::4], z[f'h{i}_sub'], rtol=1e-4, atol=1e-5, err_msg=f'h{i}')
+        np.testing.assert_allclose(c.numpy()[:, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=1e-5, err_msg=f'c{i}')
+
+
+def test_etnet_oracle_golden():
+    """ETNetOracle against the reference class EITR (model/eitr/eitr.py:4-16, u_trans.py:13-123): images and encoder
+    states of the 3-frame golden."""
+    z = load_npz('etnet_seq.npz')
+    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=int(z['seed']))
+    assert weights.state_dict_digest(sd) == str(z['weights_sha'])
+    m = omod.ETNetOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    seed, F, B, H, W = [int(v) for v in z['voxel_args']]
+    vox = synth.sparse_voxels(seed, F, B, H, W, density=0.15)
+    assert sha(vox) == str(z['voxel_sha'])
+    torch.set_num_threads(1)
+    for f in range(F):
+        img = m(torch.from_numpy(vox[f:f + 1])).numpy()
+        np.testing.assert_allclose(img, z['images'][f:f + 1], **TOL, err_msg=f'frame {f}')
+    for i, (h, c) in enumerate(m.states):
+        np.testing.assert_allclose(h.numpy()[:, ::4], z[f'h{i}_sub'], rtol=1e-4, atol=1e-5, err_msg=f'h{i}')
+        np.testing.assert_allclose(c.numpy()[:, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=1e-5, err_msg=f'c{i}')
