@@ -32,6 +32,9 @@ PER_FILE = {
 # grew (a branchy unrolled epilogue, dynamic indexing of a register array) -- silently, at a 10x slowdown.  These files
 # are compiled with -Rpass-analysis=kernel-resource-usage and the build fails if any of their kernels uses scratch.
 NO_SCRATCH = {'conv.hip', 'lpips.hip'}
+# sources compiled more than once: (object tag, extra flags).  conv.hip carries one split arithmetic per object
+# (csrc/conv.h arith_mode): mode 2 (f16 + MX-fp8, plus the exact-fp32 kernels) and mode 3 (three f16 products, fp32-grade)
+VARIANTS = {'conv.hip': [('', ['-DEVR_ARITH=2']), ('.h3', ['-DEVR_ARITH=3'])]}
 
 
 def _check_no_scratch(fname, remarks):
@@ -66,12 +69,12 @@ def build(force=False, verbose=True):
     headers.append(os.path.abspath(__file__))
     objs, rebuilt = [], False
     procs = []
-    for f in sources():
+    for f, tag, vflags in [(f, t, fl) for f in sources() for t, fl in VARIANTS.get(f, [('', [])])]:
         src = os.path.join(CSRC, f)
-        obj = os.path.join(OBJ, f + '.o')
+        obj = os.path.join(OBJ, f + tag + '.o')
         objs.append(obj)
         if force or _newer(src, obj, headers):
-            cmd = [HIPCC, '-c'] + COMMON + PER_FILE.get(f, []) + os.environ.get('EVR_EXTRA_HIPCC_FLAGS', '').split() + ['-x', 'hip', src, '-o', obj]
+            cmd = [HIPCC, '-c'] + COMMON + PER_FILE.get(f, []) + vflags + os.environ.get('EVR_EXTRA_HIPCC_FLAGS', '').split() + ['-x', 'hip', src, '-o', obj]
             check = f in NO_SCRATCH
             if check:
                 cmd.append('-Rpass-analysis=kernel-resource-usage')

@@ -30,3 +30,37 @@ extern "C" int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name
     }
     return EVR_OK;
 }
+
+// A HIP stream whose kernels may only be dispatched to `n_cus` compute units, taken evenly from every XCD (the chip
+// enumerates CUs XCD-major: CU i of XCD x is bit x * cus_per_xcd + i).  evreal_amd.pipeline runs the evaluation half of a
+// frame (robust normalisation, MSE/SSIM, LPIPS) on such a stream so that its small kernels stop displacing the ConvLSTM
+// work-groups of the reconstruction stream on every CU.
+extern "C" int evr_stream_create_cu_masked(int device, int n_cus, int from_top, evr_stream_t* out) {
+    EVR_REQUIRE(out != nullptr && n_cus >= 1, "evr_stream_create_cu_masked: bad arguments");
+    hipDeviceProp_t p;
+    EVR_HIP(hipGetDeviceProperties(&p, device));
+    const int total = p.multiProcessorCount;
+    EVR_REQUIRE(n_cus <= total, "evr_stream_create_cu_masked: %d CUs requested, the device has %d", n_cus, total);
+    const int n_xcd = (total % 8 == 0) ? 8 : 1, per = total / n_xcd;
+    uint32_t mask[32];
+    memset(mask, 0, sizeof(mask));
+    EVR_REQUIRE(total <= 32 * 32, "evr_stream_create_cu_masked: %d CUs exceed the mask", total);
+    for (int k = 0; k < n_cus; ++k) {
+        const int x = k % n_xcd, i = k / n_xcd;
+        const int cu = x * per + (from_top ? per - 1 - i : i);
+        mask[cu >> 5] |= 1u << (cu & 31);
+    }
+    int prev = 0;
+    EVR_HIP(hipGetDevice(&prev));
+    EVR_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) return evr::hip_fail(e, "hipExtStreamCreateWithCUMask", __FILE__, __LINE__);
+    *out = (evr_stream_t)s;
+    return EVR_OK;
+}
+extern "C" int evr_stream_destroy(evr_stream_t stream) {
+    if (stream) EVR_HIP(hipStreamDestroy((hipStream_t)stream));
+    return EVR_OK;
+}

@@ -84,8 +84,9 @@ struct ConvArgs {
     const float* pred_w; float pred_b; int pred_sigmoid;
     const float* pred_skip_dot;   // optional [n, hout, wout]: sum_c pred_w[c] * skip[c] computed by the skip's producer (then post_add is null)
     int crop_h, crop_w, crop_y0, crop_x0;
-    int x3;                   // weights are in the split layout (pack_split_weights) and in0/in1 are PACKED tensors:
-    int in_packed;            //   the main loop feeds LDS slots straight to the MFMAs
+    int x3;                   // arithmetic mode (arith_mode()): 2 / 3 = weights in that mode's split layout and in0/in1 PACKED / H2
+    int in_packed;            //   tensors: the main loop feeds LDS slots straight to the MFMAs; 0 = fp32 MFMA on PLAIN tensors
+    float acc_scale;          // mode 3: accumulators (which start at bias / acc_scale) are multiplied by this 2^-(e_w + H2_ACT_EXP)
     unsigned div_hw_mul, div_hw_sh, div_w_mul, div_w_sh;   // m / (hm*wm) and r / wm by multiply-high (set_fastdiv)
     int group_store;          // PACKED outputs as whole 64-B groups after a lane exchange (packed.h xchg16); 0: 4-channel pieces
     int mx_sa, mx_sb;         // E8M0 block scales of the fp8 correction MFMA: 127 - 12 (activations), 127 - e (weights)
@@ -99,6 +100,7 @@ struct ConvArgs {
     int prog_steps;
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
+    unsigned* sat;            // optional device counter: output runs beyond the packed format's exact range (packed.h sat_note)
 };
 
 // Division of n < 2^31 by an invariant d >= 1 as (umulhi(n, mul) + n) >> sh (Granlund-Montgomery, round-up form):
@@ -224,8 +226,68 @@ inline int pack_split_weights(std::vector<float>& w) {
     }
     return e;
 }
-// arithmetic mode of the 32-channel-chunk convolutions: split (f16 + MX-fp8 corrections) unless EVR_FP32=1 (exact fp32 MFMA)
-inline bool use_split_mode() { return getenv("EVR_FP32") == nullptr; }
+// ---- H2: the second PACKED format (fp32-grade arithmetic mode).  Per 16 values 16 f16 hi | 16 f16 lo of v * 2^e:
+// hi = RNE_f16(v 2^e), lo = RNE_f16(v 2^e - hi) -> 22 significant bits while lo stays a normal half (|v 2^e| >= 2^-3).
+// Activations use the fixed exponent H2_ACT_EXP (range +-4094; full precision from 2^-7 up, 2^-29 absolute below);
+// weights a per-tensor exponent that brings max|w| to [2^13, 2^14).  conv.hip multiplies hi_w hi_x + hi_w lo_x + lo_w hi_x
+// on three v_mfma_f32_32x32x16_f16 per 16 k (the dropped lo lo term is 2^-22 of the product), fp32 accumulation of
+// products scaled by 2^(e_w + H2_ACT_EXP); the epilogue multiplies by ConvArgs::acc_scale = 2^-(e_w + H2_ACT_EXP).
+constexpr int H2_ACT_EXP = 4;
+inline void pack_group16_h2(const float* v, int e, unsigned char* dst) {
+    unsigned short hi[16], lo[16];
+    for (int k = 0; k < 16; ++k) {
+        const float c = clampf(__builtin_ldexpf(v[k], e), 65504.0f);
+        hi[k] = f16_rne(c);
+        lo[k] = f16_rne(c - f16_to_f32(hi[k]));
+    }
+    memcpy(dst, hi, 32);
+    memcpy(dst + 32, lo, 32);
+}
+inline void pack_h2_act(std::vector<float>& x) {
+    for (size_t base = 0; base + 16 <= x.size(); base += 16) {
+        unsigned char g[64];
+        pack_group16_h2(&x[base], H2_ACT_EXP, g);
+        memcpy(&x[base], g, 64);
+    }
+}
+inline void unpack_h2(const float* src, float* dst, size_t n, int e) {
+    for (size_t base = 0; base + 16 <= n; base += 16) {
+        unsigned short g[32]; memcpy(g, src + base, 64);
+        for (int k = 0; k < 16; ++k) dst[base + k] = __builtin_ldexpf(f16_to_f32(g[k]) + f16_to_f32(g[16 + k]), -e);
+    }
+}
+// weights -> H2 groups; returns the exponent e (max|w| 2^e in [2^13, 2^14))
+inline int pack_h2_weights(std::vector<float>& w) {
+    float mx = 0.f;
+    for (float v : w) { const float a = v < 0 ? -v : v; if (a == a && a > mx) mx = a; }
+    int e = 0;
+    if (mx > 0.f) { int ex; (void)__builtin_frexpf(16384.0f / mx, &ex); e = ex - 1; if (__builtin_ldexpf(mx, e) >= 16384.0f) --e; }
+    if (e > 40) e = 40;
+    if (e < -40) e = -40;
+    for (size_t base = 0; base + 16 <= w.size(); base += 16) {
+        unsigned char g[64];
+        pack_group16_h2(&w[base], e, g);
+        memcpy(&w[base], g, 64);
+    }
+    return e;
+}
+// arithmetic mode of the 32-channel-chunk convolutions (ConvArgs::x3):
+//   2  split f16 + MX-fp8 corrections on PACKED tensors (default);
+//   3  three f16 products on H2 tensors, fp32-grade (EVR_ARITH=h3);
+//   0  exact fp32 MFMA on PLAIN tensors (EVR_FP32=1 or EVR_ARITH=fp32)
+inline int arith_mode() {
+    if (getenv("EVR_FP32")) return 0;
+    const char* e = getenv("EVR_ARITH");
+    if (!e || !*e || !strcmp(e, "mx")) return 2;
+    if (!strcmp(e, "h3")) return 3;
+    if (!strcmp(e, "fp32")) return 0;
+    return 2;
+}
+inline bool use_split_mode() { return arith_mode() != 0; }
+// value of the `packed` flags for tensors of a mode: 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2
+inline int packed_fmt(int mode) { return mode == 3 ? 2 : (mode == 2 ? 1 : 0); }
+// weights (K contiguous, multiples of 16) -> the mode's split layout in place; returns the tensor exponent
+inline int pack_weights_for(int mode, std::vector<float>& w) { return mode == 3 ? pack_h2_weights(w) : pack_split_weights(w); }
 // (A/B switch for the whole-group PACKED stores)
 inline int use_group_store() { const char* e = getenv("EVR_GROUP_STORE"); return e ? atoi(e) : 1; }
 
@@ -233,6 +295,9 @@ inline int use_group_store() { const char* e = getenv("EVR_GROUP_STORE"); return
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
 // kernel reads it with scalar loads; it is uploaded once per shape, not per launch).
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img = nullptr);
+// (conv.hip is compiled once per split arithmetic: mode 2 + the fp32 kernels, and mode 3; launch_conv_igemm dispatches on a.x3)
+int launch_conv_igemm_mx(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
+int launch_conv_igemm_h3(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 // picks (wm, nb) for the shape: fills the 256 CUs when M is small
 void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);
 
@@ -252,6 +317,7 @@ struct HeadArgs {
     // head_mfma_kernel only: the prediction layer's skip term of every pixel, sum_c pred_w[c] * out[c] (fp32, before the
     // PACKED rounding), so the last decoder reads one float per pixel instead of the 32 channels (ConvArgs::pred_skip_dot)
     const float* pred_w; float* pred_dot;   // [32] / [n, hp, wp], or null
+    unsigned* sat;       // optional device counter of output runs beyond the packed format's exact range (packed.h sat_note)
 };
 // weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B)
 void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out);
@@ -290,7 +356,7 @@ int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, 
 // (packed: all three tensors are PACKED)
 int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream);
 // PLAIN -> PACKED (in place allowed), n a multiple of 16: the output of a VALU kernel that feeds a matrix-core convolution
-int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream);
+int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream, int fmt = 1);
 // SPADE-E2VID helpers (spade.hip; model/spade_e2v.py of the reference)
 struct SpadePredArgs {
     const float* x; const float* head;   // NHWC [n,hp,wp,32]

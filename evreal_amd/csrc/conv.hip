@@ -43,7 +43,24 @@
 #include "packed.h"
 #include <cstdlib>
 
+// This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
+// exact-fp32 kernels -- and EVR_ARITH = 3 -- three f16 products on H2 tensors (conv.h).  Kernels live in their own inner
+// namespace so the two objects do not collide; conv_misc.hip dispatches on ConvArgs::x3.
+#ifndef EVR_ARITH
+#define EVR_ARITH 2
+#endif
+#if EVR_ARITH == 3
+#define EVR_ANS h3
+#define EVR_LAUNCH_NAME launch_conv_igemm_h3
+#else
+#define EVR_ANS mx
+#define EVR_LAUNCH_NAME launch_conv_igemm_mx
+#endif
+
 namespace evr {
+namespace EVR_ANS {
+[[maybe_unused]] constexpr int ARITH = EVR_ARITH;
+[[maybe_unused]] constexpr int FMT = (EVR_ARITH == 3) ? 2 : 1;      // format of this build's packed tensors (packed.h)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -71,9 +88,20 @@ __device__ __forceinline__ i32x8 cat8(u32x4_t p, u32x4_t q) {
 // acc += W . X over the chunk; the weights are the instruction's first operand (acc holds C^T, see the epilogue)
 __device__ __forceinline__ f32x16 mma_split(f32x16 acc, const SplitFrag& w, const SplitFrag& x, int sc_w, int sc_x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(w.f0, w.f1), cat8(x.f0, x.f1), acc, 0, 0, 0, sc_w, 0, sc_x);
+    if constexpr (ARITH == 3) {
+        // H2 rows: slots 0,1 = f16 hi of k 0-15, slots 2,3 = f16 lo of k 0-15, slots 4-7 = k 16-31 -- the same four slots per
+        // lane half (f0 / f1 now hold the lo halves of the k-values in h0 / h1).  hi hi + hi lo + lo hi; lo lo (2^-22) dropped
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.f0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.f0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.f1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.f1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(w.f0, w.f1), cat8(x.f0, x.f1), acc, 0, 0, 0, sc_w, 0, sc_x);
+    }
 #endif
     return acc;
 }
@@ -124,11 +152,11 @@ struct EpiCtx {
 // (row = element offset of the pixel row, c4 = first of the lane's 4 channels; n_valid and cout_total are multiples
 // of 4 -- checked at launch -- so a run is never ragged)
 __device__ __forceinline__ f4 ld4(const float* p, unsigned row, int c4, int packed) {
-    if (packed) return load4_packed(p, row, c4);
+    if (packed) return load4_fmt<FMT>(p, row, c4);
     return *(const f4*)(p + row + (unsigned)c4);
 }
 __device__ __forceinline__ void st4(float* p, unsigned row, int c4, f4 v, int packed) {
-    if (packed) store4_packed(p, row, c4, v);
+    if (packed) store4_fmt<FMT>(p, row, c4, v);
     else *(f4*)(p + row + (unsigned)c4) = v;
 }
 // output pixel and first channel (inside its column group) of the lane in 32-column block nb
@@ -190,13 +218,14 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
             if constexpr (!LSTM) {
                 if (pk && a.group_store) {      // a PACKED operand: the lane's whole group (3 x 16 B), exchanged in epi_finish
                     const int cg = cgb - 4 * h + 16 * h;
-                    f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0;
+                    f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
                     if (cg < nvalid) {               // (a 16-channel tail block: only the lower half of the lane pair loads)
                         const f4* gp = (const f4*)(pre_ptr + row + (unsigned)cg);
                         g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
+                        if constexpr (FMT == 2) g3 = gp[3];      // H2: hi 32 B | lo 32 B
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { pre[nb][j] = g0[j]; pre[nb][4 + j] = g1[j]; pre[nb][8 + j] = g2[j]; }
+                    for (int j = 0; j < 4; ++j) { pre[nb][j] = g0[j]; pre[nb][4 + j] = g1[j]; pre[nb][8 + j] = g2[j]; pre[nb][12 + j] = g3[j]; }
                     continue;
                 }
             }
@@ -210,7 +239,9 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
                     if (c4 - 4 * h < nvalid) {                        // wave-uniform (n_valid is a multiple of 8 or the run is whole)
                         if (pk) {
                             const float* qp = pre_ptr + pk_off(row, c4);
-                            const f4 hi_lo = {qp[0], qp[1], pre_ptr[pk_lo_off(row, c4)], 0.f};   // 8-B hi piece, 4-B lo8 piece
+                            f4 hi_lo = {qp[0], qp[1], 0.f, 0.f};                   // 8-B hi piece + ...
+                            if constexpr (FMT == 2) { hi_lo[2] = qp[8]; hi_lo[3] = qp[9]; }      // ... the 8-B lo piece 32 B on (H2)
+                            else hi_lo[2] = pre_ptr[pk_lo_off(row, c4)];                        // ... the 4-B lo8 piece
                             v = hi_lo;
                         } else {
                             v = *(const f4*)(pre_ptr + row + (unsigned)c4);
@@ -230,6 +261,13 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
     const int epi = a.epi;
     const int m = ec.m;
     const bool mvalid = ec.mvalid;
+    if constexpr (ARITH == 3 && FAST) {      // (FAST = a split kernel) products were accumulated at 2^(e_w + H2_ACT_EXP)
+        const float sc = a.acc_scale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] *= sc;
+    }
     if constexpr (LSTM) {
         static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
         // N tile of 128 = 4 gates x 32 hidden channels (rows permuted at model creation); the conv is stride 1 on
@@ -251,12 +289,12 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
             }
             *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
             if (!a.out_packed) *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
-            else if (!a.group_store) store4_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
+            else if (!a.group_store) store4_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
         }
         if (a.out_packed && a.group_store) {       // the wave's 32 hidden channels of this pixel = two PACKED groups, one per lane of the pair
             float w16[16];
             xchg16(hall, w16);
-            store16_packed(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 16 * h, w16);
+            store16_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 16 * h, w16);
         }
         return;
     } else {
@@ -347,10 +385,17 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
             const bool pre_group = has_pre && pre_pk && a.group_store;
             f32x16 pvall = pre[nb];
             if (pre_group) {      // whole-group operand (epi_prefetch): decode, back to the accumulator order (all lanes take part)
-                unsigned g[12];
+                if constexpr (FMT == 2) {
+                    unsigned g[16];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) g[i] = __float_as_uint(pre[nb][i]);
-                unpack16_xchg(g, pvall);
+                    for (int i = 0; i < 16; ++i) g[i] = __float_as_uint(pre[nb][i]);
+                    unpack16_xchg_h2(g, pvall);
+                } else {
+                    unsigned g[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) g[i] = __float_as_uint(pre[nb][i]);
+                    unpack16_xchg(g, pvall);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -364,7 +409,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     f4 pv = {pvall[4 * q], pvall[4 * q + 1], pvall[4 * q + 2], pvall[4 * q + 3]};
                     if (has_pre && pre_pk && !pre_group) {
                         const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])};
-                        pv = unpack4(phi, __float_as_uint(pv[2]));
+                        if constexpr (FMT == 2) { const uint2 plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])}; pv = unpack4_h2(phi, plo); }
+                        else pv = unpack4(phi, __float_as_uint(pv[2]));
                     }
                     if (res) v += pv;
 #pragma unroll
@@ -378,7 +424,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     if (group_store) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) outv[4 * q + j] = v[j];
-                    } else if (!pw) st4(a.out, orow, c4, v, a.out_packed);
+                    } else if (!pw) { if (a.out_packed) sat_check4<FMT>(a.sat, v); st4(a.out, orow, c4, v, a.out_packed); }
                     else {
                         const f4 w4 = pw_shared ? pwq[q] : *(const f4*)(pw + c4);
 #pragma unroll
@@ -390,7 +436,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 float w16[16];
                 xchg16(outv, w16);
                 const int cg = cgb - 4 * h + 16 * h;           // the lane's group inside the column group
-                if (mvalid && cg < nvalid) store16_packed(a.out, opx * ct, cg, w16);
+                if (mvalid && cg < nvalid) { sat_check16<FMT>(a.sat, w16); store16_fmt<FMT>(a.out, opx * ct, cg, w16); }
                 __builtin_amdgcn_sched_barrier(0);             // one block's conversion temporaries at a time
             }
             // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
@@ -1315,7 +1361,10 @@ static int launch_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t strea
     return EVR_OK;
 }
 
-int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
+}  // namespace EVR_ANS
+using namespace EVR_ANS;
+
+int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
     EVR_REQUIRE(!a.pred_w || (a.cout == 32 * nb && img), "conv_igemm: fused prediction needs a single N tile and an image pointer");
     EVR_REQUIRE(a.tp.grp_cols % 32 == 0 && a.tp.ngroups * a.tp.grp_cols == a.cout && a.tp.ngroups <= MAX_PHASES, "conv_igemm: bad column groups");
     EVR_REQUIRE(a.cout % (32 * nb) == 0, "conv_igemm: cout %d not a multiple of %d", a.cout, 32 * nb);
@@ -1330,7 +1379,14 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
     const bool packed_io = a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed;
     EVR_REQUIRE(!packed_io || a.x3, "conv_igemm: PACKED tensors need the split mode");
     EVR_REQUIRE(!a.x3 || a.in_packed, "conv_igemm: the split kernels take PACKED inputs");
-    EVR_REQUIRE(!a.x3 || (a.mx_sa > 0 && a.mx_sb > 0), "conv_igemm: split mode without block scales");
+    EVR_REQUIRE(a.x3 != 2 || (a.mx_sa > 0 && a.mx_sb > 0), "conv_igemm: split mode without block scales");
+    EVR_REQUIRE(a.x3 != 3 || a.acc_scale > 0.f, "conv_igemm: three-product mode without the accumulator scale");
+    EVR_REQUIRE(a.x3 == 0 || a.x3 == 2 || a.x3 == 3, "conv_igemm: unknown arithmetic mode %d", a.x3);
+#if EVR_ARITH == 3
+    EVR_REQUIRE(a.x3 == 3, "conv_igemm: this object carries the three-f16-product kernels only (mode %d requested)", a.x3);
+#else
+    EVR_REQUIRE(a.x3 != 3, "conv_igemm: the three-f16-product kernels live in the other object");
+#endif
     EVR_REQUIRE(a.div_hw_sh < 32 && a.div_w_sh < 32 && (a.div_hw_mul || (unsigned)(a.hm * a.wm) == (1u << a.div_hw_sh)) && (a.div_w_mul || (unsigned)a.wm == (1u << a.div_w_sh)),
                 "conv_igemm: plan without set_fastdiv()");
     EVR_REQUIRE(!a.out_packed || (a.n_valid % 8 == 0 && a.cout_total % 8 == 0), "conv_igemm: PACKED output needs channel counts that are multiples of 8");
@@ -1398,15 +1454,21 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
             if (wm == 2) return launch_t<32, 2, 4, true, false, false, 2>(a, d_args, stream, img);
             return launch_t<32, 1, 4, true, false, false, 2>(a, d_args, stream, img);
         }
+#if EVR_ARITH == 2
         if (wm == 8) return launch_t<32, 8, 4, true, false>(a, d_args, stream, img);
         // register staging measured +1..4 % over LDS-DMA for this kernel (EVR_LSTM_DMA=1 selects the DMA loader)
         if (wm == 4 && !getenv("EVR_LSTM_DMA")) return launch_t<32, 4, 4, true, false, true>(a, d_args, stream, img);
         if (wm == 4) return launch_t<32, 4, 4, true, false>(a, d_args, stream, img);
         if (wm == 2) return launch_t<32, 2, 4, true, false>(a, d_args, stream, img);
         return launch_t<32, 1, 4, true, false>(a, d_args, stream, img);
+#endif
     }
     if (a.tp.ngroups > 1) {   // transposed conv: column groups = sub-pixel phases
+#if EVR_ARITH == 2
 #define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { if (mode == 2) return launch_t<32, WM_, NB_, false, true, false, 2>(a, d_args, stream, img); return launch_t<32, WM_, NB_, false, true>(a, d_args, stream, img); }
+#else
+#define EVR_CASEG(WM_, NB_) if (kc == 32 && wm == WM_ && nb == NB_) { return launch_t<32, WM_, NB_, false, true, false, 2>(a, d_args, stream, img); }
+#endif
         EVR_CASEG(4, 4) EVR_CASEG(2, 4) EVR_CASEG(1, 4) EVR_CASEG(4, 2) EVR_CASEG(2, 2) EVR_CASEG(1, 2)
         EVR_CASEG(4, 1) EVR_CASEG(2, 1) EVR_CASEG(1, 1)
 #undef EVR_CASEG
@@ -1419,525 +1481,16 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
         EVR_CASEX(4, 1) EVR_CASEX(2, 1) EVR_CASEX(1, 1)
 #undef EVR_CASEX
     }
+#if EVR_ARITH == 2
 #define EVR_CASE(KC_, WM_, NB_) if (kc == KC_ && wm == WM_ && nb == NB_) return launch_t<KC_, WM_, NB_, false, false>(a, d_args, stream, img);
     EVR_CASE(32, 4, 4) EVR_CASE(32, 2, 4) EVR_CASE(32, 1, 4)
     EVR_CASE(32, 4, 2) EVR_CASE(32, 2, 2) EVR_CASE(32, 1, 2)
     EVR_CASE(32, 4, 1) EVR_CASE(32, 2, 1) EVR_CASE(32, 1, 1)
     EVR_CASE(16, 4, 1) EVR_CASE(16, 2, 1) EVR_CASE(16, 1, 1)
 #undef EVR_CASE
+#endif
     set_error("conv_igemm: no kernel for kc=%d wm=%d nb=%d", kc, wm, nb);
     return EVR_ERR_UNSUPPORTED;
-}
-
-void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb) {
-    int n_b = (a.cout % 128 == 0) ? 4 : (a.cout % 64 == 0) ? 2 : 1;
-    if (kc == 16) n_b = 1;
-    if (a.epi == EPI_LSTM) n_b = 4;
-    const int64_t M = (int64_t)a.n * a.hm * a.wm;
-    const int ntiles = a.cout / (32 * n_b);
-    // Wave-quantisation model: a CU holds bpc blocks (LDS- and register-limited); every wave does the same work
-    // whatever WM is, and the waves resident on a SIMD share its matrix pipe, so
-    //   time ~ rounds(WM) * waves_per_SIMD(WM),  rounds = ceil(blocks / (256 CUs * bpc)).
-    // Pick the WM that minimises it (ties -> the larger tile: fewer weight re-loads).
-    const int occ = (n_b == 4) ? 2 : (n_b == 2) ? 3 : 4;          // waves/SIMD the kernels' VGPR budgets allow
-    int best = 4; double best_cost = 1e30;
-    for (int w = 4; w >= 1; w >>= 1) {
-        const int lds = 2 * (32 * w + 32 * n_b) * kc * 4;
-        int bpc = (160 * 1024) / lds;
-        if (bpc > (4 * occ) / w) bpc = (4 * occ) / w;
-        if (bpc < 1) bpc = 1;
-        const int64_t blocks = ((M + 32 * w - 1) / (32 * w)) * ntiles;
-        const int64_t rounds = (blocks + 256LL * bpc - 1) / (256LL * bpc);
-        const double eff = (w == 4) ? 1.0 : (w == 2) ? 0.93 : 0.85;   // smaller tiles re-load the weight tile more often
-        const double cost = (double)rounds * (bpc * w / 4.0) / eff;
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
-    }
-    if (a.epi == EPI_LSTM) {   // the ConvLSTM kernel is tuned (register staging) at WM = 4; shrink only to fill the chip
-        best = 4;
-        while (best > 1 && ((M + 32 * best - 1) / (32 * best)) * ntiles < 512) best >>= 1;
-    }
-    if (a.epi == EPI_LSTM && getenv("EVR_LSTM_WM8")) best = 8;   // experiment: 256x128 block tile
-    *wm = best; *nb = n_b;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Head convolution: tiny Cin (num_bins), so K = B*k*k is too ragged for the MFMA tiles; a direct
-// VALU kernel with the input tile in LDS and wave-uniform weights is HBM-bound on its NHWC output.
-// eval.py:398-410 from the tensorizer's {sum, sumsq, nnz}: returns false when the tensor stays as is
-__device__ __forceinline__ bool norm_params(const double* stats, int n, float& mean, float& sd) {
-    mean = 0.f; sd = 1.f;
-    if (!stats) return false;
-    const double s1 = stats[n * 3], s2 = stats[n * 3 + 1], nz = stats[n * 3 + 2];
-    if (!(nz > 0.0)) return false;
-    const float nf = (float)nz;
-    mean = (float)s1 / nf;
-    const float ex2 = (float)s2 / nf;
-    sd = sqrtf(__fsub_rn(ex2, __fmul_rn(mean, mean)));
-    if (sd == sd) sd = fmaxf(sd, 1e-6f);
-    return true;
-}
-__device__ __forceinline__ float norm_apply(float v, float mean, float sd) {
-    const float mask = (v != 0.f) ? 1.f : 0.f;
-    return __fmul_rn(mask, __fsub_rn(v, mean)) / sd;
-}
-
-template <int K, int COUT>
-__global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
-    constexpr int TS = 16, IS = TS + K - 1;
-    extern __shared__ float tile[];   // [B][IS][IS]
-    const int n = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS, tid = threadIdx.x;
-
-    float mean, sd;
-    const bool norm = norm_params(a.stats, n, mean, sd);   // eval.py:398-410 fused into the load
-    const float* vin = a.vox + (int64_t)n * a.B * a.H * a.W;
-    for (int i = tid; i < a.B * IS * IS; i += 256) {
-        const int b = i / (IS * IS), rr = (i / IS) % IS, cc = i % IS;
-        const int y = ty0 + rr - K / 2 - a.pad_top, x = tx0 + cc - K / 2 - a.pad_left;
-        float v = 0.f;
-        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
-            v = vin[((int64_t)b * a.H + y) * a.W + x];
-            if (norm) v = norm_apply(v, mean, sd);
-        }
-        tile[i] = v;
-    }
-    __syncthreads();
-    const int ly = tid / TS, lx = tid % TS;
-    const int oy = ty0 + ly, ox = tx0 + lx;
-    float acc[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = a.bias[co];
-    for (int b = 0; b < a.B; ++b) {
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float v = tile[(b * IS + ly + ky) * IS + lx + kx];
-                const float* w = a.wgt + ((b * K + ky) * K + kx) * COUT;   // wave-uniform -> scalar loads
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-            }
-        }
-    }
-    if (oy < a.hp && ox < a.wp) {
-        float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * COUT;
-#pragma unroll
-        for (int co = 0; co < COUT; co += 4) {
-            float4 v = make_float4(acc[co], acc[co + 1], acc[co + 2], acc[co + 3]);
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (a.out_packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(o, 0u, co, t); continue; }
-#endif
-            *(float4*)(o + co) = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Head convolution on the matrix cores (split mode, k = 5, 32 output channels; its K = 125 is too ragged for the f16 + fp8
-// chunks, so this kernel keeps three bf16 products: x = hi + lo, w = hi + lo, acc += hi*hi + hi*lo + lo*hi): GEMM M = pixels, N = 32,
-// K = (bin, ky, kx).  The direct VALU kernel above spends 4000 FMAs per pixel (0.65 ms per 64 frames, the HBM
-// floor of its 761-MB output is 0.15 ms); here a pixel costs ~5 instructions per lane.
-//   K order  chosen so the two lane halves of an MFMA operand differ by ONE LDS row: the 5 kernel rows are padded
-//            to 6 (the 6th has zero weights) and half h takes ky = 2*kyp + h.  Element e < 75 = (b, kyp, kx),
-//            8 elements per 16-k slab, 10 slabs (K = 160 incl. padding): every gather address is the lane's base
-//            plus a compile-time offset -- no address arithmetic.
-//   A (weights)  live in 80 VGPRs for the whole kernel, loaded in fragment order (head_pack_wfrag).
-//   B (pixels)   the normalised, zero-padded input tile [B][8+5][32+4] sits in LDS as u32 = hi | lo << 16 (split once
-//            per element); a lane gathers 8 elements per slab and two v_perm build the hi and lo operands.
-//   C^T      lane = pixel, registers = channels -> bias, ReLU, PACKED 8-B stores.
-__global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TH = 8, TW = 32, LR = TH + 5, LC = TW + 4, PLANE = LR * LC;
-    extern __shared__ unsigned htile[];   // [B][LR][LC]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-
-    // weight fragments (slab s, {hi, lo}: 16 B per lane) stay in registers across ALL tiles of this persistent block;
-    // the empty asm makes them opaque so hipcc neither sinks the loads into the tile loop nor re-loads them there
-    const u32x4_t* wf = (const u32x4_t*)a.wfrag;
-    u32x4_t w_hi[10], w_lo[10];
-#pragma unroll
-    for (int s = 0; s < 10; ++s) { w_hi[s] = wf[(2 * s) * 64 + lane]; w_lo[s] = wf[(2 * s + 1) * 64 + lane]; }
-#pragma unroll
-    for (int s = 0; s < 10; ++s) { asm volatile("" : "+v"(w_hi[s])); asm volatile("" : "+v"(w_lo[s])); }
-    f4 bias4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bias4[q] = *(const f4*)(a.bias + 8 * q + 4 * h);
-
-    const int tiles_x = (a.wp + TW - 1) / TW, tiles_y = (a.hp + TH - 1) / TH;
-    const int ntiles = a.n * tiles_y * tiles_x;
-    // input tile fetch, software-pipelined: the raw values of tile t+1 are requested (all loads back to back, no
-    // consumer in between) before tile t is computed and land in LDS after it
-    constexpr int NL = (5 * PLANE + 255) / 256;
-    float raw[NL];
-    auto fetch = [&](int tile) {
-        const int n = tile / (tiles_y * tiles_x), trem = tile - n * (tiles_y * tiles_x);
-        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
-        const float* vin = a.vox + (int64_t)n * a.B * a.H * a.W;
-#pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            const int i = tid + it * 256;
-            const int b = i / PLANE, rem = i - b * PLANE, rr = rem / LC, cc = rem - rr * LC;
-            const int y = ty0 + rr - 2 - a.pad_top, x = tx0 + cc - 2 - a.pad_left;
-            const bool ok = i < a.B * PLANE && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            const float v = vin[ok ? ((int64_t)b * a.H + y) * a.W + x : 0];      // (no branch around the load)
-            raw[it] = ok ? v : __uint_as_float(0x7fc00001u);                  // NaN payload marks "outside"
-        }
-    };
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / (tiles_y * tiles_x), trem = tile - n * (tiles_y * tiles_x);
-        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
-        float mean, sd;
-        const bool norm = norm_params(a.stats, n, mean, sd);   // eval.py:398-410 fused into the load
-        __syncthreads();                                       // everyone is done with the previous tile
-#pragma unroll
-        for (int it = 0; it < NL; ++it) {
-            const int i = tid + it * 256;
-            float v = raw[it];
-            const bool outside = __float_as_uint(v) == 0x7fc00001u;
-            if (outside) v = 0.f; else if (norm) v = norm_apply(v, mean, sd);
-            const unsigned hi = cvt_pk_bf16(v, 0.f) & 0xffffu;
-            const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
-            if (i < a.B * PLANE) htile[i] = hi | (lo << 16);
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-#pragma unroll 1
-        for (int rp = 0; rp < 2; ++rp) {
-            const int ty = wv * 2 + rp;
-            const unsigned* base = htile + (ty + h) * LC + r;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j];
-#pragma unroll
-            for (int s = 0; s < 10; ++s) {
-                unsigned e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int el = 8 * s + j; if (el > 74) el = 74;                // padding slots: zero weights, any address
-                    const int b = el / 15, rem = el % 15, kyp = rem / 5, kx = rem % 5;
-                    e[j] = base[b * PLANE + (2 * kyp) * LC + kx];
-                }
-                u32x4_t ah, al;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ah[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
-                    al[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
-                }
-                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
-                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, w_hi[s]), b_lo = __builtin_bit_cast(bf16x8, w_lo[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc, 0, 0, 0);
-            }
-            const int oy = ty0 + ty, ox = tx0 + r;
-            if (a.relu) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
-            }
-            float* o = a.out + (((int64_t)n * a.hp + oy) * a.wp + ox) * 32;
-            if (a.pred_dot) {       // skip term of the fused prediction layer (model/unet.py:136-138): sum_c w[c] * head[c]
-                float dot = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f4 w4 = *(const f4*)(a.pred_w + 8 * q + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dot = fmaf(acc[4 * q + j], w4[j], dot);
-                }
-                dot += __shfl_xor(dot, 32, 64);
-                if (h == 0 && oy < a.hp && ox < a.wp) a.pred_dot[((int64_t)n * a.hp + oy) * a.wp + ox] = dot;
-            }
-            if (a.out_packed && a.group_store) {     // the lane pair of a pixel trades runs: each stores one whole 64-B PACKED group
-                float w16[16];
-                xchg16(acc, w16);
-                if (oy < a.hp && ox < a.wp) store16_packed(o, 0u, 16 * h, w16);
-            } else if (oy < a.hp && ox < a.wp) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
-                    else *(f4*)(o + 8 * q + 4 * h) = v;
-                }
-            }
-        }
-    }
-#endif
-}
-
-void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
-    // out[((2*s + part) * 64 + lane) * 4 + d]: lane = channel c + 32*h; dword d holds k-positions 2d, 2d+1 of the lane's 8
-    out.assign((size_t)20 * 64 * 4, 0u);
-    for (int s = 0; s < 10; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int c = lane & 31, h = lane >> 5;
-            for (int j = 0; j < 8; ++j) {
-                const int el = 8 * s + j;
-                float v = 0.f;
-                if (el < 15 * B && el <= 74) {
-                    const int b = el / 15, rem = el % 15, ky = 2 * (rem / 5) + h, kx = rem % 5;
-                    if (ky <= 4) v = w[((size_t)(b * 5 + ky) * 5 + kx) * 32 + c];
-                }
-                const unsigned short hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
-                out[((size_t)(2 * s) * 64 + lane) * 4 + j / 2] |= (unsigned)hi << (16 * (j & 1));
-                out[((size_t)(2 * s + 1) * 64 + lane) * 4 + j / 2] |= (unsigned)lo << (16 * (j & 1));
-            }
-        }
-}
-
-int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
-    if (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5) {
-        const HeadArgs& a2 = a;
-        const int ntiles = a.n * ((a.hp + 7) / 8) * ((a.wp + 31) / 32);
-        const dim3 g((unsigned)(ntiles < 768 ? ntiles : 768));        // persistent: 3 blocks per CU walk the tiles
-        hipLaunchKernelGGL(head_mfma_kernel, g, dim3(256), (size_t)a.B * 13 * 36 * sizeof(unsigned), stream, a2);
-        EVR_LAUNCH_CHECK();
-        return EVR_OK;
-    }
-    const dim3 grid((a.wp + 15) / 16, (a.hp + 15) / 16, a.n);
-    const int IS = 16 + a.k - 1;
-    const size_t lds = (size_t)a.B * IS * IS * sizeof(float);
-    EVR_REQUIRE(lds <= 64 * 1024, "head_conv: num_bins %d too large", a.B);
-#define EVR_HEAD(K_, C_) if (a.k == K_ && a.cout == C_) { hipLaunchKernelGGL((head_conv_kernel<K_, C_>), grid, dim3(256), lds, stream, a); EVR_LAUNCH_CHECK(); return EVR_OK; }
-    EVR_HEAD(5, 32) EVR_HEAD(3, 16) EVR_HEAD(3, 32) EVR_HEAD(5, 16) EVR_HEAD(3, 64)
-#undef EVR_HEAD
-    set_error("head_conv: unsupported kernel_size %d / base channels %d", a.k, a.cout);
-    return EVR_ERR_UNSUPPORTED;
-}
-
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pred_kernel(const PredArgs a) {
-    // 8 lanes per pixel, one float4 (4 channels) each per 32-channel group: a wave reads 8 pixels x 128 B
-    // contiguous lines (the thread-per-pixel form over-fetched 3.7x, profiles/r01_pmc_fetch_size_nseq16.md)
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = gid >> 3;
-    const int sub = (int)(gid & 7);
-    const int64_t total = (int64_t)a.n * a.H * a.W;
-    const bool live = i < total;
-    float acc = 0.f;
-    if (live) {
-        const int n = (int)(i / ((int64_t)a.H * a.W));
-        const int rem = (int)(i - (int64_t)n * a.H * a.W);
-        const int y = rem / a.W, x = rem - y * a.W;
-        const int64_t pix = ((int64_t)n * a.hp + (y + a.iy0)) * a.wp + (x + a.ix0);
-        for (int c4 = sub; c4 < a.c / 4; c4 += 8) {
-            float4 v = ld4_any(a.x + pix * a.c, c4 * 4, a.x_packed);
-            if (a.skip) { const float4 u = ld4_any(a.skip + pix * a.c, c4 * 4, a.skip_packed); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-            const float* w = a.wgt + c4 * 4;
-            acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
-        }
-    }
-    acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64);
-    if (live && sub == 0) {
-        acc += a.bias;
-        if (a.sigmoid) acc = sigmoidf_(acc);
-        a.img[i] = acc;   // (prev_rec needs the un-cropped frame: models that use it keep crop == full, see model.cpp)
-    }
-}
-
-int launch_pred(const PredArgs& a, hipStream_t stream) {
-    EVR_REQUIRE(a.c % 4 == 0, "pred: channels %d not a multiple of 4", a.c);
-    const int64_t total = (int64_t)a.n * a.H * a.W * 8;
-    hipLaunchKernelGGL(pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// HyperE2VID context downsample (ConvolutionalContextFusion, hyper_dynamic.py:19-23, before its conv)
-__global__ __launch_bounds__(256) void ctx_down_kernel(const CtxArgs a) {
-    const int ho = a.hp / 4, wo = a.wp / 4, C = a.B + 1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)a.n * C * ho * wo;
-    if (i >= total) return;
-    const int ox = (int)(i % wo); int64_t p = i / wo;
-    const int oy = (int)(p % ho); p /= ho;
-    const int ch = (int)(p % C);
-    const int n = (int)(p / C);
-    float mean, sd;
-    const bool norm = (ch < a.B) && norm_params(a.stats, n, mean, sd);
-    auto ld = [&](int py, int px) -> float {      // padded coordinates
-        if (ch == a.B) return a.prev_rec[((int64_t)n * a.hp + py) * a.wp + px];
-        const int y = py - a.pad_top, x = px - a.pad_left;
-        if ((unsigned)y >= (unsigned)a.H || (unsigned)x >= (unsigned)a.W) return 0.f;
-        float v = a.vox[(((int64_t)n * a.B + ch) * a.H + y) * a.W + x];
-        return norm ? norm_apply(v, mean, sd) : v;
-    };
-    // aten upsample_bilinear2d with scale 4: src = 4*o + 1.5 -> rows 4o+1, 4o+2 with lambdas 0.5/0.5
-    const int y0 = 4 * oy + 1, x0 = 4 * ox + 1;
-    const float v00 = ld(y0, x0), v01 = ld(y0, x0 + 1), v10 = ld(y0 + 1, x0), v11 = ld(y0 + 1, x0 + 1);
-    a.out[i] = 0.5f * (0.5f * v00 + 0.5f * v01) + 0.5f * (0.5f * v10 + 0.5f * v11);
-}
-
-int launch_ctx_down(const CtxArgs& a, hipStream_t stream) {
-    EVR_REQUIRE(a.hp % 4 == 0 && a.wp % 4 == 0, "ctx_down: padded size %dx%d not a multiple of 4", a.wp, a.hp);
-    const int64_t total = (int64_t)a.n * (a.B + 1) * (a.hp / 4) * (a.wp / 4);
-    hipLaunchKernelGGL(ctx_down_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-
-// Per-pixel dynamic 5x5 filtering.  One block = 8 consecutive pixels of a row; thread = channel (c <= 256,
-// coalesced NHWC reads).  The pixel's 6x25 atoms are built in LDS from its 72 coefficients and the 12x25 bases.
-__global__ __launch_bounds__(256) void dynamic_filter_kernel(const float* __restrict__ x, const float* __restrict__ coeff,
-                                                              const float* __restrict__ bases, float* __restrict__ out,
-                                                              int n, int h, int w, int c) {
-    constexpr int PX = 8, NA = 6, NBAS = 12, KK = 25;
-    __shared__ float sb[NBAS * KK];
-    __shared__ float atoms[PX][NA * KK];
-    const int tid = threadIdx.x;
-    const int wblk = (w + PX - 1) / PX;
-    const int bx = blockIdx.x % wblk, row = blockIdx.x / wblk;   // row over n*h
-    const int img = row / h, py = row % h, px0 = bx * PX;
-    for (int i = tid; i < NBAS * KK; i += 256) sb[i] = bases[i];
-    __syncthreads();
-    for (int i = tid; i < PX * NA * KK; i += 256) {
-        const int p = i / (NA * KK), r = i % (NA * KK), m = r / KK, l = r % KK;
-        float s = 0.f;
-        if (px0 + p < w) {
-            const float* cf = coeff + (((int64_t)img * h + py) * w + px0 + p) * (NA * NBAS) + m * NBAS;
-            for (int k = 0; k < NBAS; ++k) s = fmaf(cf[k], sb[k * KK + l], s);      // einsum 'bmkhw,kl->bmlhw'
-        }
-        atoms[p][r] = s;
-    }
-    __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
-        for (int p = 0; p < PX && px0 + p < w; ++p) {
-            float acc[NA] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int px = px0 + p;
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const int yy = py + ky - 2;
-#pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int xx = px + kx - 2;
-                    float v = 0.f;
-                    if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) v = x[(((int64_t)img * h + yy) * w + xx) * c + ch];
-                    const int l = ky * 5 + kx;
-#pragma unroll
-                    for (int m = 0; m < NA; ++m) acc[m] = fmaf(atoms[p][m * KK + l], v, acc[m]);   // 'bmlhw,bclhw->bcmhw'
-                }
-            }
-            float* o = out + (((int64_t)img * h + py) * w + px) * (int64_t)(c * NA) + ch * NA;
-#pragma unroll
-            for (int m = 0; m < NA; ++m) o[m] = acc[m];
-        }
-    }
-}
-
-int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w, int c,
-                          hipStream_t stream) {
-    const int wblk = (w + 7) / 8;
-    hipLaunchKernelGGL(dynamic_filter_kernel, dim3((unsigned)(wblk * n * h)), dim3(256), 0, stream, x, coeff, bases, out, n, h, w, c);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) of (x + skip), NHWC.
-__global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __restrict__ x, const float* __restrict__ skip,
-                                                              float* __restrict__ out, int n, int h, int w, int c,
-                                                              int x_packed, int skip_packed, int out_packed) {
-    const int c4n = c / 4;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)n * 2 * h * 2 * w * c4n;
-    if (i >= total) return;
-    const int c4 = (int)(i % c4n);
-    int64_t p = i / c4n;
-    const int ox = (int)(p % (2 * w)); p /= 2 * w;
-    const int oy = (int)(p % (2 * h));
-    const int img = (int)(p / (2 * h));
-    // aten area_pixel_compute_source_index: src = 0.5*(dst+0.5)-0.5, clamped at 0
-    float sy = 0.5f * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
-    float sx = 0.5f * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
-    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
-    auto ld = [&](int yy, int xx) {
-        const int64_t o = (((int64_t)img * h + yy) * w + xx) * c;
-        float4 v = ld4_any(x + o, c4 * 4, x_packed);
-        if (skip) { const float4 u = ld4_any(skip + o, c4 * 4, skip_packed); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-        return v;
-    };
-    const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
-    float4 o4;
-    o4.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
-    o4.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
-    o4.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
-    o4.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-    st4_any(out + (((int64_t)img * 2 * h + oy) * 2 * w + ox) * c, c4 * 4, o4, out_packed);
-}
-
-int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, int out_packed, hipStream_t stream) {
-    EVR_REQUIRE(c % 4 == 0, "upsample: channels %d not a multiple of 4", c);
-    EVR_REQUIRE(!(x_packed || skip_packed || out_packed) || c % 16 == 0, "upsample: PACKED tensors need channels %d to be a multiple of 16", c);
-    const int64_t total = (int64_t)n * 4 * h * w * (c / 4);
-    hipLaunchKernelGGL(upsample2x_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c, x_packed, skip_packed, out_packed);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ o, int64_t n4, int packed) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        // 4-channel run i: PACKED tensors are addressed per 16-channel group (the row base is the group, c4 = 0..12)
-        const int64_t base = packed ? (i >> 2) * 16 : i * 4;
-        const int c4 = packed ? (int)(i & 3) * 4 : 0;
-        const float4 a = ld4_any(x + base, c4, packed), b = ld4_any(y + base, c4, packed);
-        st4_any(o + base, c4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w), packed);
-    }
-}
-
-int launch_add(const float* x, const float* y, float* out, int64_t n, int packed, hipStream_t stream) {
-    EVR_REQUIRE(n % 16 == 0, "add: element count not a multiple of 16");
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y, out, n / 4, packed);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-// PLAIN -> PACKED, one 16-channel group per thread (may run in place: a thread reads its 64 B before it writes them)
-__global__ __launch_bounds__(256) void to_packed_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t groups) {
-    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
-        const float4* sp = (const float4*)(src + g * 16);
-        const float4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
-        float* d = dst + g * 16;
-        st4_any(d, 0, v0, 1); st4_any(d, 4, v1, 1); st4_any(d, 8, v2, 1); st4_any(d, 12, v3, 1);
-    }
-}
-int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream) {
-    EVR_REQUIRE(n % 16 == 0, "to_packed: element count not a multiple of 16");
-    int64_t blocks = (n / 16 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(to_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, dst, n / 16);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
-}
-
-
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, int packed) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)n * h * w * c;
-    if (i >= total) return;
-    const int x = (int)(i % w); int64_t p = i / w;
-    const int y = (int)(p % h); p /= h;
-    const int ch = (int)(p % c);
-    const int img = (int)(p / c);
-    const float* row = src + (((int64_t)img * h + y) * w + x) * c;
-    float v = row[ch];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (packed) v = load1_packed(row, ch);
-#endif
-    dst[i] = v;
-}
-
-int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream) {
-    EVR_REQUIRE(!packed || c % 16 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c);
-    const int64_t total = (int64_t)n * h * w * c;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c, packed);
-    EVR_LAUNCH_CHECK();
-    return EVR_OK;
 }
 
 }  // namespace evr

@@ -12,6 +12,7 @@
 // in the same gray value); conv2..conv5 run on the convolution kernels of conv.hip (split arithmetic: conv2 on the implicit
 // GEMM, conv3..conv5 on the band kernel; pool1/feat1.. are then PACKED tensors, conv.h); 3x3/2 max pools and the
 // per-layer score are NHWC streaming kernels (one wave per pixel for the channel norms).
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -300,7 +301,7 @@ __global__ void lpips_final_kernel(const double* __restrict__ partials, double* 
 
 constexpr int SCORE_BLOCKS = 32;
 
-struct Layer { int cin, cout, k, pad; bool x3 = false; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
+struct Layer { int cin, cout, k, pad; int x3 = 0; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
 
 }  // namespace
 
@@ -422,8 +423,9 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
             L.w.assign((size_t)cout[l] * taps * cin[l], 0.f); L.b.assign(b->data_host, b->data_host + cout[l]);
             for (int co = 0; co < cout[l]; ++co) for (int ci = 0; ci < cin[l]; ++ci) for (int t = 0; t < taps; ++t)
                 L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
-            L.x3 = use_split_mode();      // conv2..conv5 run on the same implicit-GEMM family as the networks
-            if (L.x3) L.mx_e = pack_split_weights(L.w);
+            L.x3 = arith_mode();          // conv2..conv5 run on the same implicit-GEMM family as the networks, in their mode
+            if (L.x3) L.mx_e = pack_weights_for(L.x3, L.w);
+            if (L.x3 == 3) for (float& bv : L.b) bv = std::ldexp(bv, L.mx_e + H2_ACT_EXP);      // (model.cpp finish_conv)
             if ((rc = up(L.w, &L.d_w))) break;
             if ((rc = up(L.b, &L.d_b))) break;
         }
@@ -472,8 +474,9 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.tp.ntaps = L.k * L.k; a.tp.ngroups = 1; a.tp.grp_cols = L.cout;
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
-        a.epi = EPI_BIAS_RELU; a.x3 = L.x3 ? 1 : 0;
-        a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED in split mode
+        a.epi = EPI_BIAS_RELU; a.x3 = L.x3;
+        a.acc_scale = (L.x3 == 3) ? std::ldexp(1.0f, -(L.mx_e + H2_ACT_EXP)) : 1.0f;
+        a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED (H2 in mode 3) in the split modes
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
@@ -509,7 +512,7 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
         hipLaunchKernelGGL(lpips_conv1_kernel, dim3((m->w[0] + 15) / 16, (m->h[0] + 15) / 16, n2), dim3(256), lds1, stream, c1);
     }
     EVR_LAUNCH_CHECK();
-    const int pk = m->L[0].x3 ? 1 : 0;
+    const int pk = packed_fmt(m->L[0].x3);
     auto pool = [&](const float* in, float* o, int h, int w, int c, int ho, int wo, int in_pk) -> int {
         const int64_t total = (int64_t)n2 * ho * wo * (c / 4);
         hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, o, n2, h, w, c, ho, wo, in_pk, pk);

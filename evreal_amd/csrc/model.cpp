@@ -50,8 +50,8 @@ struct Conv {   // one prepared implicit-GEMM convolution
     bool transposed = false;
     int epi = EPI_BIAS, hidden = 0;
     ConvTaps tp;
-    bool x3 = false;            // weights packed for the split kernels (pack_split_weights)
-    int mx_e = 0;               //   and the exponent of their fp8 pieces
+    int x3 = 0;                 // arithmetic mode (conv.h arith_mode): 2 / 3 = weights packed for that split kernel family, 0 = fp32
+    int mx_e = 0;               //   and the exponent of their packed pieces
     double useful_taps = 0;   // (tap, group) pairs that carry weights (direct-conv FLOP accounting)
     std::vector<float> w, b;    // host, prepared layout
     float* d_w = nullptr; float* d_b = nullptr;
@@ -93,12 +93,14 @@ struct evr_model {
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
     bool packed = false;   // split mode: tensors between matrix-core convolutions use the PACKED format
+    int fmt = 0;           //   value of the `packed` flags of those tensors (conv.h packed_fmt: 1 PACKED, 2 H2)
     int pred_x_packed = 0, pred_skip_packed = 0;
     std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes): state and activations, zeroed by every reset
     std::vector<float*> shape_consts;                // per-shape constant tables (ET-Net sine table): freed with the shape, never zeroed
     std::map<std::string, DevTensor> named[2];   // debug names -> tensor valid after a frame of parity p
     std::vector<Step> steps;
     ConvArgs* d_args = nullptr;
+    unsigned* d_sat = nullptr;   // [convs.size() + 1] range-guard counters of the packed producers (last: the head conv); evr_model_saturation
     int64_t frame = 0;
     double flops = 0.0;
     HeadArgs head;
@@ -137,7 +139,7 @@ struct evr_model {
 
     ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
                    if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
-                   if (d_head_wfrag) (void)hipFree(d_head_wfrag);
+                   if (d_head_wfrag) (void)hipFree(d_head_wfrag); if (d_sat) (void)hipFree(d_sat);
                    for (auto& pr : et_ln) { (void)hipFree(pr.first); (void)hipFree(pr.second); }
                    for (float* q : sp_seg_dw) (void)hipFree(q); for (float* q : sp_seg_db) (void)hipFree(q); if (d_sp_pred_w) (void)hipFree(d_sp_pred_w);
                    if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
@@ -343,17 +345,20 @@ void prep_s2d(Conv& c) {
 int finish_conv(evr_model* m, Conv& c) {
     int rc;
     // arithmetic mode: split (f16 + MX-fp8 corrections, conv.h) for the 32-channel-chunk convolutions unless EVR_FP32=1
-    c.x3 = (c.kc == 32) && use_split_mode();
+    c.x3 = (c.kc == 32) ? arith_mode() : 0;
     if (c.x3 && c.k == 5 && c.stride == 2 && !c.transposed && c.cin1 == 0 && c.n_gemm % 64 == 0 && 25 * (c.cin0 / 32) < BAND_PROG_MAX - 2) {
         prep_s2d(c);
-        const int e2 = pack_split_weights(c.w2);      // (the same values rearranged: the same exponent as c.w below)
+        const int e2 = pack_weights_for(c.x3, c.w2);      // (the same values rearranged: the same exponent as c.w below)
         std::vector<float> probe(c.w);
-        EVR_REQUIRE(pack_split_weights(probe) == e2, "conv %s: the two weight layouts disagree on the fp8 exponent", c.name.c_str());
+        EVR_REQUIRE(pack_weights_for(c.x3, probe) == e2, "conv %s: the two weight layouts disagree on the packing exponent", c.name.c_str());
         if ((rc = upload(c.w2, &c.d_w2))) return rc;
         EVR_HIP(hipMalloc((void**)&c.d_prog, c.prog.size() * sizeof(unsigned)));
         EVR_HIP(hipMemcpy(c.d_prog, c.prog.data(), c.prog.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
-    if (c.x3) c.mx_e = pack_split_weights(c.w);
+    if (c.x3) c.mx_e = pack_weights_for(c.x3, c.w);
+    // mode 3 accumulates products scaled by 2^(e_w + H2_ACT_EXP): the accumulators start at the bias in that scale (exact:
+    // a power of two) and the epilogue multiplies by ConvArgs::acc_scale
+    if (c.x3 == 3) for (float& b : c.b) b = std::ldexp(b, c.mx_e + H2_ACT_EXP);
     if ((rc = upload(c.w, &c.d_w))) return rc;
     if ((rc = upload(c.b, &c.d_b))) return rc;
     m->convs.push_back(std::move(c));
@@ -463,7 +468,7 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
     if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
-    if (use_split_mode() && B == 5 && k == 5 && C == 32) {
+    if (arith_mode() == 2 && B == 5 && k == 5 && C == 32) {
         std::vector<unsigned> wf;
         head_pack_wfrag(m->head_w.data(), B, wf);
         EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -619,7 +624,7 @@ int build_spade(evr_model* m) {
         }
         if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
         if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
-        if (use_split_mode()) {
+        if (arith_mode() == 2) {
             std::vector<unsigned> wf;
             head_pack_wfrag(m->head_w.data(), 5, wf);
             EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -799,9 +804,11 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.wgt = c.d_w; a.bias = c.d_b; a.cout = c.n_gemm; a.n_valid = c.n_valid;
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
-        a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3 ? 1 : 0;
+        a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3;
+        a.acc_scale = (c.x3 == 3) ? std::ldexp(1.0f, -(c.mx_e + H2_ACT_EXP)) : 1.0f;
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
+        a.sat = m->d_sat ? m->d_sat + ci : nullptr;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;
         if (const char* e = getenv("EVR_ABLATE")) a.debug_ablate = (c.epi == EPI_LSTM || getenv("EVR_ABLATE_ALL")) ? atoi(e) : 0;
@@ -847,12 +854,12 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
     const bool lstm = d.recurrent_block == EVR_REC_CONVLSTM;
     int rc;
-    const bool P = m->packed;   // every tensor that feeds a matrix-core convolution is PACKED in split mode
+    const int P = m->packed ? m->fmt : 0;   // every tensor that feeds a matrix-core convolution is PACKED (1) / H2 (2) in the split modes
     DevTensor head;
     if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = P ? m->d_head_wfrag : nullptr;      // matrix-core head conv in split-bf16 mode
+    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;      // matrix-core head conv in split-bf16 mode
 
     // x[p]: current activation pointer per parity
     const float* x[2] = {head.p, head.p};
@@ -1085,7 +1092,7 @@ int plan_firenet(evr_model* m, hipStream_t stream) {
 
 int plan_spade(evr_model* m, hipStream_t stream) {
     const int n = m->n_seq, hp = m->hp, wp = m->wp;
-    const bool P = m->packed;
+    const int P = m->packed ? m->fmt : 0;
     int rc;
     EVR_REQUIRE(hp % 4 == 0 && wp % 4 == 0, "SPADE-E2VID: padded size %dx%d not a multiple of 4", wp, hp);
     DevTensor xpad, xorg, xorgh, head;
@@ -1096,7 +1103,7 @@ int plan_spade(evr_model* m, hipStream_t stream) {
     m->sp_xpad = xpad.p; m->sp_xorg = xorg.p; m->sp_xorg_half = xorgh.p;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
+    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;
 
     const float* x[2] = {head.p, head.p};
     int h = hp, w = wp;
@@ -1222,14 +1229,14 @@ int plan_spade(evr_model* m, hipStream_t stream) {
 
 int plan_etnet(evr_model* m, hipStream_t stream) {
     const int n = m->n_seq, hp = m->hp, wp = m->wp;
-    const bool P = m->packed;
+    const int P = m->packed ? m->fmt : 0;
     int rc;
     EVR_REQUIRE(hp % 8 == 0 && wp % 8 == 0, "ET-Net: padded size %dx%d not a multiple of 8", wp, hp);
     DevTensor head;
     if ((rc = alloc(m, &head, n, hp, wp, 32, stream, P))) return rc;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
+    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;
     const float* x[2] = {head.p, head.p};
     int h = hp, w = wp;
     DevTensor blk[3][2];
@@ -1286,7 +1293,7 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
     if ((rc = tok(&QKV, 768, false))) return rc; if ((rc = tok(&CQ, 256, false))) return rc; if ((rc = tok(&CKV, 512, false))) return rc;
     if ((rc = tok(&AO, 256, P))) return rc; if ((rc = tok(&FF, 1024, P))) return rc; if ((rc = tok(&SP, 256, false))) return rc;
 
-    auto ln = [&](int idx, const float* in, float* out, bool out_packed) {
+    auto ln = [&](int idx, const float* in, float* out, int out_packed) {
         Step s; s.kind = ST_LN; s.conv = idx; s.a[0] = s.a[1] = in; s.out = out; s.out_packed = out_packed; m->steps.push_back(s);
     };
     // linear layer = 1x1 conv over [n, L, 1, C]: in (PACKED when P) -> out [+ post_add]
@@ -1368,7 +1375,7 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
     name2(m, "hs_trans", hm, hm);
     // ---- UpsampleConv decoders with skip sums (u_trans.py:116-117) ----
     const float* y[2] = {hm.p, hm.p};
-    bool ypk = P;
+    int ypk = P;
     h = th; w = tw;
     for (int i = 0; i < 3; ++i) {
         const int cin = 256 >> i, cout = 128 >> i;
@@ -1418,6 +1425,8 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
     else { set_error("evr_model_create: unknown arch %d", desc->arch); rc = EVR_ERR_UNSUPPORTED; }
     m->sd.clear();   // host pointers are only valid during this call
     if (rc) { delete m; return rc; }
+    if (hipMalloc((void**)&m->d_sat, (m->convs.size() + 1) * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(m->d_sat, 0, (m->convs.size() + 1) * sizeof(unsigned)) != hipSuccess) { delete m; set_error("evr_model_create: counter allocation failed"); return EVR_ERR_HIP; }
     *out = m;
     return EVR_OK;
 }
@@ -1439,7 +1448,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     EVR_HIP(hipStreamSynchronize(stream));
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
-    m->packed = false;
+    m->packed = false; m->fmt = packed_fmt(arith_mode());
     if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID || m->desc.arch == EVR_ARCH_ETNET) {
         m->packed = true;
         for (const auto& c : m->convs) if (!c.x3) m->packed = false;
@@ -1456,6 +1465,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->head.n = n_seq; m->head.B = m->desc.num_bins; m->head.H = H; m->head.W = W; m->head.hp = m->hp; m->head.wp = m->wp;
     m->head.pad_top = m->pad_top; m->head.pad_left = m->pad_left; m->head.k = m->desc.kernel_size;
     m->head.cout = m->desc.base_num_channels; m->head.wgt = m->d_head_w; m->head.bias = m->d_head_b; m->head.relu = 1;
+    m->head.sat = m->d_sat ? m->d_sat + m->convs.size() : nullptr;
     const bool spade = m->desc.arch == EVR_ARCH_SPADE_E2VID;
     if (spade) {      // the head convolution reads the explicit padded copy (spade.hip): no padding of its own
         m->head.H = m->hp; m->head.W = m->wp; m->head.pad_top = 0; m->head.pad_left = 0;
@@ -1523,7 +1533,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 if ((rc = launch_head_conv(m->ctxconv, stream))) return rc;
                 break;
             case ST_TOPACKED:
-                if ((rc = launch_to_packed(s.out, s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream))) return rc;
+                if ((rc = launch_to_packed(s.out, s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream, m->fmt))) return rc;
                 break;
             case ST_DYN:
                 if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
@@ -1579,10 +1589,28 @@ extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst,
     if (n_out) *n_out = t.numel();
     if (!dst) return EVR_OK;
     EVR_REQUIRE(dst_elems >= t.numel(), "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)t.numel());
-    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, t.packed ? 1 : 0, (hipStream_t)stream);
+    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, t.packed ? m->fmt : 0, (hipStream_t)stream);
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }
+
+// Range guard of the packed activation formats (packed.h sat_note): how many output runs (4 or 16 channels of one pixel)
+// of the matrix-core producers left the format's exact range since the counters were last cleared, and in which layer most.
+// PACKED (default arithmetic) keeps only the f16 half of such values (2^-12 relative); H2 (EVR_ARITH=h3) CLAMPS them at
+// +-4094.  Synchronises the stream.  Zero means the arithmetic's error analysis held for every frame so far.
+extern "C" int evr_model_saturation(evr_model* m, int64_t* runs_host, char* worst_layer, size_t worst_len, int clear, evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    EVR_REQUIRE(m && runs_host, "evr_model_saturation: null argument");
+    std::vector<unsigned> h(m->convs.size() + 1, 0u);
+    EVR_HIP(hipMemcpyAsync(h.data(), m->d_sat, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    if (clear) EVR_HIP(hipMemsetAsync(m->d_sat, 0, h.size() * sizeof(unsigned), stream));
+    EVR_HIP(hipStreamSynchronize(stream));
+    int64_t total = 0; size_t worst = 0;
+    for (size_t i = 0; i < h.size(); ++i) { total += h[i]; if (h[i] > h[worst]) worst = i; }
+    *runs_host = total;
+    if (worst_layer && worst_len) snprintf(worst_layer, worst_len, "%s", total == 0 ? "" : (worst < m->convs.size() ? m->convs[worst].name.c_str() : "head"));
+    return EVR_OK;
+}
 
 extern "C" int evr_model_profile_enable(evr_model* m, const char* filter) {
     EVR_REQUIRE(m != nullptr, "evr_model_profile_enable: null model");
@@ -1631,7 +1659,7 @@ extern "C" int evr_split_pack(const float* src, float* dst, int64_t n) {
 // the device codec (packed.h through to_packed_kernel): src/dst device pointers, dst may equal src
 extern "C" int evr_split_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream) {
     EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_pack_device: n = %lld must be a multiple of 16", (long long)n);
-    return launch_to_packed(src, dst, n, (hipStream_t)stream);
+    return launch_to_packed(src, dst, n, (hipStream_t)stream, 1);
 }
 
 extern "C" int evr_split_unpack(const float* src, float* dst, int64_t n) {

@@ -55,6 +55,62 @@ __device__ __forceinline__ void store4_packed(float* p, unsigned row_off, int c4
     unsigned* q = (unsigned*)(p + pk_lo_off(row_off, c4));
     q[0] = lo8; q[4] = x8;
 }
+// ---- the second PACKED format, "H2" (conv.h): per 16 channels 16 f16 'hi' | 16 f16 'lo' of x * 2^H2_ACT_EXP -------------
+// hi = RNE_f16(x 2^a) (saturating), lo = RNE_f16(x 2^a - hi): 22 significant bits -- the fp32-grade arithmetic mode (three
+// f16 products per term, conv.hip).  A 4-channel run is an 8-B hi piece and an 8-B lo piece 32 B further on.
+constexpr float H2_SCALE = 16.0f, H2_INV = 1.0f / 16.0f;               // 2^H2_ACT_EXP (conv.h)
+__device__ __forceinline__ f4 unpack4_h2(uint2 hi, uint2 lo) {
+    const h2_t a0 = __builtin_bit_cast(h2_t, hi.x), a1 = __builtin_bit_cast(h2_t, hi.y);
+    const h2_t b0 = __builtin_bit_cast(h2_t, lo.x), b1 = __builtin_bit_cast(h2_t, lo.y);
+    f4 v;
+    v[0] = ((float)a0[0] + (float)b0[0]) * H2_INV; v[1] = ((float)a0[1] + (float)b0[1]) * H2_INV;
+    v[2] = ((float)a1[0] + (float)b1[0]) * H2_INV; v[3] = ((float)a1[1] + (float)b1[1]) * H2_INV;
+    return v;
+}
+__device__ __forceinline__ void pack4_h2(f4 v, uint2& hi, uint2& lo) {
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_fmed3f(v[j] * H2_SCALE, -65504.0f, 65504.0f);
+    const h2_t h0 = {(_Float16)c[0], (_Float16)c[1]}, h1 = {(_Float16)c[2], (_Float16)c[3]};
+    const h2_t l0 = {(_Float16)(c[0] - (float)h0[0]), (_Float16)(c[1] - (float)h0[1])};
+    const h2_t l1 = {(_Float16)(c[2] - (float)h1[0]), (_Float16)(c[3] - (float)h1[1])};
+    hi.x = __builtin_bit_cast(unsigned, h0); hi.y = __builtin_bit_cast(unsigned, h1);
+    lo.x = __builtin_bit_cast(unsigned, l0); lo.y = __builtin_bit_cast(unsigned, l1);
+}
+__device__ __forceinline__ f4 load4_h2(const float* p, unsigned row_off, int c4) {
+    const float* q = p + pk_off(row_off, c4);
+    return unpack4_h2(*(const uint2*)q, *(const uint2*)(q + 8));
+}
+__device__ __forceinline__ void store4_h2(float* p, unsigned row_off, int c4, f4 v) {
+    uint2 hi, lo;
+    pack4_h2(v, hi, lo);
+    float* q = p + pk_off(row_off, c4);
+    *(uint2*)q = hi; *(uint2*)(q + 8) = lo;
+}
+// Range guard of the packed formats.  PACKED: the fp8 residual lo8 = (x - hi) 2^12 saturates from |x| >= 256 on (and the fp8
+// copy x8 at 448): beyond that a value keeps only its f16 half (2^-12 relative).  H2: x 2^4 saturates at +-65504, i.e.
+// |x| > 4094 is CLAMPED.  Producers count the 4- / 16-channel runs that cross the limit in a per-layer counter
+// (evr_model_saturation); the test is a handful of v_max per run and the atomic fires only when it trips.
+template <int FMT> __device__ __forceinline__ void sat_note(unsigned* sat, float mx) {
+    constexpr float LIM = (FMT == 2) ? 65504.0f / H2_SCALE : 256.0f;
+    if (sat && mx > LIM) atomicAdd(sat, 1u);
+}
+template <int FMT> __device__ __forceinline__ void sat_check4(unsigned* sat, f4 v) {
+    sat_note<FMT>(sat, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+}
+template <int FMT> __device__ __forceinline__ void sat_check16(unsigned* sat, const float (&w)[16]) {
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, fabsf(w[k]));
+    sat_note<FMT>(sat, mx);
+}
+// compile-time format selection for the matrix-core kernels (FMT: 1 = the f16 | fp8 | fp8 format above, 2 = H2)
+template <int FMT> __device__ __forceinline__ f4 load4_fmt(const float* p, unsigned row_off, int c4) {
+    if constexpr (FMT == 2) return load4_h2(p, row_off, c4); else return load4_packed(p, row_off, c4);
+}
+template <int FMT> __device__ __forceinline__ void store4_fmt(float* p, unsigned row_off, int c4, f4 v) {
+    if constexpr (FMT == 2) store4_h2(p, row_off, c4, v); else store4_packed(p, row_off, c4, v);
+}
 // ---- whole-group stores from the MFMA accumulator layout ----------------------------------------------------------
 // A lane of the 32x32 MFMA result holds, of a 32-channel block, v[4q + j] = channel 8q + 4h + j (h = lane >> 5, lanes l
 // and l ^ 32 = the two halves of one pixel).  xchg16 trades two 4-runs with the partner (v_permlane32_swap) so that the
@@ -96,6 +152,41 @@ __device__ __forceinline__ void store16_packed(float* p, unsigned row_off, int c
     u4* q = (u4*)(p + row_off + (unsigned)cg);
     q[0] = hi0; q[1] = hi1; q[2] = lo; q[3] = x8;
 }
+// H2 twins of store16_packed / unpack16_xchg: the group is hi 8 dwords | lo 8 dwords
+__device__ __forceinline__ void store16_h2(float* p, unsigned row_off, int cg, const float (&w)[16]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 hi0, hi1, lo0, lo1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float c0 = __builtin_amdgcn_fmed3f(w[2 * k] * H2_SCALE, -65504.0f, 65504.0f), c1 = __builtin_amdgcn_fmed3f(w[2 * k + 1] * H2_SCALE, -65504.0f, 65504.0f);
+        const float d0 = __builtin_amdgcn_fmed3f(w[8 + 2 * k] * H2_SCALE, -65504.0f, 65504.0f), d1 = __builtin_amdgcn_fmed3f(w[8 + 2 * k + 1] * H2_SCALE, -65504.0f, 65504.0f);
+        const h2_t a = {(_Float16)c0, (_Float16)c1}, b = {(_Float16)d0, (_Float16)d1};
+        const h2_t al = {(_Float16)(c0 - (float)a[0]), (_Float16)(c1 - (float)a[1])}, bl = {(_Float16)(d0 - (float)b[0]), (_Float16)(d1 - (float)b[1])};
+        hi0[k] = __builtin_bit_cast(unsigned, a); hi1[k] = __builtin_bit_cast(unsigned, b);
+        lo0[k] = __builtin_bit_cast(unsigned, al); lo1[k] = __builtin_bit_cast(unsigned, bl);
+    }
+    u4* q = (u4*)(p + row_off + (unsigned)cg);
+    q[0] = hi0; q[1] = hi1; q[2] = lo0; q[3] = lo1;
+}
+__device__ __forceinline__ void unpack16_xchg_h2(const unsigned (&g)[16], f32x16_t& v) {
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {      // dword d = channels 2d, 2d + 1 (hi in g[d], lo in g[8 + d])
+        const h2_t hh = __builtin_bit_cast(h2_t, g[d]), ll = __builtin_bit_cast(h2_t, g[8 + d]);
+        w[2 * d] = ((float)hh[0] + (float)ll[0]) * H2_INV;
+        w[2 * d + 1] = ((float)hh[1] + (float)ll[1]) * H2_INV;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[j]), __float_as_uint(w[4 + j]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[8 + j]), __float_as_uint(w[12 + j]), false, false);
+        v[j] = __uint_as_float(a[0]); v[8 + j] = __uint_as_float(a[1]);
+        v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
+    }
+}
+template <int FMT> __device__ __forceinline__ void store16_fmt(float* p, unsigned row_off, int cg, const float (&w)[16]) {
+    if constexpr (FMT == 2) store16_h2(p, row_off, cg, w); else store16_packed(p, row_off, cg, w);
+}
 // the reverse: one PACKED group as loaded (hi 8 dwords | lo8 4 dwords) -> its 16 values -> the accumulator order of the
 // lane pair (the same swaps: v_permlane32_swap is its own inverse on a register pair)
 __device__ __forceinline__ void unpack16_xchg(const unsigned (&g)[12], f32x16_t& v) {
@@ -117,23 +208,26 @@ __device__ __forceinline__ void unpack16_xchg(const unsigned (&g)[12], f32x16_t&
         v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
     }
 }
-// one channel of a PACKED pixel row
-__device__ __forceinline__ float load1_packed(const float* row, int ch) {
+// one channel of a PACKED pixel row (fmt: 1 = f16 | fp8 | fp8, 2 = H2)
+__device__ __forceinline__ float load1_packed(const float* row, int ch, int fmt = 1) {
     const unsigned char* g = (const unsigned char*)(row + (ch & ~15));
     const int k = ch & 15;
+    if (fmt == 2) return ((float)((const _Float16*)g)[k] + (float)((const _Float16*)g)[16 + k]) * H2_INV;
     return fmaf(__builtin_amdgcn_cvt_f32_fp8((int)g[32 + k], 0), PK_LO_INV, (float)((const _Float16*)g)[k]);
 }
 #endif
 
-// 4 consecutive channels (c4 % 4 == 0) of the pixel row at `row`, PLAIN or PACKED
+// 4 consecutive channels (c4 % 4 == 0) of the pixel row at `row`: packed = 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2
 __device__ __forceinline__ float4 ld4_any(const float* row, int c4, int packed) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (packed == 2) { const f4 t = load4_h2(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
     if (packed) { const f4 t = load4_packed(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
 #endif
     return *(const float4*)(row + c4);
 }
 __device__ __forceinline__ void st4_any(float* row, int c4, float4 v, int packed) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (packed == 2) { const f4 t = {v.x, v.y, v.z, v.w}; store4_h2(row, 0u, c4, t); return; }
     if (packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(row, 0u, c4, t); return; }
 #endif
     *(float4*)(row + c4) = v;

@@ -210,6 +210,8 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
             tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
     tracker.finalize(idx)
     ds.raise_if_dropped()       # once per sequence: out-of-sensor events the kernel dropped (the reference raises)
+    if hasattr(model, 'warn_if_saturated'):
+        model.warn_if_saturated(sequence['name'])
     if bad is not None:
         raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
             int(tb['idx0'][bad]), int(tb['idx1'][bad]), ds.num_events))
@@ -270,6 +272,8 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     for j in range(S):
         trackers[j].finalize(plans[j][2])
         out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
+    if hasattr(model, 'warn_if_saturated'):
+        model.warn_if_saturated(', '.join(q['name'] for q in sequences))
     for j in range(S):      # the reference raises inside the sequence loop: same message, after the files are written
         dss[j].raise_if_dropped()
         bad = plans[j][1]

@@ -34,6 +34,8 @@ SYMBOLS = {
     'evr_last_error': (c_char_p, []),
     'evr_version': (c_int, []),
     'evr_device_info': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_size_t]),
+    'evr_stream_create_cu_masked': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'evr_stream_destroy': (c_int, [c_void_p]),
     'evr_voxelize_workspace_bytes': (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     'evr_voxelize': (c_int, [c_void_p] * 5 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
@@ -52,6 +54,7 @@ SYMBOLS = {
     'evr_model_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p]),
     'evr_model_read_tensor': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     'evr_model_flops_per_step': (c_double, [c_void_p]),
+    'evr_model_saturation': (c_int, [c_void_p, ctypes.POINTER(c_int64), c_char_p, c_size_t, c_int, c_void_p]),
     'evr_model_profile_enable': (c_int, [c_void_p, c_char_p]),
     'evr_model_profile_read': (c_int, [c_void_p, c_int, c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                        ctypes.POINTER(c_int64), ctypes.POINTER(c_int), c_void_p]),

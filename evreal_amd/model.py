@@ -146,6 +146,27 @@ class _HipModel:
             out.append(dict(name=nm, ms=ms[i], flops_per_launch=fl[i], launches=ln[i]))
         return out
 
+    def saturation(self, clear=False):
+        """(runs, layer): output runs of the matrix-core layers that left the packed activation format's exact range since
+        the counters were cleared, and the layer with most of them ('' when zero).  Synchronises."""
+        n = ctypes.c_int64(0)
+        name = ctypes.create_string_buffer(64)
+        _lib.check(self.lib.evr_model_saturation(self.handle, ctypes.byref(n), name, 64, 1 if clear else 0, _lib.stream_ptr()),
+                   'evr_model_saturation')
+        return n.value, name.value.decode()
+
+    def warn_if_saturated(self, what=''):
+        """Once per sequence (eval loops): report activations beyond the split format's range instead of degrading silently."""
+        n, layer = self.saturation(clear=True)
+        if n:
+            import os
+            mode = os.environ.get('EVR_ARITH', 'mx') if not os.environ.get('EVR_FP32') else 'fp32'
+            print(f"WARNING: {n} activation runs{(' of ' + what) if what else ''} left the exact range of the '{mode}' packed "
+                  f"format (most in layer '{layer}'): those values kept reduced precision"
+                  + (" (clamped at +-4094)" if mode == 'h3' else " (f16 only, 2^-12 relative)")
+                  + "; rerun with EVR_ARITH=h3 or EVR_FP32=1 for data of this magnitude")
+        return n
+
     def flops_per_step(self):
         return float(self.lib.evr_model_flops_per_step(self.handle))
 

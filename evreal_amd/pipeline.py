@@ -34,12 +34,26 @@ class HotPath:
         self.overlap = bool(overlap)
         if self.overlap:
             self.imgs = [self.img, torch.empty_like(self.img)]
-            self.side = torch.cuda.Stream(device=self.dev)
+            self.side = self._side_stream()
             self.ev_model = [torch.cuda.Event(), torch.cuda.Event()]     # image k is complete (main stream)
             self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
             self.k = 0
         self._vox_events = None
         model.reset_states()
+
+    def _side_stream(self):
+        """The evaluation stream.  EVR_SIDE_CUS=n restricts it to n compute units spread over the XCDs
+        (hipExtStreamCreateWithCUMask through the C ABI); unset / 0: an ordinary stream."""
+        import ctypes, os
+        n = int(os.environ.get('EVR_SIDE_CUS', '0') or 0)
+        if n <= 0:
+            return torch.cuda.Stream(device=self.dev)
+        h = ctypes.c_void_p()
+        lib = _lib.load()
+        _lib.check(lib.evr_stream_create_cu_masked(self.dev.index or 0, n, int(os.environ.get('EVR_SIDE_TOP', '1')), ctypes.byref(h)),
+                   'evr_stream_create_cu_masked')
+        self._side_handle = h
+        return torch.cuda.ExternalStream(h.value, device=self.dev)
 
     def time_voxelizer(self, on):
         """on=True: bracket the tensorizer launches of every following step with HIP events on the stream they are

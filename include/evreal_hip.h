@@ -41,6 +41,11 @@ const char* evr_last_error(void);
 int evr_version(void);
 /* Device facts used by bench.py's roofline block: CU count, clock (MHz), name. */
 int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_t name_len);
+/* A stream restricted to n_cus compute units spread evenly over the XCDs (from_top: the highest-numbered CUs of each XCD
+ * instead of the lowest).  The reference is single-stream (eval.py:227: one synchronize per frame); evreal_amd runs the
+ * evaluation half of a frame (eval.py:234-238) on such a stream beside the next frame's reconstruction. */
+int evr_stream_create_cu_masked(int device, int n_cus, int from_top, evr_stream_t* out);
+int evr_stream_destroy(evr_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Events -> voxel grid.  Replaces utils/event_utils.py:27-59 (events_to_voxel_torch) and :4-24
@@ -166,6 +171,12 @@ int evr_model_read_tensor(evr_model* m, const char* name, float* dst, int64_t ds
                           int64_t* n_out, evr_stream_t stream);
 /* Direct-convolution FLOPs (2*MAC) of one evr_model_step at the current shape. */
 double evr_model_flops_per_step(const evr_model* m);
+/* Range guard of the packed activation formats the split arithmetic modes store between layers: number of output runs
+ * (4 or 16 channels of one pixel) that left the format's exact range since the last clear, and the layer with most of them
+ * (name copied into worst_layer).  0 = every frame so far stayed inside the arithmetic's error analysis; otherwise rerun
+ * with EVR_ARITH=h3 (fp32-grade, range +-4094) or EVR_FP32=1.  The reference runs fp32 (model/submodules.py:227-245) and
+ * has no such limit.  Synchronises the stream. */
+int evr_model_saturation(evr_model* model, int64_t* runs_host, char* worst_layer, size_t worst_len, int clear, evr_stream_t stream);
 /* Per-layer timing for the roofline block of bench.py.  While enabled, evr_model_step brackets every
  * convolution launch whose layer name contains `filter` ("" = all layers) with HIP events on the launch
  * stream; filter == NULL disables.  evr_model_profile_read synchronises the stream, then returns per

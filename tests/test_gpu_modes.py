@@ -4,6 +4,8 @@
   takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here, once with the
   128 x 128-tile kernel for every layer (EVR_WIDE=0) and once with the 256 x 256-tile ConvLSTM kernel (EVR_WIDE_MIN=1).
 * EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split (f16 + MX-fp8) / PACKED.
+* EVR_ARITH=h3    -- the fp32-grade split mode: three f16 products per term on H2 tensors (csrc/conv.h); the whole suite again
+                     with the image gate tightened from 1e-4 to 1e-5.
 The switches are read when the library plans its launches, hence one fresh interpreter per mode.
 """
 import os
@@ -40,6 +42,23 @@ def test_parity_with_twin_band_kernel_on_small_shapes():
 
 def test_parity_in_exact_fp32_mode():
     _run({'EVR_FP32': '1'})
+
+
+def test_parity_in_fp32_equivalent_mode():
+    _run({'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5'})
+
+
+def test_parity_in_fp32_equivalent_mode_on_the_band_kernels():
+    _run({'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
+
+
+def test_drift_100_frames_in_fp32_equivalent_mode():
+    """100 frames x 8 sequences at 346x260 in the three-f16-product mode, gate 1e-5 per pixel (measured 2.4e-7: the level
+    of the exact-fp32 mode's own summation-order difference from the CPU oracle)."""
+    env = dict(os.environ, EVR_ARITH='h3', EVR_TEST_IMG_ATOL='1e-5', EVR_WIDE_MIN='1')
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
 
 
 def test_drift_100_frames_with_wide_band_kernel():
