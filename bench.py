@@ -2,7 +2,7 @@
 """Headline benchmark: reconstructed frames/s (+ Mevents/s voxelized) of the E2VID hot path at 346x260,
 5 bins, 15k events/window on MI355X (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-seq S] [--sensor WxH]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-seq S] [--sensor WxH] [--config NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,21 +10,34 @@
 torch.distributed.run, one process per GPU, RCCL); under a launcher the flag must equal WORLD_SIZE.
 
 A step = one frame for each of S independent synthetic sequences per GPU (sequences shard across GPUs,
-SURVEY 8e): raw events (resident in HBM) -> voxel grid -> event-tensor normalization -> pad -> E2VID
-forward (split f16 + MX-fp8 MFMA, fp32 accumulate; EVR_FP32=1: exact fp32 MFMA) -> crop -> robust percentile
-normalization -> clip -> MSE + SSIM + LPIPS against the reference frame (LPIPS = AlexNet v0.1 structure on
-synthetic weights unless EVREAL_LPIPS_WEIGHTS names a real state_dict: they cannot be downloaded here).
-The evaluation half of a frame (robust norm, MSE/SSIM, LPIPS) runs on a second HIP stream and overlaps the
-reconstruction of the next frame (`--no-overlap`: one stream); all of a step's work is inside the timed region.
+SURVEY 8e): raw events (resident in HBM) -> voxel grid -> [event-tensor normalization] -> pad -> network forward
+-> crop -> [robust percentile normalization] -> clip -> MSE + SSIM + LPIPS against the reference frame (LPIPS =
+AlexNet v0.1 structure on synthetic weights unless EVREAL_LPIPS_WEIGHTS names a real state_dict: they cannot be
+downloaded here).  The evaluation half of a frame runs on a second HIP stream and overlaps the reconstruction of
+the next frame (`--no-overlap`: one stream); all of a step's work is inside the timed region.
 
-Rank 0 prints ONE JSON line (contract in the task statement).  Besides `roofline` (dominant kernel: the ConvLSTM gate
-convolutions) and `cpu_baseline` it carries, all measured OUTSIDE the timed region of the same run:
+`--config` selects the workload (BASELINE.json configs 2-5; the default `e2vid` is the configuration the metric is
+quoted on):
+    e2vid    E2VID (BN, transposed decoders, sigmoid), 346x260, 64 sequences, normalization + robust norm
+    firenet  FireNet (the SHIPPED checkpoint, tests/golden/firenet_weights.npz), 240x180, k_events windows, 64 sequences
+    hyper    HyperE2VID layout (dynamic decoder, the reference's Fourier-Bessel table), 346x260, 4 sequences
+    color    ColorNet over the E2VID+ layout, 970x624 (BS-ERGB's 970x625 cropped to even sides: the reference's ColorNet
+             raises on odd sides), 50k events/window, 1 sequence = 5 recurrent streams; no metrics (the reference skips them)
+Arithmetic (csrc/conv.h): default split f16 + MX-fp8 ("mx"); EVR_ARITH=h3 three f16 products, fp32-grade; EVR_FP32=1
+exact fp32 MFMA.
+
+Rank 0 prints ONE JSON line (contract in the task statement).  Besides `roofline` (dominant kernel) and
+`cpu_baseline` it carries, all measured OUTSIDE the timed region of the same run:
   roofline_voxelizer  HIP-event time of the tensorizer launches (in the step and standalone at S and 512 windows)
   score_parity        the first frames of sequence 0 replayed on the GPU and through the CPU oracle: per-frame image
                       error, mean MSE/SSIM/LPIPS of both, relative error, agreement to 3 significant figures
-  fp32_exact          the same steps in a sub-process with EVR_FP32=1 (exact fp32 MFMA arithmetic)
-  sensor_640x480      the same workload on 640x480 streams (north_star's second sensor size), sub-process
-  small_batch         1 and 4 sequences per GPU (the reference's regime is batch 1)
+  fp32_equiv          the same steps in a sub-process with EVR_ARITH=h3 (three f16 products: fp32-grade), with its own parity
+  fp32_exact          ... with EVR_FP32=1 (exact fp32 MFMA arithmetic), with its own parity
+  sensor_640x480      the same workload on 640x480 streams (north_star's second sensor size), with its own parity
+  configs             BASELINE configs 3, 4, 5 (`--config firenet|hyper|color` sub-processes), each with frames/s, dominant
+                      layer + roofline fraction and an oracle comparison
+  eval_cli            the drop-in `evreal_amd.eval.evaluate` on a synthetic dataset tree (8 sequences), images on / off
+  small_batch         1, 4 and 8 sequences per GPU (the reference's regime is batch 1)
   steady_state        >= 2 s of back-to-back steps (the timed region of a 20-step run is 0.25 s)
 """
 import argparse
@@ -42,12 +55,33 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BINS, K_EVENTS = 5, 15000
+BINS = 5
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak (micro-benchmark ceiling 2382)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 / _f16 dense peak (micro-benchmark ceiling 2382)
 PEAK_HBM_GBS = 8000.0             # same guide: HBM3E spec (6.3 TB/s measured with a float4 copy)
 TRAFFIC_SOURCES = ['evreal_amd/csrc/conv.hip', 'evreal_amd/csrc/conv.h', 'evreal_amd/csrc/model.cpp',
                    'evreal_amd/csrc/packed.h']
+OKEYS = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size', 'norm',
+         'use_upsample_conv', 'recurrent_block_type', 'final_activation']
+
+
+def arith_name():
+    if os.environ.get('EVR_FP32') or os.environ.get('EVR_ARITH') == 'fp32':
+        return 'fp32'
+    return 'h3' if os.environ.get('EVR_ARITH') == 'h3' else 'mx'
+
+
+DTYPE = {'mx': 'f16+mxfp8', 'h3': 'f16x3', 'fp32': 'f32'}
+ARITH_TEXT = {
+    'mx': ("split: x = hi + lo8*2^-12, w = hi + wlo8*2^-(e+12) (f16 hi, fp8 e4m3 residuals); per 32 k acc += hi_w*hi_x on 2 x "
+           "v_mfma_f32_32x32x16_f16 + (w8*lo8 + wlo8*x8) on 1 x v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; activations "
+           "stored PACKED (f16 hi | fp8 lo8 | fp8 x8 per 16 channels) by the producer"),
+    'h3': ("three f16 products: x 2^4 = hi + lo, w 2^e = hi + lo (f16 halves: 22 significant bits); per 16 k acc += lo_w*hi_x + "
+           "hi_w*lo_x + hi_w*hi_x on 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (the dropped lo*lo term is 2^-22 of a product); "
+           "activations stored H2 (16 f16 hi | 16 f16 lo per 16 channels) by the producer"),
+    'fp32': "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"}
+# matrix cycles per algorithmic flop relative to one f16 product (what mfma_issue_* reports against the f16 peak)
+ISSUE_FACTOR = {'mx': 2.0, 'h3': 3.0, 'fp32': 1.0}
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -69,11 +103,65 @@ def resolve_world(args_gpus, environ):
     return ('ranked' if int(ws) > 1 else 'inprocess', int(ws))
 
 
-# ------------------------------------------------------------------------------------------------ inputs
-def build_inputs(rank, n_seq, n_steps, device, W_, H_):
-    """Step-major resident event arrays: window (step, seq) = 15k consecutive events of sequence `seq`."""
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One of BASELINE.json's configurations: network (HIP), its CPU oracle, sensor, windowing, pre/post switches."""
+
+    def __init__(self, name, sensor=None):
+        from evreal_amd import model, weights
+        from oracle import model as omod
+        self.name = name
+        self.color = False
+        t = lambda sd: {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        if name == 'e2vid':
+            self.W, self.H, self.n_seq, self.k = 346, 260, 64, 15000
+            kw = dict(weights.E2VID_KWARGS)
+            self.sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
+            self.net = model.E2VIDRecurrent(kw)
+            self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **{k: kw[k] for k in OKEYS})
+            self.norm_in, self.post, self.enc = True, 'robust', kw['num_encoders']
+            self.title = "E2VID (synthetic weights, BN folded)"
+        elif name == 'firenet':
+            self.W, self.H, self.n_seq, self.k = 240, 180, 64, 15000
+            z = np.load(os.path.join(ROOT, 'tests', 'golden', 'firenet_weights.npz'))
+            self.sd = {k: z[k] for k in z.files}
+            self.net = model.FireNet_legacy(unet_kwargs=dict(num_bins=5, recurrent_block_type='convgru', base_num_channels=16,
+                                                             num_residual_blocks=2, kernel_size=3, norm='none'))
+            self.make_oracle = lambda: omod.FireNetLegacyOracle(t(self.sd))
+            self.norm_in, self.post, self.enc = True, 'none', 4          # config/method/FireNet.json; legacy.py:127-130 pads to /16
+            self.title = "FireNet (the shipped checkpoint pretrained/FireNet/model.pth as arrays)"
+        elif name == 'hyper':
+            self.W, self.H, self.n_seq, self.k = 346, 260, 4, 15000
+            z = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2vid_hyper_seq.npz'))
+            kw = json.loads(bytes(z['kwargs']).decode())
+            fixed = {k[6:]: z[k] for k in z.files if k.startswith('fixed.')}       # the reference's Fourier-Bessel table
+            self.sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=24, fixed=fixed)
+            self.net = model.E2VIDRecurrent(kw)
+            okw = {k: kw[k] for k in OKEYS}; okw['use_dynamic_decoder'] = True
+            self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **okw)
+            self.norm_in, self.post, self.enc = False, 'none', kw['num_encoders']   # config/method/HyperE2VID.json
+            self.title = "HyperE2VID layout (dynamic first decoder, synthetic weights + the reference's Fourier-Bessel bases)"
+        elif name == 'color':
+            self.W, self.H, self.n_seq, self.k = 970, 624, 1, 50000
+            kw = dict(weights.E2VID_PLUS_KWARGS)
+            self.sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=2)
+            base = model.E2VIDRecurrent(kw); base.load_state_dict(self.sd)
+            self.base = base
+            self.net = None
+            self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **{k: kw[k] for k in OKEYS})
+            self.norm_in, self.post, self.enc, self.color = False, 'none', kw['num_encoders'], True
+            self.title = "ColorNet over the E2VID+ layout (synthetic weights): 4 Bayer streams at half + 1 grayscale stream at full resolution"
+        else:
+            raise SystemExit(f"bench.py: unknown --config {name}")
+        if sensor is not None:
+            self.W, self.H = sensor
+        if self.net is not None:
+            self.net.load_state_dict(self.sd)
+
+
+def build_inputs(rank, n_seq, n_steps, device, W_, H_, k):
+    """Step-major resident event arrays: window (step, seq) = k consecutive events of sequence `seq`."""
     from evreal_amd import synth
-    k = K_EVENTS
     xy = np.empty((n_steps, n_seq, k, 2), np.int16)
     ts = np.empty((n_steps, n_seq, k), np.float64)
     pol = np.empty((n_steps, n_seq, k), np.uint8)
@@ -90,36 +178,36 @@ def build_inputs(rank, n_seq, n_steps, device, W_, H_):
 
 
 # ------------------------------------------------------------------------------------------------ CPU leg
-def cpu_baseline(host_inputs, sd, kw, n_frames, W_, H_, budget_s=25.0, lpips_sd=None, keep_frames=0):
+def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_frames=0):
     """Oracle ("port") timed on the host cores, batch 1 like the reference: C voxelizer (1 thread) + numpy
-    normalization + torch-CPU E2VID forward + numpy percentile + MSE + scipy SSIM + torch-CPU LPIPS.  BOUNDED: the torch
+    normalization + torch-CPU forward + numpy percentile + MSE + scipy SSIM + torch-CPU LPIPS.  BOUNDED: the torch
     thread count is the faster of {8, 32} (capped by the core count; all 256 threads of the GPU box's host run this
     batch-1 network ~100x slower), then sequence 0 runs from a state reset, window 0 onwards, until `n_frames` or
     ~`budget_s` seconds are used.  The first `keep_frames` frames' images and scores are returned for score_parity."""
     import ctypes
-    from oracle import model as omod, prepost as op, metrics as omet, lpips as olp
+    from oracle import prepost as op, metrics as omet, lpips as olp
     from evreal_amd import synth
     xy, ts, pol, refs = host_inputs
+    W_, H_, k = wl.W, wl.H, wl.k
     lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'liboracle.so'))
-    okw = {k: kw[k] for k in ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size',
-                              'norm', 'use_upsample_conv', 'recurrent_block_type', 'final_activation']}
-    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **okw)
-    crop = op.CropParams(W_, H_, kw['num_encoders'])
-    offs = np.array([0, K_EVENTS], dtype=np.int64)
+    o = wl.make_oracle()
+    crop = op.CropParams(W_, H_, wl.enc)
+    offs = np.array([0, k], dtype=np.int64)
     out = np.empty((1, BINS, H_, W_), np.float32)
     f = lambda a: a.ctypes.data_as(ctypes.c_void_p)
 
     def frame(w, keep=None):
         t0 = time.perf_counter()
-        xs, ys, tf, ps = synth.window_events_f32(ts[w, 0], xy[w, 0], pol[w, 0], 0, K_EVENTS)
+        xs, ys, tf, ps = synth.window_events_f32(ts[w, 0], xy[w, 0], pol[w, 0], 0, k)
         lib.oracle_voxelize(f(xs), f(ys), f(tf), f(ps), f(offs), 1, BINS, H_, W_, f(out))
         t1 = time.perf_counter()
-        v = op.normalize_event_tensor(out)
+        v = op.normalize_event_tensor(out) if wl.norm_in else out
         t2 = time.perf_counter()
         with torch.no_grad():
             img = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())[0, 0]
         t3 = time.perf_counter()
-        img = op.post_process_normalization(img, 'robust')
+        if wl.post != 'none':
+            img = op.post_process_normalization(img, wl.post)
         t4 = time.perf_counter()
         a, b = omet.clip01(img), omet.clip01(refs[0])
         sc = [omet.mse(a, b), omet.ssim(a, b)]
@@ -144,15 +232,15 @@ def cpu_baseline(host_inputs, sd, kw, n_frames, W_, H_, budget_s=25.0, lpips_sd=
     times = {'voxel': 0.0, 'norm': 0.0, 'forward': 0.0, 'post': 0.0, 'metrics': 0.0}
     kept, done = [], 0
     while done < max(n_frames, keep_frames) and (done < keep_frames or (time.perf_counter() - t_start) < budget_s):
-        for k, dt in zip(times, frame(done % xy.shape[0], kept if done < keep_frames else None)):
-            times[k] += dt
+        for kk, dt in zip(times, frame(done % xy.shape[0], kept if done < keep_frames else None)):
+            times[kk] += dt
         done += 1
     total = sum(times.values())
     res = {"value": round(done / total, 3), "unit": "frames/s", "cores": best, "kind": "port",
-           "sample": f"{done} frames of one {W_}x{H_} sequence, batch 1, E2VID forward on {best} torch threads of the "
+           "sample": f"{done} frames of one {W_}x{H_} sequence, batch 1, {wl.name} forward on {best} torch threads of the "
                      f"{os.cpu_count()}-core host (C voxelizer and numpy/scipy stages 1 thread), torch {torch.__version__}",
-           "ms_per_frame": {k: round(1e3 * v / max(done, 1), 3) for k, v in times.items()},
-           "mevents_per_s_voxelizer": round(K_EVENTS * done / max(times['voxel'], 1e-9) / 1e6, 2)}
+           "ms_per_frame": {kk: round(1e3 * v / max(done, 1), 3) for kk, v in times.items()},
+           "mevents_per_s_voxelizer": round(k * done / max(times['voxel'], 1e-9) / 1e6, 2)}
     return res, kept
 
 
@@ -160,14 +248,14 @@ def sig3(x):
     return float(f"{x:.3g}")
 
 
-def score_parity(gpu_frames, cpu_frames, names):
+def score_parity(gpu_frames, cpu_frames, names, gate=1e-4):
     """gpu_frames / cpu_frames: [(image [H,W], [scores...])] for the same windows of sequence 0."""
     n = min(len(gpu_frames), len(cpu_frames))
     if n == 0:
         return None
     img_err = [float(np.abs(gpu_frames[i][0] - cpu_frames[i][0]).max()) for i in range(n)]
     out = {"frames": n, "sequence": 0, "image_max_abs_err": max(img_err), "image_max_abs_err_per_frame_max5": sorted(img_err)[-5:],
-           "image_gate_1e-4": bool(max(img_err) < 1e-4),
+           "image_gate": gate, "image_gate_ok": bool(max(img_err) < gate),
            "oracle": "oracle/ (torch-CPU fp32 restatement pinned against the reference classes; MSE/SSIM/LPIPS arithmetic "
                      "restated from scikit-image / pyiqa: parity unpinned, see DESIGN.md section 3)"}
     ok = True
@@ -232,21 +320,196 @@ def time_launches(fn, reps, device):
     return e0.elapsed_time(e1) / reps
 
 
+def layer_table(prof):
+    return {p['name']: {"us": round(1e3 * p['ms'] / p['launches'], 2),
+                        "tflops": round(p['flops_per_launch'] * p['launches'] / (p['ms'] * 1e-3) / 1e12, 2)} for p in prof if p['launches']}
+
+
+def dominant_group(prof, fp32_layers=False):
+    """The layer group that takes the most time of a fully bracketed step: ConvLSTM / ConvGRU gate convolutions (*.rec*, g1/g2),
+    or a single other layer."""
+    groups = {}
+    for p in prof:
+        key = 'recurrent gate convolutions' if ('.rec' in p['name'] or p['name'][:2] in ('g1', 'g2')) else p['name']
+        g = groups.setdefault(key, {'ms': 0.0, 'flops': 0.0, 'launches': 0, 'layers': []})
+        g['ms'] += p['ms']; g['flops'] += p['flops_per_launch'] * p['launches']; g['launches'] += p['launches']; g['layers'].append(p['name'])
+    if not groups:
+        return None
+    name, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
+    total = sum(v['ms'] for v in groups.values())
+    return name, g, total
+
+
+# ------------------------------------------------------------------------------------------------ colour workload
+def run_color(args, wl, device):
+    """BASELINE config 5: ColorNet (model/model.py:46-105) -- voxelize -> Bayer split -> 4 half-resolution + 1 full-resolution
+    recurrent streams -> uint8 planes -> colour merge, all on the GPU; the reference skips quantitative metrics in colour mode."""
+    from evreal_amd import model
+    from evreal_amd.voxel import Voxelizer
+    from oracle import color as oc, prepost as op, voxel as ov
+    from evreal_amd import synth
+    n_seq, K, Wm = args.n_seq or wl.n_seq, args.steps, args.warmup
+    W_, H_, k = wl.W, wl.H, wl.k
+    net = model.ColorNet(wl.base)
+    xy, ts, pol, offs, refs, host = build_inputs(0, n_seq, K + Wm, device, W_, H_, k)
+    vz = Voxelizer(str(device))
+    grid = torch.empty((n_seq, BINS, H_, W_), dtype=torch.float32, device=device)
+
+    def step(s):
+        vz.voxelize_raw(xy, ts, pol, offs[s], BINS, (H_, W_), out=grid)
+        return net(grid)
+
+    for s in range(Wm):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(Wm, Wm + K):
+        step(s)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    net.model.profile(''); net.half.profile('')          # the fully bracketed pass, outside the timed region
+    for s in range(Wm, Wm + min(K, 4)):
+        step(s)
+    torch.cuda.synchronize()
+    prof = [dict(p, name='full.' + p['name']) for p in net.model.profile_read()] + [dict(p, name='half.' + p['name']) for p in net.half.profile_read()]
+    net.model.profile(None); net.half.profile(None)
+    flops = net.model.flops_per_step() + net.half.flops_per_step()
+    an = arith_name()
+    peak = PEAK_F32_MFMA_TFLOPS if an == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+    dom = dominant_group(prof)
+    out = {"metric": "reconstructed frames/sec + Mevents/sec voxelized, ColorNet (E2VID+ layout) %dx%d B=5" % (W_, H_),
+           "value": round(n_seq * K / elapsed, 2), "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+           "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": DTYPE[an], "data": "synthetic", "mevents_per_s": round(n_seq * K * k / elapsed / 1e6, 2),
+           "model_tflops": round(flops * K / elapsed / 1e12, 2),
+           "config": {"workload": "%s on synthetic %dx%d Poisson events (BS-ERGB's 970x625 cropped to even sides: the reference's "
+                                  "ColorNet raises on odd ones), 5 bins, %d events/window, %d sequence(s) per GPU = %d recurrent streams; per "
+                                  "frame: voxelize(raw)+Bayer split+5 forwards+uint8 planes+colour merge; no metrics (the reference skips "
+                                  "them in colour mode, utils/eval_metrics.py:272)" % (wl.title, W_, H_, k, n_seq, 5 * n_seq),
+                      "sequences_per_gpu": n_seq, "events_per_window": k, "sensor": [W_, H_], "bins": BINS,
+                      "gflop_per_frame": round(flops / n_seq / 1e9, 3)}}
+    if dom:
+        name, g, total = dom
+        ach = g['flops'] / (g['ms'] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "traffic": None, "kernel": name + " (" + ", ".join(g['layers']) + ")", "arithmetic": ARITH_TEXT[an],
+                           "share_of_bracketed_time": round(g['ms'] / total, 3), "avg_launch_us": round(1e3 * g['ms'] / g['launches'], 2),
+                           "layers": layer_table(prof)}
+    # ---- parity: F frames of sequence 0, every stream against its own oracle instance; merge against the oracle restatement
+    F = min(args.parity_frames, K + Wm)
+    net.reset_states()
+    oracles = [wl.make_oracle() for _ in range(5)]
+    ch, cf = op.CropParams(W_ // 2, H_ // 2, wl.enc), op.CropParams(W_, H_, wl.enc)
+    xyh, tsh, polh, _ = host
+    worst, plane_flips, merge_diff, t_cpu = 0.0, 0.0, 0, 0.0
+    torch.set_num_threads(min(32, os.cpu_count()))
+    for s in range(F):
+        o = step(s)
+        planes = o['planes'][0].cpu().numpy(); gray = o['gray'][0, 0].cpu().numpy(); bgr = o['image'][0].cpu().numpy()
+        t1 = time.perf_counter()
+        xs, ys, tf, ps = synth.window_events_f32(tsh[s, 0], xyh[s, 0], polh[s, 0], 0, k)
+        v = ov.events_to_voxel(xs, ys, tf, ps, BINS, (H_, W_))[None]
+        split = oc.bayer_split(v)[0]
+        with torch.no_grad():
+            want_p = np.stack([ch.crop(oracles[c](torch.from_numpy(ch.pad(split[c:c + 1]))).numpy())[0, 0] for c in range(4)])
+            want_g = cf.crop(oracles[4](torch.from_numpy(cf.pad(v))).numpy())[0, 0]
+        t_cpu += time.perf_counter() - t1
+        worst = max(worst, float(np.abs(planes - want_p).max()), float(np.abs(gray - want_g).max()))
+        plane_flips = max(plane_flips, float((oc.to_u8(planes) != oc.to_u8(want_p)).mean()), float((oc.to_u8(gray) != oc.to_u8(want_g)).mean()))
+        merge_diff = max(merge_diff, int(np.abs(bgr.astype(int) - oc.merge(planes, gray).astype(int)).max()))
+    out["score_parity"] = {"frames": F, "sequence": 0, "image_max_abs_err": worst, "image_gate": 1e-4, "image_gate_ok": bool(worst < 1e-4),
+                           "what": "float reconstructions of the 4 Bayer planes and the grayscale stream vs five oracle instances",
+                           "uint8_plane_mismatch_fraction_max": plane_flips, "merge_max_abs_diff_u8": merge_diff,
+                           "merge_note": "colour merge vs oracle/color.py (OpenCV restated; cv2 absent: parity unpinned)"}
+    out["cpu_baseline"] = {"value": round(F / max(t_cpu, 1e-9), 3), "unit": "frames/s", "cores": min(32, os.cpu_count()), "kind": "port",
+                           "sample": f"{F} frames of one sequence: numpy voxelizer + 5 torch-CPU forwards per frame"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ drop-in CLI
+def run_eval_cli(args, device):
+    """SURVEY 8b's drop-in: `evreal_amd.eval.evaluate` over a synthetic dataset tree written in the reference's on-disk format
+    (SURVEY 3.4): 8 sequences of 346x260, one reference frame per 15k-event window, E2VID checkpoint + config JSONs as the
+    reference lays them out; `between_frames` windows (config std), MSE+SSIM+LPIPS, 8 sequences advanced together."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from evreal_amd import eval as ev, synth, weights
+    n_seq, frames = 8, 160
+    W_, H_ = 346, 260
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
+    tmp = tempfile.mkdtemp(prefix='evr_cli_')
+    res = {}
+    cwd = os.getcwd()
+    try:
+        for sub in ('eval', 'method', 'dataset'):
+            os.makedirs(os.path.join(tmp, 'config', sub))
+        # LPIPS weights where the tracker looks for them (pretrained/lpips_alex.pth; pyiqa would download the real ones)
+        os.makedirs(os.path.join(tmp, 'pretrained'))
+        lp_path = os.environ.get('EVREAL_LPIPS_WEIGHTS')
+        torch.save(torch.load(lp_path, map_location='cpu', weights_only=False) if lp_path else
+                   {k: torch.from_numpy(np.asarray(v)) for k, v in weights.synth_lpips_state_dict(seed=0).items()},
+                   os.path.join(tmp, 'pretrained', 'lpips_alex.pth'))
+        os.environ.pop('EVREAL_LPIPS_WEIGHTS', None)
+        torch.save({'model': {k: v for k, v in kw.items() if k != 'final_activation'},
+                    'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, os.path.join(tmp, 'e2vid.pth'))
+        json.dump({"model_name": "E2VID", "model_path": os.path.join(tmp, 'e2vid.pth'), "event_tensor_normalization": True,
+                   "post_process_norm": "robust"}, open(os.path.join(tmp, 'config/method/E2VID.json'), 'w'))
+        for name, save in (('std', True), ('stdnoimg', False)):
+            json.dump({"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "between_frames"}, "keep_ratio": 1.0},
+                       "save_images": save, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 1.0, "create_video": False,
+                       "batch_sequences": n_seq}, open(os.path.join(tmp, f'config/eval/{name}.json'), 'w'))
+        seqs = {}
+        for s in range(n_seq):
+            # 1 Mev/s and 66.67 frames/s: 15k events between consecutive reference frames
+            synth.write_sequence(os.path.join(tmp, 'data', 'SYN', f's{s}'), 100 + s, (frames + 1) * 15000, 1.0e6, W_, H_, 1.0e6 / 15000)
+            seqs[f's{s}'] = {}
+        json.dump({"root_path": os.path.join(tmp, 'data', 'SYN'), "sequences": seqs}, open(os.path.join(tmp, 'config/dataset/SYN.json'), 'w'))
+        os.chdir(tmp)
+        for name in ('stdnoimg', 'std'):
+            for rep in range(2):                       # first pass warms allocations / the LPIPS model; the second is timed
+                shutil.rmtree(os.path.join(tmp, 'outputs'), ignore_errors=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    r = ev.evaluate(['E2VID'], [name], ['SYN'], ['mse', 'ssim', 'lpips'])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            dm = r[name][0][0]
+            nfr = sum(len(open(os.path.join(tmp, 'outputs', name, 'SYN', f's{s}', 'E2VID', 'timestamps.txt')).read().splitlines())
+                      for s in range(n_seq))
+            res['save_images_on' if name == 'std' else 'save_images_off'] = {
+                "value": round(nfr / dt, 1), "unit": "frames/s", "frames": nfr, "seconds": round(dt, 3),
+                "scored_frames": int(dm.get_count('mse')), "mse": dm.get_average('mse'), "ssim": dm.get_average('ssim'),
+                "lpips": dm.get_average('lpips') if 'lpips' in dm.data_dict else None}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    res["what"] = ("evreal_amd.eval.evaluate(['E2VID'], [cfg], ['SYN'], ['mse','ssim','lpips']) end to end (sequence open + upload, "
+                   "window tables, frame loop, text files, PNGs), %d sequences x %d frames of %dx%d advanced together "
+                   "(batch_sequences = %d); wall clock of the whole call" % (n_seq, frames, W_, H_, n_seq))
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--n-seq', type=int, default=64, help='independent sequences advanced together per GPU')
-    ap.add_argument('--sensor', default='346x260', help='sensor WxH of the synthetic streams (346x260 | 640x480)')
+    ap.add_argument('--config', default='e2vid', choices=['e2vid', 'firenet', 'hyper', 'color', 'eval_cli'])
+    ap.add_argument('--n-seq', type=int, default=0, help='independent sequences advanced together per GPU (0: the config default)')
+    ap.add_argument('--sensor', default='', help='sensor WxH of the synthetic streams (default: the config; e2vid also 640x480)')
     ap.add_argument('--cpu-frames', type=int, default=200, help='frames of the CPU baseline (0 disables)')
-    ap.add_argument('--parity-frames', type=int, default=12, help='frames of sequence 0 replayed through the oracle')
-    ap.add_argument('--profile-filter', default='rec', help='layers bracketed with HIP events (roofline block)')
+    ap.add_argument('--parity-frames', type=int, default=0, help='frames of sequence 0 replayed through the oracle (0: 12 / 4 in sub-runs)')
+    ap.add_argument('--profile-filter', default=None, help='layers bracketed with HIP events (roofline block)')
     ap.add_argument('--no-overlap', action='store_true', help='evaluation kernels on the reconstruction stream (no second HIP stream)')
-    ap.add_argument('--sub', action='store_true', help='side run: headline + roofline only (no CPU leg, no sub-runs)')
+    ap.add_argument('--sub', action='store_true', help='side run: headline + roofline + a short oracle comparison (no sub-runs)')
     args = ap.parse_args()
-    W_, H_ = [int(v) for v in args.sensor.lower().split('x')]
+    if not args.parity_frames:
+        args.parity_frames = 4 if args.sub else 12
 
     mode, world = resolve_world(args.gpus, os.environ)
     if mode == 'relaunch':
@@ -261,26 +524,39 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+
+    def emit(out):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio: keep the JSON the LAST stdout line
+        print(json.dumps(out), flush=True)
+
+    if args.config == 'eval_cli':
+        emit(run_eval_cli(args, device))
+        return
+    sensor = tuple(int(v) for v in args.sensor.lower().split('x')) if args.sensor else None
+    wl = Workload(args.config, sensor)
+    if wl.color:
+        emit(run_color(args, wl, device))
+        return
+
     dist = None
     if world > 1 or os.environ.get('EVR_FORCE_DIST'):      # EVR_FORCE_DIST=1: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    side = (world == 1) and not args.sub                   # the side blocks run on the single-GPU default run only
+    side = (world == 1) and not args.sub and args.config == 'e2vid' and sensor is None   # the side blocks run on the default run only
 
-    from evreal_amd import model, weights
+    from evreal_amd import weights
     from evreal_amd.pipeline import HotPath
     from evreal_amd.dist import reduce_metric_sums
     from evreal_amd.lpips import LPIPS
     from evreal_amd.voxel import Voxelizer
 
-    kw = dict(weights.E2VID_KWARGS)
-    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=0)
-    net = model.E2VIDRecurrent(kw)
-    net.load_state_dict(sd)
-    n_seq, K, Wm = args.n_seq, args.steps, args.warmup
-    xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, K + Wm, device, W_, H_)
+    net = wl.net
+    W_, H_, K_EVENTS = wl.W, wl.H, wl.k
+    n_seq, K, Wm = args.n_seq or wl.n_seq, args.steps, args.warmup
+    xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, K + Wm, device, W_, H_, K_EVENTS)
     lpips_path = os.environ.get('EVREAL_LPIPS_WEIGHTS')
     if lpips_path:      # a real pyiqa/lpips AlexNet-v0.1 state_dict supplied by the user
         lpips_sd = {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in
@@ -290,9 +566,15 @@ def main():
         lpips_sd = weights.synth_lpips_state_dict(seed=0)
         lpips_tag = "synthetic(seed=0)"
     lp = LPIPS(lpips_sd)
-    hp = HotPath(net, BINS, (H_, W_), n_seq, event_tensor_normalization=True, post_process_norm='robust',
-                 metrics=('mse', 'ssim', 'lpips'), device=str(device), lpips=lp, overlap=not args.no_overlap)
+    mk = lambda ns: HotPath(net, BINS, (H_, W_), ns, event_tensor_normalization=wl.norm_in, post_process_norm=wl.post,
+                            metrics=('mse', 'ssim', 'lpips'), device=str(device), lpips=lp, overlap=not args.no_overlap)
+    hp = mk(n_seq)
     scores = torch.zeros((K + Wm, n_seq, 3), dtype=torch.float64, device=device)
+    an = arith_name()
+    # layers bracketed inside the timed region: the recurrent gate convolutions for E2VID (the dominant kernel the roofline block
+    # quotes, as in earlier rounds); every launch for the other configurations, whose dominant layer is found from the table
+    pf = args.profile_filter if args.profile_filter is not None else ('rec' if wl.name == 'e2vid' else '')
+    pf_timed = pf if wl.name == 'e2vid' else None      # (bracketing EVERY launch costs host time: the other configs do it in a pass of its own)
 
     def barrier():
         if dist is not None:
@@ -301,7 +583,7 @@ def main():
 
     for s in range(Wm):
         hp.step_raw(xy, ts, pol, offs[s], refs, scores[s])
-    net.profile(args.profile_filter)
+    net.profile(pf_timed)
     hp.time_voxelizer(True)
     barrier()
     t0 = time.perf_counter()
@@ -309,19 +591,28 @@ def main():
         hp.step_raw(xy, ts, pol, offs[s], refs, scores[s])
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = net.profile_read()
+    prof = net.profile_read() if pf_timed is not None else []
     net.profile(None)
     vox_ms_in_step = hp.time_voxelizer(False)
     sc = scores[Wm:].cpu().numpy()                       # [K, n_seq, 3] before anything below rewrites the buffer
+    hp.check_dropped()                                   # out-of-sensor events would have been dropped silently: raise instead
+    sat_runs, sat_layer = net.saturation()
 
     # ---- everything below is outside the timed region ----
     scratch = torch.zeros((n_seq, 3), dtype=torch.float64, device=device)
+    if pf_timed is None:                                 # the fully bracketed pass (same two-stream step)
+        net.profile(pf)
+        for s in range(Wm, Wm + min(K, 6)):
+            hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
+        barrier()
+        prof = net.profile_read()
+        net.profile(None)
     # the same layers once more with the evaluation kernels on the SAME stream, so the dominant kernel's duration is
     # also known without the second stream's kernels sharing the chip with it
     prof_single = None
     if hp.overlap:
         hp.overlap = False
-        net.profile(args.profile_filter)
+        net.profile(pf)
         for s in range(Wm, min(Wm + 3, Wm + K)):
             hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
         barrier()
@@ -352,64 +643,68 @@ def main():
     tot = reduce_metric_sums(torch.from_numpy(sums).to(device), dist)
     elapsed = float(tmax.item())
 
+    out = None
     if rank == 0:
         frames = n_seq * K * world
         fps = frames / elapsed
         flops_step = net.flops_per_step()
-        lstm = [p for p in prof if '.rec' in p['name']]
+        # `achieved` counts ALGORITHMIC (direct convolution) flops in every mode; in the split modes the matrix pipe is busy
+        # for ISSUE_FACTOR x that in f16-rate cycles (mfma_issue_*); `peak` is the dense f16/bf16 (fp32: fp32) MFMA peak.
+        fp32_net = (an == 'fp32') or wl.name == 'firenet'          # FireNet's 16-channel layers run the exact fp32 MFMA in every mode
+        peak = PEAK_F32_MFMA_TFLOPS if fp32_net else PEAK_BF16_MFMA_TFLOPS
+        issue = 1.0 if fp32_net else ISSUE_FACTOR[an]
+        if wl.name == 'e2vid':
+            lstm = [p for p in prof if '.rec' in p['name']]
+            dom_name = ("conv3x3_wide_kernel<LSTM=true, WN> (ConvLSTM gate convolutions: 256 x 128 tiles, two blocks per CU, up to 256 input "
+                        "channels; 256 x 256 tiles above)" if an != 'fp32' else "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=0> (ConvLSTM gate convolutions)")
+            share = None
+        else:
+            name, g, total_ms = dominant_group(prof)
+            lstm = [p for p in prof if p['name'] in g['layers']]
+            dom_name = name + " (" + ", ".join(g['layers']) + ")"
+            share = round(g['ms'] / total_ms, 3)
         rl_flops = sum(p['flops_per_launch'] * p['launches'] for p in lstm)
         rl_ms = sum(p['ms'] for p in lstm)
         rl_launches = sum(p['launches'] for p in lstm)
         achieved = rl_flops / (rl_ms * 1e-3) / 1e12 if rl_ms > 0 else 0.0
-        # arithmetic mode of the 32-channel-chunk convolutions (model.cpp finish_conv): default split f16 + MX-fp8 (csrc/conv.h)
-        # (f16 main product + one MX-scaled fp8 MFMA for the two cross terms per 32 k, fp32 accumulate: ~2^-16 relative per
-        # product term); EVR_FP32=1 selects the exact fp32 MFMA.  `achieved` counts ALGORITHMIC (direct convolution)
-        # flops in both modes; in split mode the matrix pipe is busy for 2x that in f16-rate cycles (the fp8 MFMA covers
-        # its 64 k in the time of 32 f16 k), reported as mfma_issue_*; `peak` stays the f16/bf16 dense peak.
-        x3 = not os.environ.get('EVR_FP32')
-        peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-        traffic, traffic_note = measured_traffic() if (x3 and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
+        traffic, traffic_note = measured_traffic() if (an == 'mx' and wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
+        sel = set(p['name'] for p in lstm)
         out = {
-            "metric": "reconstructed frames/sec + Mevents/sec voxelized, E2VID %dx%d B=5" % (W_, H_),
+            "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID'}[wl.name], W_, H_),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16+mxfp8" if x3 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": 'f32' if fp32_net else DTYPE[an], "data": "synthetic",
             "mevents_per_s": round(frames * K_EVENTS / elapsed / 1e6, 2),
             "model_tflops": round(flops_step * K * world / elapsed / 1e12, 2),
             "rccl_ranks": world if dist is not None else 0,
-            "config": {"workload": "E2VID (synthetic weights, BN folded) on synthetic %dx%d Poisson events, 5 bins, "
-                                   "15k events/window (k_events), %d sequences per GPU advanced together; per frame: "
-                                   "voxelize(raw)+event-tensor norm+pad+forward+crop+robust norm+clip+MSE+SSIM+LPIPS "
-                                   "(LPIPS: AlexNet-v0.1 structure, weights %s)" % (W_, H_, n_seq, lpips_tag),
-                       "sequences_per_gpu": n_seq, "events_per_window": K_EVENTS, "sensor": [W_, H_], "bins": BINS,
+            "config": {"workload": "%s on synthetic %dx%d Poisson events, 5 bins, %d events/window (k_events), %d sequences per GPU "
+                                   "advanced together; per frame: voxelize(raw)%s+pad+forward+crop%s+clip+MSE+SSIM+LPIPS "
+                                   "(LPIPS: AlexNet-v0.1 structure, weights %s)" % (
+                                       wl.title, W_, H_, K_EVENTS, n_seq, '+event-tensor norm' if wl.norm_in else '',
+                                       '+robust norm' if wl.post != 'none' else '', lpips_tag),
+                       "name": wl.name, "sequences_per_gpu": n_seq, "events_per_window": K_EVENTS, "sensor": [W_, H_], "bins": BINS,
                        "gflop_per_frame": round(flops_step / n_seq / 1e9, 3),
                        "lpips_gflop_per_frame": round(lp.flops() / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
-                       "lpips_weights": lpips_tag,
+                       "lpips_weights": lpips_tag, "arithmetic_mode": an,
+                       "range_guard": {"runs_beyond_exact_range": sat_runs, "layer": sat_layer},
                        "scores": {"mse": tot[0, 0] / tot[0, 3], "ssim": tot[0, 1] / tot[0, 3], "lpips": tot[0, 2] / tot[0, 3],
                                   "count": int(tot[0, 3])}},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                         "kernel": ("conv3x3_wide_kernel<LSTM=true, WN> (ConvLSTM gate convolutions: 256 x 128 tiles, two blocks per CU, up to 256 input channels; 256 x 256 tiles above)" if x3 else
-                                    "conv_igemm_kernel<32,4,4,LSTM=true,REGSTAGE,X3=0> (ConvLSTM gate convolutions)"),
-                         "arithmetic": ("split: x = hi + lo8*2^-12, w = hi + wlo8*2^-(e+12) (f16 hi, fp8 e4m3 residuals); per 32 k "
-                                        "acc += hi_w*hi_x on 2 x v_mfma_f32_32x32x16_f16 + (w8*lo8 + wlo8*x8) on 1 x "
-                                        "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; activations stored PACKED (f16 hi | "
-                                        "fp8 lo8 | fp8 x8 per 16 channels) by the producer" if x3 else
-                                        "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"),
-                         "mfma_issue_tflops": round(achieved * (2 if x3 else 1), 2),
-                         "mfma_issue_frac": round(achieved * (2 if x3 else 1) / peak, 4),
+                         "kernel": dom_name, "share_of_bracketed_time": share,
+                         "arithmetic": ARITH_TEXT['fp32' if fp32_net else an],
+                         "mfma_issue_tflops": round(achieved * issue, 2),
+                         "mfma_issue_frac": round(achieved * issue / peak, 4),
                          "streams": ("2: reconstruction | evaluation (robust norm, MSE/SSIM, LPIPS of the previous frame) -- "
                                      "the timed launches share the chip with the evaluation kernels"
                                      if prof_single is not None else "1"),
                          "single_stream": (None if prof_single is None else (lambda l: {
                              "avg_launch_us": round(1e3 * sum(p['ms'] for p in l) / max(sum(p['launches'] for p in l), 1), 2),
-                             "achieved": round(sum(p['flops_per_launch'] * p['launches'] for p in l) / (sum(p['ms'] for p in l) * 1e-3) / 1e12, 2)})(
-                             [p for p in prof_single if '.rec' in p['name']])),
+                             "achieved": round(sum(p['flops_per_launch'] * p['launches'] for p in l) / max(sum(p['ms'] for p in l) * 1e-3, 1e-12) / 1e12, 2)})(
+                             [p for p in prof_single if p['name'] in sel])),
                          "gflop_per_launch": round(rl_flops / max(rl_launches, 1) / 1e9, 3),
                          "avg_launch_us": round(1e3 * rl_ms / max(rl_launches, 1), 2), "launches": rl_launches,
-                         "layers": {p['name']: {"us": round(1e3 * p['ms'] / p['launches'], 2),
-                                                "tflops": round(p['flops_per_launch'] * p['launches'] / (p['ms'] * 1e-3) / 1e12, 2)}
-                                    for p in prof}},
+                         "layers": layer_table(prof)},
             "steady_state": steady,
         }
 
@@ -439,11 +734,10 @@ def main():
         if side:
             # ---- small batches (the reference's regime is one sequence at a time) ----
             sb = {}
-            for ns in (1, 4):
+            for ns in (1, 4, 8):
                 if ns >= n_seq:
                     continue
-                h2 = HotPath(net, BINS, (H_, W_), ns, event_tensor_normalization=True, post_process_norm='robust',
-                             metrics=('mse', 'ssim', 'lpips'), device=str(device), lpips=lp, overlap=not args.no_overlap)
+                h2 = mk(ns)
                 sc2 = torch.zeros((ns, 3), dtype=torch.float64, device=device)
                 ofs = [offs[s][:ns + 1].contiguous() for s in range(K + Wm)]
                 for s in range(Wm):
@@ -462,21 +756,23 @@ def main():
                           "the same for the sequences of a dataset" % n_seq)
             out["small_batch"] = sb
 
-            # ---- score parity: first frames of sequence 0, GPU replay vs the CPU oracle ----
+        if side or args.sub:
+            # ---- score parity: first frames of sequence 0, GPU replay (THIS dispatch: same n_seq, same kernels) vs the CPU oracle
             F = min(args.parity_frames, K + Wm)
-            hp.overlap_saved, hp.overlap = hp.overlap, False
+            saved, hp.overlap = hp.overlap, False
             net.reset_states()
             gpu_frames = []
             for s in range(F):
-                img, scs = hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
+                img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
                 torch.cuda.synchronize()
                 gpu_frames.append((img[0, 0].cpu().numpy().copy(), [float(v) for v in scratch[0].cpu().numpy()]))
-            hp.overlap = hp.overlap_saved
+            hp.overlap = saved
             cb, cpu_frames = (None, [])
             if args.cpu_frames > 0:
-                cb, cpu_frames = cpu_baseline(host_inputs, sd, kw, args.cpu_frames, W_, H_, lpips_sd=lpips_sd, keep_frames=F)
+                cb, cpu_frames = cpu_baseline(wl, host_inputs, args.cpu_frames if side else F, budget_s=25.0 if side else 0.0,
+                                              lpips_sd=lpips_sd, keep_frames=F)
             out["cpu_baseline"] = cb
-            out["score_parity"] = score_parity(gpu_frames, cpu_frames, ['mse', 'ssim', 'lpips'])
+            out["score_parity"] = score_parity(gpu_frames, cpu_frames, ['mse', 'ssim', 'lpips'], gate=1e-5 if an in ('h3', 'fp32') else 1e-4)
         else:
             out["cpu_baseline"] = None
 
@@ -487,23 +783,40 @@ def main():
     if rank == 0 and side:
         # release this process's device memory before the sub-runs allocate theirs
         del hp, net, lp, xy, ts, pol, offs, refs, scores
+        wl.net = None
         torch.cuda.empty_cache()
-        fp = sub_run(['--n-seq', str(n_seq), '--sensor', args.sensor], {'EVR_FP32': '1'}, K, Wm)
-        out["fp32_exact"] = ({k: fp.get(k) for k in ('value', 'ms_per_step', 'dtype', 'steady_state')} |
-                             {"roofline": {k: fp.get('roofline', {}).get(k) for k in ('achieved', 'peak', 'frac', 'avg_launch_us', 'kernel')},
-                              "scores": fp.get('config', {}).get('scores')}) if 'error' not in fp else fp
-        if (W_, H_) == (346, 260):
-            big = sub_run(['--n-seq', str(n_seq), '--sensor', '640x480'], {}, K, Wm)
-            out["sensor_640x480"] = ({k: big.get(k) for k in ('value', 'ms_per_step', 'dtype', 'mevents_per_s', 'model_tflops', 'steady_state')} |
-                                     {"roofline": {k: big.get('roofline', {}).get(k) for k in ('achieved', 'peak', 'frac', 'avg_launch_us')},
-                                      "roofline_voxelizer": {k: big.get('roofline_voxelizer', {}).get(k) for k in ('achieved', 'frac')},
-                                      "gflop_per_frame": big.get('config', {}).get('gflop_per_frame'),
-                                      "sequences_per_gpu": n_seq}) if 'error' not in big else big
+        pick = lambda d, keys: {k: d.get(k) for k in keys}
+        rl_keys = ('achieved', 'peak', 'frac', 'avg_launch_us', 'kernel', 'share_of_bracketed_time', 'mfma_issue_frac')
+        par_keys = ('frames', 'image_max_abs_err', 'image_gate', 'image_gate_ok', 'all_3sf')
+
+        def brief(d, extra=()):
+            if 'error' in d:
+                return d
+            b = pick(d, ('value', 'ms_per_step', 'dtype', 'mevents_per_s', 'model_tflops', 'steady_state') + tuple(extra))
+            b["roofline"] = pick(d.get('roofline') or {}, rl_keys)
+            sp = d.get('score_parity') or {}
+            b["score_parity"] = pick(sp, par_keys) | {k: sp[k] for k in ('mse', 'ssim', 'lpips', 'uint8_plane_mismatch_fraction_max', 'merge_max_abs_diff_u8') if k in sp}
+            b["scores"] = (d.get('config') or {}).get('scores')
+            b["workload"] = (d.get('config') or {}).get('workload')
+            b["sequences_per_gpu"] = (d.get('config') or {}).get('sequences_per_gpu')
+            b["gflop_per_frame"] = (d.get('config') or {}).get('gflop_per_frame')
+            b["cpu_frames_per_s"] = (d.get('cpu_baseline') or {}).get('value')
+            return b
+
+        out["fp32_equiv"] = brief(sub_run([], {'EVR_ARITH': 'h3'}, K, Wm))
+        out["fp32_exact"] = brief(sub_run([], {'EVR_FP32': '1'}, K, Wm))
+        big = sub_run(['--sensor', '640x480'], {}, K, Wm)
+        out["sensor_640x480"] = brief(big) | ({"roofline_voxelizer": pick(big.get('roofline_voxelizer') or {}, ('achieved', 'frac'))} if 'error' not in big else {})
+        out["configs"] = {
+            "1 (E2VID, CPU PyTorch path)": "cpu_baseline above: the oracle port on the host cores, same windows, same metrics",
+            "2 (E2VID 346x260, MSE+SSIM+LPIPS)": "the headline line",
+            "3 (FireNet 240x180, k_events)": brief(sub_run(['--config', 'firenet'], {}, K, Wm)),
+            "4 (HyperE2VID 346x260, 4 sequences)": brief(sub_run(['--config', 'hyper'], {}, K, Wm)),
+            "5 (ColorNet E2VID+ 970x624, 50k events/window)": brief(sub_run(['--config', 'color'], {}, max(K // 2, 4), Wm, timeout=600)),
+        }
+        out["eval_cli"] = sub_run(['--config', 'eval_cli'], {}, K, Wm, timeout=600)
     if rank == 0:
-        # RCCL prints a version banner through C stdio; flush it first so the JSON stays the LAST stdout line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == '__main__':

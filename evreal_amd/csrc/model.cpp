@@ -110,6 +110,7 @@ struct evr_model {
     int pred_fused_conv = -1;
     // HyperE2VID dynamic decoder (submodules.py:100-127)
     bool dynamic = false;
+    double dyn_flops = 0.0;   // per launch of the dynamic-filter step (profile table)
     std::vector<float> ctx_w, ctx_b, fb_bases;
     float* d_ctx_w = nullptr; float* d_ctx_b = nullptr; float* d_bases = nullptr;
     float* prev_rec = nullptr;
@@ -995,6 +996,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             for (int p = 0; p < 2; ++p) a3.out[p] = o.p;
             plan_conv(m, di, n, h, w, a3, cout); push_conv(m, di);
+            m->dyn_flops = 2.0 * n * h * w * (double)cin * 25 * 6;
             m->flops += 2.0 * n * h * w * (double)cin * 25 * 6 + 2.0 * n * h * w * 72.0 * 25 + 2.0 * n * h * w * 9.0 * (d.num_bins + 1) * 32;
             name2(m, "ctx", ctxf, ctxf); name2(m, "coeff", coef, coef);
             last_plain = -1;   // the next decoder adds its skip itself
@@ -1502,8 +1504,28 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
         if (m->frame == 0 && (rc = launch_spade_first(m->sp_xpad, m->sp_xorg, m->n_seq, m->desc.num_bins, m->hp, m->wp, stream))) return rc;
         ha.vox = m->sp_xpad; ha.stats = nullptr;
     }
-    if ((rc = launch_head_conv(ha, stream))) return rc;
+    // per-layer event timing (evr_model_profile_*): conv layers by name; every other launch under its step kind
+    // (ids convs.size() + kind; "head" = convs.size() + 64, "pred" = + 65), selected by the same substring filter
+    static const char* const kind_names[] = {"head", "conv", "upsample", "add", "pred", "ctx_down", "ctx_conv", "dynamic_filter", "to_packed",
+                                             "spade_nearest", "spade_seg", "spade_apply", "instnorm", "layernorm", "attention", "add_pos", "mean6"};
+    auto bracket_begin = [&](int id, const char* name, evr_model::ProfPair& pp) -> bool {
+        if (!m->prof_on || std::string(name).find(m->prof_filter) == std::string::npos) return false;
+        pp = evr_model::ProfPair{id, nullptr, nullptr};
+        if (hipEventCreate(&pp.a) != hipSuccess || hipEventCreate(&pp.b) != hipSuccess) return false;
+        (void)hipEventRecord(pp.a, stream);
+        return true;
+    };
+    auto bracket_end = [&](evr_model::ProfPair& pp) { (void)hipEventRecord(pp.b, stream); m->prof_pending.push_back(pp); };
+    const int nconv = (int)m->convs.size();
+    {
+        evr_model::ProfPair pp{};
+        const bool on = bracket_begin(nconv + 64, "head", pp);
+        if ((rc = launch_head_conv(ha, stream))) return rc;
+        if (on) bracket_end(pp);
+    }
     for (const Step& s : m->steps) {
+        evr_model::ProfPair spp{};
+        const bool son = (s.kind != ST_CONV) && bracket_begin(nconv + (int)s.kind, kind_names[(int)s.kind], spp);
         switch (s.kind) {
             case ST_CONV: {
                 const Conv& c = m->convs[s.conv];
@@ -1564,6 +1586,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 break;
             default: break;
         }
+        if (son) bracket_end(spp);
     }
     PredArgs pa{};
     pa.x = m->pred_x[p]; pa.skip = m->pred_skip[p]; pa.n = m->n_seq; pa.hp = m->hp; pa.wp = m->wp; pa.c = m->pred_c;
@@ -1574,7 +1597,12 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
         SpadePredArgs sa = m->sp_pred;
         sa.x = m->pred_x[p]; sa.img = img;
         if ((rc = launch_spade_pred(sa, stream))) return rc;
-    } else if (m->pred_fused_conv < 0 && (rc = launch_pred(pa, stream))) return rc;
+    } else if (m->pred_fused_conv < 0) {
+        evr_model::ProfPair pp{};
+        const bool on = bracket_begin(nconv + 65, "pred", pp);
+        if ((rc = launch_pred(pa, stream))) return rc;
+        if (on) bracket_end(pp);
+    }
     m->frame++;
     return EVR_OK;
 }
@@ -1616,8 +1644,8 @@ extern "C" int evr_model_profile_enable(evr_model* m, const char* filter) {
     EVR_REQUIRE(m != nullptr, "evr_model_profile_enable: null model");
     for (auto& pp : m->prof_pending) { (void)hipEventDestroy(pp.a); (void)hipEventDestroy(pp.b); }
     m->prof_pending.clear();
-    m->prof_ms.assign(m->convs.size(), 0.0);
-    m->prof_n.assign(m->convs.size(), 0);
+    m->prof_ms.assign(m->convs.size() + 80, 0.0);
+    m->prof_n.assign(m->convs.size() + 80, 0);
     m->prof_on = filter != nullptr;
     m->prof_filter = filter ? filter : "";
     return EVR_OK;
@@ -1627,7 +1655,7 @@ extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names,
                                       int64_t* launches, int* n_layers, evr_stream_t stream) {
     EVR_REQUIRE(m && names && ms && flops_per_launch && launches && n_layers, "evr_model_profile_read: null argument");
     EVR_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (m->prof_ms.size() != m->convs.size()) { m->prof_ms.assign(m->convs.size(), 0.0); m->prof_n.assign(m->convs.size(), 0); }
+    if (m->prof_ms.size() != m->convs.size() + 80) { m->prof_ms.assign(m->convs.size() + 80, 0.0); m->prof_n.assign(m->convs.size() + 80, 0); }
     for (auto& pp : m->prof_pending) {
         float t = 0.f;
         EVR_HIP(hipEventElapsedTime(&t, pp.a, pp.b));
@@ -1636,10 +1664,18 @@ extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names,
     }
     m->prof_pending.clear();
     int k = 0;
-    for (size_t i = 0; i < m->convs.size() && k < max_layers; ++i) {
+    static const char* const kind_names[] = {"head", "conv", "upsample", "add", "pred", "ctx_down", "ctx_conv", "dynamic_filter", "to_packed",
+                                             "spade_nearest", "spade_seg", "spade_apply", "instnorm", "layernorm", "attention", "add_pos", "mean6"};
+    const size_t nconv = m->convs.size();
+    for (size_t i = 0; i < m->prof_n.size() && k < max_layers; ++i) {
         if (m->prof_n[i] == 0) continue;
-        snprintf(names + (size_t)k * 64, 64, "%s", m->convs[i].name.c_str());
-        ms[k] = m->prof_ms[i]; flops_per_launch[k] = m->convs[i].flops; launches[k] = m->prof_n[i];
+        const char* nm = i < nconv ? m->convs[i].name.c_str() : (i == nconv + 64 ? "head" : i == nconv + 65 ? "pred" : (i - nconv < 17 ? kind_names[i - nconv] : "?"));
+        snprintf(names + (size_t)k * 64, 64, "%s", nm);
+        double fl = 0.0;
+        if (i < nconv) fl = m->convs[i].flops;
+        else if (i == nconv + 64) fl = 2.0 * m->n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
+        else if (i == nconv + (size_t)ST_DYN) fl = m->dyn_flops;
+        ms[k] = m->prof_ms[i]; flops_per_launch[k] = fl; launches[k] = m->prof_n[i];
         ++k;
     }
     *n_layers = k;

@@ -65,6 +65,8 @@ class MemMapDataset:
             self.length = min(self.length, max_length + 1)
         self._vox = None
         self._dev = None
+        self._img = None
+        self._255 = None
         self._table = None
 
     @property
@@ -222,10 +224,8 @@ class MemMapDataset:
         return self._table
 
     # -- device residency ----------------------------------------------------------------------
-    def upload(self):
-        """Move the sequence's events (13 B each) and reference frames (uint8) into HBM once."""
-        if self._dev is not None:
-            return self._dev
+    def host_events(self):
+        """The sequence's event columns as the arrays that go to HBM (int16 xy, float64 t, uint8 p), validated."""
         fh = self.filehandle
         xy = np.ascontiguousarray(fh["xy"])
         # The reference trusts the coordinates (SURVEY 8a quirk 6): index_put_ raises beyond the sensor and WRAPS negative
@@ -246,12 +246,25 @@ class MemMapDataset:
         if pol.size and not np.isin(pol, (0, 1)).all():
             raise ValueError(f"{self.data_path}: events_p.npy must hold 0/1 (or bool) polarities, found values "
                              f"{np.unique(pol)[:6].tolist()}")
+        return xy.astype(np.int16), np.array(fh["t"], dtype=np.float64), pol.astype(np.uint8)
+
+    def upload_images(self):
+        """Reference frames (uint8) into HBM once."""
+        if self._img is None and self.has_images:
+            _lib.require_gpu()
+            self._img = torch.from_numpy(np.array(self.filehandle["images"][..., 0])).to(self.device)   # [F,H,W] u8
+        return self._img
+
+    def upload(self):
+        """Move the sequence's events (13 B each) and reference frames (uint8) into HBM once."""
+        if self._dev is not None:
+            return self._dev
+        xy, t, pol = self.host_events()
         _lib.require_gpu()
-        d = {'xy': torch.from_numpy(xy.astype(np.int16)).to(self.device),
-             'ts': torch.from_numpy(np.array(fh["t"], dtype=np.float64)).to(self.device),
-             'p': torch.from_numpy(pol.astype(np.uint8)).to(self.device)}
+        d = {'xy': torch.from_numpy(xy).to(self.device), 'ts': torch.from_numpy(t).to(self.device),
+             'p': torch.from_numpy(pol).to(self.device)}
         if self.has_images:
-            d["images"] = torch.from_numpy(np.array(fh["images"][..., 0])).to(self.device)   # [F,H,W] u8
+            d["images"] = self.upload_images()
         self._dev = d
         self._vox = Voxelizer(self.device)
         return d
@@ -286,15 +299,17 @@ class MemMapDataset:
         H, W = self.sensor_resolution
         return int(max(self.length, 1)) * (-(-H // 16) * 16) * (-(-W // 16) * 16)
 
-    def frames(self, frame_indices):
+    def frames(self, frame_indices, out=None):
         """Reference frames [n,1,H,W] fp32 in [0,1] (dataset.py:80-85: images[i][:,:,0] / 255)."""
-        d = self.upload()
+        images = self.upload_images()
         idx = torch.from_numpy(np.asarray(frame_indices, dtype=np.int64)).to(self.device)
         # tensor / tensor: a true IEEE division (torch's CUDA kernel turns `/ python_scalar` into `* (1/255)`,
         # which differs from the reference's CPU result in the last bit)
-        if '_255' not in d:
-            d['_255'] = torch.tensor(255.0, dtype=torch.float32, device=self.device)
-        return torch.div(d['images'][idx].to(torch.float32), d['_255']).unsqueeze(1)
+        if self._255 is None:
+            self._255 = torch.tensor(255.0, dtype=torch.float32, device=self.device)
+        if out is not None:
+            return torch.div(images[idx].to(torch.float32), self._255, out=out)
+        return torch.div(images[idx].to(torch.float32), self._255).unsqueeze(1)
 
     def __getitem__(self, index):
         assert 0 <= index < len(self), f"index {index} out of bounds (0 <= x < {len(self)})"
@@ -309,3 +324,50 @@ class MemMapDataset:
         return {'frame': frame, 'events': grid[0], 'frame_timestamp': fts,
                 'voxel_timestamp': torch.tensor(tb['voxel_timestamp'][index], dtype=torch.float64),
                 'dt': torch.tensor(tb['dt'][index], dtype=torch.float64), 'event_count': int(tb['event_count'][index])}
+
+
+class SequenceBatch:
+    """S sequences of one sensor size whose events sit in ONE resident array, so that a single tensorizer launch covers
+    windows of different sequences (step-major: window (step, slot)) -- the input side of eval.eval_method_on_sequences."""
+
+    def __init__(self, datasets):
+        assert len(datasets) >= 1
+        self.dss = list(datasets)
+        H, W = self.dss[0].sensor_resolution
+        assert all(tuple(d.sensor_resolution) == (H, W) for d in self.dss), "batched sequences must share the sensor size"
+        self.H, self.W, self.num_bins = H, W, self.dss[0].num_bins
+        self.device = self.dss[0].device
+        cols = [d.host_events() for d in self.dss]
+        self.base = np.concatenate([[0], np.cumsum([len(c[1]) for c in cols])]).astype(np.int64)    # slot j = events [base[j], base[j+1])
+        _lib.require_gpu()
+        self.xy = torch.from_numpy(np.concatenate([c[0] for c in cols])).to(self.device)
+        self.ts = torch.from_numpy(np.concatenate([c[1] for c in cols])).to(self.device)
+        self.p = torch.from_numpy(np.concatenate([c[2] for c in cols])).to(self.device)
+        self.vox = Voxelizer(self.device)
+
+    def voxel_steps(self, items, out, stats, stream=None):
+        """items[j] = the item indices of slot j for this chunk (ragged: an exhausted slot gets empty windows);
+        out [n_steps, S, B, H, W], stats [n_steps, S, 3] are filled for n_steps = max(len(items[j]))."""
+        S = len(self.dss)
+        n = max(len(it) for it in items)
+        b = np.zeros((n, S), np.int64); e = np.zeros((n, S), np.int64)
+        for j, (ds, it) in enumerate(zip(self.dss, items)):
+            tb = ds.table()
+            it = np.asarray(it, dtype=np.int64)
+            if len(it) and not tb['valid'][it].all():
+                bad = int(it[~tb['valid'][it]][0])
+                raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
+                    int(tb['idx0'][bad]), int(tb['idx1'][bad]), ds.num_events))
+            b[:len(it), j] = tb['idx0'][it] + self.base[j]
+            e[:len(it), j] = tb['idx1'][it] + self.base[j]
+        b = b.reshape(-1); e = np.maximum(e.reshape(-1), b)
+        lens = e - b
+        rec = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(self.device, non_blocking=True)
+        self.vox.voxelize_raw_windows(self.xy, self.ts, self.p, dev(b), dev(e), dev(rec), int(lens.sum()), self.num_bins,
+                                      (self.H, self.W), out=out[:n].view(n * S, self.num_bins, self.H, self.W),
+                                      stats=stats[:n].view(n * S, 3), stream=stream)
+        return n
+
+    def raise_if_dropped(self):
+        self.vox.raise_if_dropped("events of " + ", ".join(d.data_path for d in self.dss))

@@ -165,57 +165,60 @@ def _plan_items(ds, tb, sequence, infer_all):
 
 
 def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
-    """eval.py:189-246."""
+    """eval.py:189-246.  Grayscale evaluation is the one-slot case of eval_method_on_sequences (same pipelined chunk loop);
+    colour evaluation (ColorNet, eval.py:222-232) keeps its own frame loop: no outer pad/crop, no metrics."""
+    if not eval_config.get('color', False):
+        return eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, [sequence], metrics)[0]
     ds = open_sequence(sequence)
-    color = eval_config.get('color', False)
     tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
     model.reset_states()
     infer_all = eval_config.get('eval_infer_all', False)
     post_norm = method_config.get('post_process_norm', "none")
     norm_in = method_config.get('event_tensor_normalization', False)
     tb = ds.table()
-    H, W = ds.sensor_resolution
-
     todo, bad, idx = _plan_items(ds, tb, sequence, infer_all)
-
-    imgs = torch.empty((CHUNK, 1, H, W), dtype=torch.float32, device=ds.device)
     for c0 in range(0, len(todo), CHUNK):
         items = todo[c0:c0 + CHUNK]
         n = len(items)
         grid, stats = ds.voxel_batch(items)
-        if color:
-            # eval.py:222-232 with color: normalise the full tensor, no outer pad/crop, ColorNet splits the streams
-            if post_norm != 'none':
-                raise NotImplementedError("colour evaluation supports post_process_norm='none' only")
-            if norm_in:
-                normalize_event_tensor(grid, stats)
-            bgr = [model(grid[j:j + 1])['image'][0] for j in range(n)]
-            tracker.update_batch_color(items, torch.stack(bgr), [float(v) for v in tb['voxel_timestamp'][items]])
-            for i in items:
-                cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
-                tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
-            continue
-        for j in range(n):
-            model(grid[j:j + 1], stats=stats[j:j + 1] if norm_in else None, out=imgs[j:j + 1])
-        im = imgs[:n, 0]
-        post_process_normalization(im, post_norm)
-        if ds.has_images:
-            refs = ds.frames(tb['frame_index'][items])[:, 0]
-            ref_ts = [float(v) for v in tb['frame_timestamp'][items]]
-        else:
-            refs, ref_ts = None, None
-        tracker.update_batch(items, im, refs, [float(v) for v in tb['voxel_timestamp'][items]], ref_ts)
+        # eval.py:222-232 with color: normalise the full tensor, no outer pad/crop, ColorNet splits the streams
+        if post_norm != 'none':
+            raise NotImplementedError("colour evaluation supports post_process_norm='none' only")
+        if norm_in:
+            normalize_event_tensor(grid, stats)
+        bgr = [model(grid[j:j + 1])['image'][0] for j in range(n)]
+        tracker.update_batch_color(items, torch.stack(bgr), [float(v) for v in tb['voxel_timestamp'][items]])
         for i in items:
             cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
             tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
     tracker.finalize(idx)
     ds.raise_if_dropped()       # once per sequence: out-of-sensor events the kernel dropped (the reference raises)
-    if hasattr(model, 'warn_if_saturated'):
-        model.warn_if_saturated(sequence['name'])
     if bad is not None:
         raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
             int(tb['idx0'][bad]), int(tb['idx1'][bad]), ds.num_events))
     return tracker.get_num_quan_evaluations(), tracker.get_mean_scores()
+
+
+class _ChunkBuffers:
+    """Device + pinned host buffers of one in-flight chunk (the frame loop keeps two: while the host books chunk c, the
+    GPU already works on chunk c + 1)."""
+
+    def __init__(self, S, B, H, W, dev, want_scores, want_lpips, want_u8, with_refs):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.grid = torch.empty((CHUNK, S, B, H, W), **f32)
+        self.stats = torch.zeros((CHUNK, S, 3), dtype=torch.float64, device=dev)
+        self.imgs = torch.empty((CHUNK, S, 1, H, W), **f32)
+        self.refs = torch.zeros((CHUNK, S, H, W), **f32) if with_refs else None
+        self.scores = torch.zeros((CHUNK * S, 2), dtype=torch.float64, device=dev) if want_scores else None
+        self.lp = torch.zeros((CHUNK * S,), dtype=torch.float64, device=dev) if want_lpips else None
+        self.h_scores = torch.empty((CHUNK * S, 2), dtype=torch.float64).pin_memory() if want_scores else None
+        self.h_lp = torch.empty((CHUNK * S,), dtype=torch.float64).pin_memory() if want_lpips else None
+        self.u8 = torch.empty((CHUNK, S, H, W), dtype=torch.uint8, device=dev) if want_u8 else None
+        self.h_u8 = torch.empty((CHUNK, S, H, W), dtype=torch.uint8).pin_memory() if want_u8 else None
+        self.ev_model = torch.cuda.Event()
+        self.ev_done = None
+        self.items = None
+        self.n = 0
 
 
 def eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, sequences, metrics):
@@ -223,7 +226,16 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     owns one batch slot of the recurrent network (slots are independent: state, normalisation statistics, metrics), so
     the results equal one eval_method_on_sequence call per sequence, but a frame of batch S costs far less than S
     frames of batch 1 (the batch-1 step is bound by kernel latency, not by the chip).  Not for colour evaluation.
+
+    The loop is a two-deep pipeline over chunks of CHUNK steps: ONE tensorizer launch voxelizes the chunk's windows of all
+    slots (their events share one resident array, dataset.SequenceBatch) straight into the step-major batch tensor; the
+    network steps run back to back on the main stream; post-normalisation, MSE/SSIM/LPIPS of every frame of the chunk and
+    the uint8 conversion for the PNG writers run on a second HIP stream (as pipeline.HotPath does per step) and land in
+    pinned host memory; the host books chunk c (text files, PNG pool) while the GPU is already inside chunk c + 1.
     Returns [(num_evaluated, mean_scores)] in the order of `sequences`."""
+    from .dataset import SequenceBatch
+    import time as _time
+    _t = {'setup': -_time.perf_counter(), 'enqueue': 0.0, 'book': 0.0, 'finalize': 0.0}
     S = len(sequences)
     dss = [open_sequence(q) for q in sequences]
     trackers = [get_eval_metrics_tracker(dataset_name, eval_config, method_name, q, metrics) for q in sequences]
@@ -231,51 +243,106 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     post_norm = method_config.get('post_process_norm', "none")
     norm_in = method_config.get('event_tensor_normalization', False)
     tbs = [ds.table() for ds in dss]
-    H, W = dss[0].sensor_resolution
-    assert all(tuple(ds.sensor_resolution) == (H, W) for ds in dss), "batched sequences must share the sensor size"
+    batch = SequenceBatch(dss)
+    H, W, dev = batch.H, batch.W, batch.device
     plans = [_plan_items(ds, tb, q, infer_all) for ds, tb, q in zip(dss, tbs, sequences)]
-    dev = dss[0].device
     model.reset_states()
     steps = max((len(p[0]) for p in plans), default=0)
-    imgs = torch.empty((CHUNK, S, 1, H, W), dtype=torch.float32, device=dev)
-    batch, stats = None, torch.zeros((S, 3), dtype=torch.float64, device=dev)
-    for c0 in range(0, steps, CHUNK):
+    # what the frame loop computes for whole chunks (every tracker of a dataset is configured alike)
+    pre = trackers[0].wants_precomputed() if all(ds.has_images for ds in dss) else []
+    want_u8 = trackers[0].save_images
+    lp_model = EvalMetricsTracker._lpips_model() if 'lpips' in pre else None
+    gpu_metrics = trackers[0]._gpu
+    bufs = [_ChunkBuffers(S, batch.num_bins, H, W, dev, bool(set(pre) & {'mse', 'ssim'}), lp_model is not None, want_u8,
+                          all(ds.has_images for ds in dss)) for _ in range(2)]
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+
+    def enqueue(c0, b):
         items = [p[0][c0:c0 + CHUNK] for p in plans]
-        vox = [ds.voxel_batch(it) if it else None for ds, it in zip(dss, items)]
-        for i in range(max(len(it) for it in items)):
-            for j in range(S):
-                if i < len(items[j]):
-                    g = vox[j][0][i]
-                    if batch is None:
-                        batch = torch.zeros((S,) + tuple(g.shape), dtype=torch.float32, device=dev)
-                    batch[j].copy_(g); stats[j].copy_(vox[j][1][i])
-                elif batch is not None:
-                    batch[j].zero_(); stats[j].zero_()          # an exhausted slot idles on empty windows
-            model(batch, stats=stats if norm_in else None, out=imgs[i])
+        if b.ev_done is not None:
+            main.wait_event(b.ev_done)              # the evaluation of the chunk that used these buffers has finished
+        n = batch.voxel_steps(items, b.grid, b.stats)
+        for i in range(n):
+            model(b.grid[i], stats=b.stats[i] if norm_in else None, out=b.imgs[i])
+        b.ev_model.record(main)
+        b.items, b.n = items, n
+        with torch.cuda.stream(side):
+            side.wait_event(b.ev_model)
+            im = b.imgs[:n].view(n * S, H, W)
+            post_process_normalization(im, post_norm)
+            if b.refs is not None:
+                for j, (ds, it) in enumerate(zip(dss, items)):
+                    if it:
+                        b.refs[:len(it), j] = ds.frames(tbs[j]['frame_index'][it])[:, 0]
+                rf = b.refs[:n].view(n * S, H, W)
+                if b.scores is not None:
+                    b.scores[:n * S].copy_(gpu_metrics(im, rf, mse='mse' in pre, ssim='ssim' in pre, clip=True))
+                    b.h_scores[:n * S].copy_(b.scores[:n * S], non_blocking=True)
+                if b.lp is not None:
+                    b.lp[:n * S].copy_(lp_model(im, rf, clip=True))
+                    b.h_lp[:n * S].copy_(b.lp[:n * S], non_blocking=True)
+            if b.u8 is not None:
+                b.u8[:n].copy_(torch.round(torch.clamp(b.imgs[:n, :, 0], 0.0, 1.0) * 255))     # eval_utils.py:83
+                b.h_u8[:n].copy_(b.u8[:n], non_blocking=True)
+            b.ev_done = torch.cuda.Event(); b.ev_done.record(side)
+
+    def book(b):
+        b.ev_done.synchronize()
+        n = b.n
+        sc = b.h_scores[:n * S].numpy().reshape(n, S, 2) if b.h_scores is not None else None
+        lp = b.h_lp[:n * S].numpy().reshape(n, S) if b.h_lp is not None else None
         for j in range(S):
-            it = items[j]
+            it = b.items[j]
             if not it:
                 continue
-            tb, ds = tbs[j], dss[j]
-            im = imgs[:len(it), j, 0].contiguous()
-            post_process_normalization(im, post_norm)
+            tb, ds, k = tbs[j], dss[j], len(it)
+            scores = None
+            if pre:
+                scores = {}
+                if 'mse' in pre: scores['mse'] = sc[:k, j, 0].copy()
+                if 'ssim' in pre: scores['ssim'] = sc[:k, j, 1].copy()
+                if 'lpips' in pre and lp is not None: scores['lpips'] = lp[:k, j].copy()
+            u8 = b.h_u8[:k, j].numpy().copy() if b.h_u8 is not None else None
             if ds.has_images:
-                refs = ds.frames(tb['frame_index'][it])[:, 0]
+                refs = b.refs[:k, j] if b.refs is not None else ds.frames(tb['frame_index'][it])[:, 0]
                 ref_ts = [float(v) for v in tb['frame_timestamp'][it]]
             else:
                 refs, ref_ts = None, None
-            trackers[j].update_batch(it, im, refs, [float(v) for v in tb['voxel_timestamp'][it]], ref_ts)
+            trackers[j].update_batch(it, b.imgs[:k, j, 0], refs, [float(v) for v in tb['voxel_timestamp'][it]], ref_ts,
+                                     scores=scores, u8=u8)
             for i in it:
                 cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
                 trackers[j].save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
+
+    _t['setup'] += _time.perf_counter()
+    prev = None
+    for k, c0 in enumerate(range(0, steps, CHUNK)):
+        b = bufs[k & 1]
+        t0 = _time.perf_counter()
+        enqueue(c0, b)
+        t1 = _time.perf_counter()
+        if prev is not None:
+            book(prev)
+        _t['enqueue'] += t1 - t0; _t['book'] += _time.perf_counter() - t1
+        prev = b
+    t1 = _time.perf_counter()
+    if prev is not None:
+        book(prev)
+    _t['book'] += _time.perf_counter() - t1
+    main.wait_stream(side)
+    t1 = _time.perf_counter()
     out = []
     for j in range(S):
         trackers[j].finalize(plans[j][2])
         out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
+    _t['finalize'] = _time.perf_counter() - t1
+    if os.environ.get('EVR_EVAL_TIMING'):
+        print('[evreal_amd.eval] host seconds: ' + ', '.join(f'{k} {v:.3f}' for k, v in _t.items()) + f' ({S} sequences, {steps} steps)', file=sys.stderr)
     if hasattr(model, 'warn_if_saturated'):
         model.warn_if_saturated(', '.join(q['name'] for q in sequences))
+    batch.raise_if_dropped()
     for j in range(S):      # the reference raises inside the sequence loop: same message, after the files are written
-        dss[j].raise_if_dropped()
         bad = plans[j][1]
         if bad is not None:
             raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(

@@ -279,22 +279,31 @@ class EvalMetricsTracker:
                          zip(self.quan_eval_indices[-n:], metric.get_last_scores(n)))
 
     # -- per batch ----------------------------------------------------------------------------
-    def update_batch(self, indices, imgs, refs, img_ts, ref_ts):
+    def wants_precomputed(self):
+        """Names of the GPU metrics a frame loop may compute for a whole chunk itself and hand to update_batch(scores=...):
+        only when no histogram equalisation stands between the frames and the scores."""
+        if self.hist_eq != 'none' or self.color or not self.has_reference_frames:
+            return []
+        return [m.name for m in self.metrics if getattr(m, 'on_gpu', False)]
+
+    def update_batch(self, indices, imgs, refs, img_ts, ref_ts, scores=None, u8=None):
         """indices: dataset indices; imgs [n,H,W] cuda (unclipped); refs [n,H,W] cuda or None;
-        img_ts / ref_ts: python floats per frame (ref_ts None -> img_ts)."""
+        img_ts / ref_ts: python floats per frame (ref_ts None -> img_ts).
+        scores: optional {metric name: numpy [n]} already computed for EVERY frame of this call (see wants_precomputed);
+        u8: optional numpy uint8 [n,H,W] = round(clip(imgs)*255), already on the host, for the PNG writers."""
         try:
-            self._update_batch(indices, imgs, refs, img_ts, ref_ts)
+            self._update_batch(indices, imgs, refs, img_ts, ref_ts, scores, u8)
         finally:
             for f in self._files.values():      # one write per file per batch reaches the OS even if a later frame raises
                 f.flush()
 
-    def _update_batch(self, indices, imgs, refs, img_ts, ref_ts):
+    def _update_batch(self, indices, imgs, refs, img_ts, ref_ts, pre=None, u8=None):
         n = len(indices)
         if ref_ts is None:
             ref_ts = img_ts
         self._append(join(self.output_dir, 'timestamps.txt'), zip(indices, img_ts), '{} {:.15f}\n')
         if self.save_images:
-            self._save_pngs(self.output_dir, indices, imgs)        # clipped inside; BEFORE hist-eq (eval_metrics.py:257-258)
+            self._save_pngs(self.output_dir, indices, imgs, u8)    # clipped inside; BEFORE hist-eq (eval_metrics.py:257-258)
         sel = []
         for j in range(n):
             inside = self.start <= img_ts[j] <= self.end
@@ -312,20 +321,27 @@ class EvalMetricsTracker:
         if not sel or not self.metrics:
             self.quan_eval_indices.extend(indices[j] for j in sel)
             return
-        js = torch.tensor(sel, device=imgs.device)
         idxs = [indices[j] for j in sel]
         gpu = [m for m in self.metrics if getattr(m, 'on_gpu', False)]
         host = [m for m in self.metrics if not getattr(m, 'on_gpu', False)]
-        isel = imgs[js].contiguous()
-        rsel = refs[js].contiguous() if refs is not None else None
+        have_pre = pre is not None and not need_proc and all(m.name in pre for m in gpu)
+        isel = rsel = None
+        if host or (gpu and not have_pre):
+            js = torch.tensor(sel, device=imgs.device)
+            isel = imgs[js].contiguous()
+            rsel = refs[js].contiguous() if refs is not None else None
         if gpu:
             want = {m.name for m in gpu}
-            scores = None
-            if want & set(GPU_METRICS):
-                scores = self._gpu(isel, rsel, mse='mse' in want, ssim='ssim' in want, clip=True).cpu().numpy()
-            lp = self._lpips_model()(isel, rsel, clip=True).cpu().numpy() if 'lpips' in want else None
+            scores = lp = None
+            if not have_pre:
+                if want & set(GPU_METRICS):
+                    scores = self._gpu(isel, rsel, mse='mse' in want, ssim='ssim' in want, clip=True).cpu().numpy()
+                lp = self._lpips_model()(isel, rsel, clip=True).cpu().numpy() if 'lpips' in want else None
             for m in gpu:
-                col = scores[:, 0] if m.name == 'mse' else scores[:, 1] if m.name == 'ssim' else lp
+                if have_pre:
+                    col = np.asarray(pre[m.name])[sel]
+                else:
+                    col = scores[:, 0] if m.name == 'mse' else scores[:, 1] if m.name == 'ssim' else lp
                 m.add(col)
                 self._append(join(self.output_dir, m.name + '.txt'),
                              [(i, float(s)) for i, s in zip(idxs, col) if math.isfinite(s)])
@@ -367,7 +383,7 @@ class EvalMetricsTracker:
     def _writer_pool(cls):
         if cls._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            cls._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('EVREAL_PNG_THREADS', '4')))
+            cls._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('EVREAL_PNG_THREADS', '') or min(16, max(4, (os.cpu_count() or 4) // 2))))
         return cls._pool
 
     def _submit_png(self, path, array, mode):
@@ -379,8 +395,9 @@ class EvalMetricsTracker:
         else:
             self._pending.append(self._writer_pool().submit(job))
 
-    def _save_pngs(self, folder, indices, imgs):
-        u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()     # eval_utils.py:83
+    def _save_pngs(self, folder, indices, imgs, u8=None):
+        if u8 is None:
+            u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()     # eval_utils.py:83
         for i, a in zip(indices, u8):
             self._submit_png(join(folder, 'frame_{:010d}.png'.format(i)), a, 'L')
 

@@ -39,11 +39,11 @@ def test_score_parity_three_significant_figures():
     cpu = [(img[i], [0.075291, 0.023561, 0.25398]) for i in range(4)]
     gpu = [(img[i] + 3e-6, [0.075292, 0.023561, 0.25399]) for i in range(4)]
     p = bench.score_parity(gpu, cpu, ['mse', 'ssim', 'lpips'])
-    assert p['frames'] == 4 and p['all_3sf'] and p['image_gate_1e-4'] and p['image_max_abs_err'] < 1e-5
+    assert p['frames'] == 4 and p['all_3sf'] and p['image_gate_ok'] and p['image_max_abs_err'] < 1e-5
     assert p['mse']['3sf'] and p['mse']['rel_err'] < 2e-5
     bad = [(img[i] + 1e-3, [0.0761, 0.0236, 0.254]) for i in range(4)]
     q = bench.score_parity(bad, cpu, ['mse', 'ssim', 'lpips'])
-    assert not q['mse']['3sf'] and not q['all_3sf'] and not q['image_gate_1e-4']
+    assert not q['mse']['3sf'] and not q['all_3sf'] and not q['image_gate_ok']
     assert bench.sig3(0.0752905513) == 0.0753 and bench.sig3(1234.5) == 1230.0
 
 

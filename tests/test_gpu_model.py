@@ -339,11 +339,14 @@ def test_large_activations_are_reported_not_silent():
             assert np.isfinite(img).all()
             worst = max(worst, float(np.abs(img - want).max()))
         runs, layer = m.saturation()
-        if scale == 30.0 or exact:
+        loose = {30.0: 1e-4, 300.0: 1e-3, 1e5: 5e-2}[scale]      # fp32 itself: summation-order differences grow with the magnitude
+        if exact:
+            assert runs == 0 and worst < loose, (scale, runs, layer, worst)
+        elif scale == 30.0:
             assert runs == 0 and worst < 1e-4, (scale, runs, layer, worst)
         else:
             assert worst < 1e-4 or runs > 0, (scale, runs, layer, worst)       # never a silent degradation
             if runs:
                 assert layer != ''
-        if scale == 300.0 and os.environ.get('EVR_ARITH', 'mx') == 'mx' and not exact:
-            assert worst < 1e-3, worst        # PACKED beyond its range: the f16 half alone still carries 2^-12
+            if os.environ.get('EVR_ARITH', 'mx') == 'mx':
+                assert worst < loose, (scale, worst)   # PACKED beyond its range: the f16 half alone still carries 2^-12
