@@ -313,14 +313,16 @@ struct HeadArgs {
     int relu;
     int out_packed;      // write `out` in the PACKED activation format
     int group_store;     //   as whole 64-B groups (see ConvArgs)
-    const void* wfrag;   // k5/32-channel split-bf16 form: weights in MFMA-fragment order (head_mfma_kernel), or null
+    const void* wfrag;   // k5/32-channel matrix-core form: weights in MFMA-fragment order (head_mfma_kernel), or null
+    float wfrag_scale, wfrag_inv_scale;   //   2^-(e_w + H2_ACT_EXP) and its inverse (head_pack_wfrag returns e_w)
     // head_mfma_kernel only: the prediction layer's skip term of every pixel, sum_c pred_w[c] * out[c] (fp32, before the
     // PACKED rounding), so the last decoder reads one float per pixel instead of the 32 channels (ConvArgs::pred_skip_dot)
     const float* pred_w; float* pred_dot;   // [32] / [n, hp, wp], or null
     unsigned* sat;       // optional device counter of output runs beyond the packed format's exact range (packed.h sat_note)
 };
-// weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B)
-void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out);
+// weights [B*k*k][32] (k = 5, B bins) -> the fragment-order table head_mfma_kernel reads (10 slabs x {hi, lo} x 64 lanes x 16 B);
+// returns the weight exponent e_w
+int head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out);
 int launch_head_conv(const HeadArgs& a, hipStream_t stream);
 
 // Prediction layer: 1x1 conv C->1 on (x [+ skip]) + bias [+ sigmoid], centre crop -> planar img [n,1,H,W].

@@ -8,7 +8,7 @@
 namespace evr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Head convolution on the matrix cores (split mode, k = 5, 32 output channels; its K = 125 is too ragged for the f16 + fp8
-// chunks, so this kernel keeps three bf16 products: x = hi + lo, w = hi + lo, acc += hi*hi + hi*lo + lo*hi): GEMM M = pixels, N = 32,
+// Head convolution on the matrix cores (split modes, k = 5, 32 output channels; its K = 125 is too ragged for the 32-channel
+// chunks of the other layers, so this kernel has its own three-f16-product loop in BOTH split modes: x 2^4 = hi + lo,
+// w 2^e = hi + lo in IEEE halves, acc += hi*lo + lo*hi + hi*hi -- 22 significant bits per factor): GEMM M = pixels, N = 32,
 // K = (bin, ky, kx).  The direct VALU kernel above spends 4000 FMAs per pixel (0.65 ms per 64 frames, the HBM
 // floor of its 761-MB output is 0.15 ms); here a pixel costs ~5 instructions per lane.
 //   K order  chosen so the two lane halves of an MFMA operand differ by ONE LDS row: the 5 kernel rows are padded
@@ -191,8 +192,12 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
             float v = raw[it];
             const bool outside = __float_as_uint(v) == 0x7fc00001u;
             if (outside) v = 0.f; else if (norm) v = norm_apply(v, mean, sd);
-            const unsigned hi = cvt_pk_bf16(v, 0.f) & 0xffffu;
-            const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+            // x 2^H2_ACT_EXP = hi + lo in two IEEE halves (22 significant bits; |v| beyond 4094 is clamped and counted)
+            const float c = __builtin_amdgcn_fmed3f(v * H2_SCALE, -65504.0f, 65504.0f);
+            if (fabsf(v) > 65504.0f / H2_SCALE && a.sat) atomicAdd(a.sat, 1u);
+            const _Float16 hh = (_Float16)c;
+            const _Float16 ll = (_Float16)(c - (float)hh);
+            const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, hh), lo = (unsigned)__builtin_bit_cast(unsigned short, ll);
             if (i < a.B * PLANE) htile[i] = hi | (lo << 16);
         }
         __syncthreads();
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j];
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j] * a.wfrag_inv_scale;      // products accumulate at 2^(e_w + H2_ACT_EXP)
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
                 unsigned e[8];
@@ -221,12 +226,14 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
                     ah[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
                     al[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
                 }
-                const bf16x8 a_hi = __builtin_bit_cast(bf16x8, ah), a_lo = __builtin_bit_cast(bf16x8, al);
-                const bf16x8 b_hi = __builtin_bit_cast(bf16x8, w_hi[s]), b_lo = __builtin_bit_cast(bf16x8, w_lo[s]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi, acc, 0, 0, 0);
+                const f16x8 a_hi = __builtin_bit_cast(f16x8, ah), a_lo = __builtin_bit_cast(f16x8, al);
+                const f16x8 b_hi = __builtin_bit_cast(f16x8, w_hi[s]), b_lo = __builtin_bit_cast(f16x8, w_lo[s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= a.wfrag_scale;
             const int oy = ty0 + ty, ox = tx0 + r;
             if (a.relu) {
 #pragma unroll
@@ -247,12 +254,16 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
             if (a.out_packed && a.group_store) {     // the lane pair of a pixel trades runs: each stores one whole 64-B PACKED group
                 float w16[16];
                 xchg16(acc, w16);
-                if (oy < a.hp && ox < a.wp) { sat_check16<1>(a.sat, w16); store16_packed(o, 0u, 16 * h, w16); }
+                if (oy < a.hp && ox < a.wp) {
+                    if (a.out_packed == 2) { sat_check16<2>(a.sat, w16); store16_h2(o, 0u, 16 * h, w16); }
+                    else { sat_check16<1>(a.sat, w16); store16_packed(o, 0u, 16 * h, w16); }
+                }
             } else if (oy < a.hp && ox < a.wp) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
+                    if (a.out_packed == 2) store4_h2(o, 0u, 8 * q + 4 * h, v);
+                    else if (a.out_packed) store4_packed(o, 0u, 8 * q + 4 * h, v);
                     else *(f4*)(o + 8 * q + 4 * h) = v;
                 }
             }
@@ -261,9 +272,16 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
 #endif
 }
 
-void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
-    // out[((2*s + part) * 64 + lane) * 4 + d]: lane = channel c + 32*h; dword d holds k-positions 2d, 2d+1 of the lane's 8
+int head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
+    // out[((2*s + part) * 64 + lane) * 4 + d]: lane = channel c + 32*h; dword d holds k-positions 2d, 2d+1 of the lane's 8.
+    // Values: w 2^e = hi + lo in two IEEE halves, e bringing max|w| to [2^13, 2^14) (conv.h pack_h2_weights' rule); returns e.
     out.assign((size_t)20 * 64 * 4, 0u);
+    float mx = 0.f;
+    for (int i = 0; i < B * 25 * 32; ++i) { const float a = w[i] < 0 ? -w[i] : w[i]; if (a == a && a > mx) mx = a; }
+    int e = 0;
+    if (mx > 0.f) { int ex; (void)__builtin_frexpf(16384.0f / mx, &ex); e = ex - 1; if (__builtin_ldexpf(mx, e) >= 16384.0f) --e; }
+    if (e > 40) e = 40;
+    if (e < -40) e = -40;
     for (int s = 0; s < 10; ++s)
         for (int lane = 0; lane < 64; ++lane) {
             const int c = lane & 31, h = lane >> 5;
@@ -274,11 +292,13 @@ void head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
                     const int b = el / 15, rem = el % 15, ky = 2 * (rem / 5) + h, kx = rem % 5;
                     if (ky <= 4) v = w[((size_t)(b * 5 + ky) * 5 + kx) * 32 + c];
                 }
-                const unsigned short hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                const float vs = __builtin_ldexpf(v, e);
+                const unsigned short hi = f16_rne(vs), lo = f16_rne(vs - f16_to_f32(hi));
                 out[((size_t)(2 * s) * 64 + lane) * 4 + j / 2] |= (unsigned)hi << (16 * (j & 1));
                 out[((size_t)(2 * s + 1) * 64 + lane) * 4 + j / 2] |= (unsigned)lo << (16 * (j & 1));
             }
         }
+    return e;
 }
 
 int launch_head_conv(const HeadArgs& a, hipStream_t stream) {

@@ -89,7 +89,8 @@ struct evr_model {
     std::vector<float> head_w, head_b, pred_w;
     float pred_b = 0.f;
     float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
-    unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split-bf16 mode, k5 x 5 bins x 32 channels)
+    unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split modes, k5 x 5 bins x 32 channels)
+    int head_wfrag_e = 0;               //   and their exponent (head_pack_wfrag)
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
     bool packed = false;   // split mode: tensors between matrix-core convolutions use the PACKED format
@@ -469,9 +470,9 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
     if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
-    if (arith_mode() == 2 && B == 5 && k == 5 && C == 32) {
+    if (arith_mode() != 0 && B == 5 && k == 5 && C == 32) {
         std::vector<unsigned> wf;
-        head_pack_wfrag(m->head_w.data(), B, wf);
+        m->head_wfrag_e = head_pack_wfrag(m->head_w.data(), B, wf);
         EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
         EVR_HIP(hipMemcpy(m->d_head_wfrag, wf.data(), wf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
@@ -625,9 +626,9 @@ int build_spade(evr_model* m) {
         }
         if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
         if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
-        if (arith_mode() == 2) {
+        if (arith_mode() != 0) {
             std::vector<unsigned> wf;
-            head_pack_wfrag(m->head_w.data(), 5, wf);
+            m->head_wfrag_e = head_pack_wfrag(m->head_w.data(), 5, wf);
             EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
             EVR_HIP(hipMemcpy(m->d_head_wfrag, wf.data(), wf.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         }
@@ -860,7 +861,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;      // matrix-core head conv in split-bf16 mode
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;      // matrix-core head conv in the split modes
 
     // x[p]: current activation pointer per parity
     const float* x[2] = {head.p, head.p};
@@ -1105,7 +1106,7 @@ int plan_spade(evr_model* m, hipStream_t stream) {
     m->sp_xpad = xpad.p; m->sp_xorg = xorg.p; m->sp_xorg_half = xorgh.p;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
 
     const float* x[2] = {head.p, head.p};
     int h = hp, w = wp;
@@ -1238,7 +1239,7 @@ int plan_etnet(evr_model* m, hipStream_t stream) {
     if ((rc = alloc(m, &head, n, hp, wp, 32, stream, P))) return rc;
     name2(m, "head", head, head);
     m->head.out = head.p; m->head.out_packed = P;
-    m->head.wfrag = (P == 1) ? m->d_head_wfrag : nullptr;
+    m->head.wfrag = P ? m->d_head_wfrag : nullptr;
     const float* x[2] = {head.p, head.p};
     int h = hp, w = wp;
     DevTensor blk[3][2];
@@ -1468,6 +1469,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->head.pad_top = m->pad_top; m->head.pad_left = m->pad_left; m->head.k = m->desc.kernel_size;
     m->head.cout = m->desc.base_num_channels; m->head.wgt = m->d_head_w; m->head.bias = m->d_head_b; m->head.relu = 1;
     m->head.sat = m->d_sat ? m->d_sat + m->convs.size() : nullptr;
+    m->head.wfrag_scale = std::ldexp(1.0f, -(m->head_wfrag_e + H2_ACT_EXP)); m->head.wfrag_inv_scale = std::ldexp(1.0f, m->head_wfrag_e + H2_ACT_EXP);
     const bool spade = m->desc.arch == EVR_ARCH_SPADE_E2VID;
     if (spade) {      // the head convolution reads the explicit padded copy (spade.hip): no padding of its own
         m->head.H = m->hp; m->head.W = m->wp; m->head.pad_top = 0; m->head.pad_left = 0;

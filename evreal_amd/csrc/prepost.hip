@@ -189,68 +189,54 @@ __device__ __forceinline__ unsigned radix_select(const unsigned (&keys)[PCT_MAXR
     return prefix;
 }
 
-template <bool REG>
-__global__ __launch_bounds__(PCT_THREADS) void pct_kernel(float* __restrict__ img, int n, float q_lo, float q_hi,
-                                                           int do_exp) {
+// numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear' (_get_indexes/_get_gamma)
+__device__ __forceinline__ void pct_rank(int n, float q100, int& prev, int& next, float& gamma) {
+    const float q = q100 / 100.0f;
+    const float vi = (float)(n - 1) * q;
+    prev = (int)floorf(vi); next = prev + 1;
+    if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma = vi - (-1.0f); }
+    else if (vi < 0.f) { prev = next = 0; gamma = vi - 0.0f; }
+    else gamma = vi - (float)prev;
+}
+
+// One work-group per (order statistic, image): the four selects a frame needs -- the two neighbours of each percentile's
+// virtual index -- are independent, so they run side by side (4 x n work-groups: a 64-frame batch fills the chip; the
+// single-work-group form walked them one after the other on 64 of 256 CUs).
+__global__ __launch_bounds__(PCT_THREADS) void pct_select_kernel(const float* __restrict__ img, int n, float q_lo, float q_hi,
+                                                                  float* __restrict__ vals) {
     __shared__ PctShared sh;
-    float* v = img + (int64_t)blockIdx.x * n;
+    const int sel = blockIdx.x;
+    const float* v = img + (int64_t)blockIdx.y * n;
     if (threadIdx.x < 4) sh.level_valid[threadIdx.x] = 0;
-    unsigned keys[PCT_MAXR];
-    int cnt = 0;
-    if (REG) {
-        cnt = (n - (int)threadIdx.x + PCT_THREADS - 1) / PCT_THREADS;
-        if (cnt < 0) cnt = 0;
-#pragma unroll
-        for (int j = 0; j < PCT_MAXR; ++j) {
-            const int i = threadIdx.x + j * PCT_THREADS;
-            float x = (i < n) ? v[i] : 0.f;
-            if (do_exp) x = expf(x);          // 'exprobust' (eval.py:391-393)
-            keys[j] = f2key(x);
-        }
-    } else if (do_exp) {
-        for (int i = threadIdx.x; i < n; i += PCT_THREADS) v[i] = expf(v[i]);
-    }
     __syncthreads();
-    // numpy: q = q/100 in the array dtype; virtual index (n-1)*q; method 'linear' (_get_indexes/_get_gamma)
-    int rank[4]; float gamma[2];
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const float q = (which ? q_hi : q_lo) / 100.0f;
-        const float vi = (float)(n - 1) * q;
-        int prev = (int)floorf(vi), next = prev + 1;
-        if (vi >= (float)(n - 1)) { prev = next = n - 1; gamma[which] = vi - (-1.0f); }
-        else if (vi < 0.f) { prev = next = 0; gamma[which] = vi - 0.0f; }
-        else gamma[which] = vi - (float)prev;
-        rank[2 * which] = prev; rank[2 * which + 1] = next;
-    }
-    float val[4];
-#pragma unroll 1
-    for (int sel = 0; sel < 4; ++sel) {     // one inlined copy of the select body (keys stay in registers)
-        const int k = (sel == 0) ? rank[0] : (sel == 1) ? rank[1] : (sel == 2) ? rank[2] : rank[3];
-        const float x = key2f(radix_select<REG>(keys, cnt, v, n, k, sh));
-        if (sel == 0) val[0] = x; else if (sel == 1) val[1] = x; else if (sel == 2) val[2] = x; else val[3] = x;
-    }
+    int prev, next; float gamma;
+    pct_rank(n, (sel & 2) ? q_hi : q_lo, prev, next, gamma);
+    const unsigned keys[PCT_MAXR] = {0u};
+    const float x = key2f(radix_select<false>(keys, 0, v, n, (sel & 1) ? next : prev, sh));
+    if (threadIdx.x == 0) vals[(int64_t)blockIdx.y * 4 + sel] = x;
+}
+
+__global__ __launch_bounds__(256) void pct_exp_kernel(float* __restrict__ img, int64_t total) {      // 'exprobust' (eval.py:391-393)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) img[i] = expf(img[i]);
+}
+
+__global__ __launch_bounds__(256) void pct_apply_kernel(float* __restrict__ img, int n, float q_lo, float q_hi,
+                                                         const float* __restrict__ vals) {
+    float* v = img + (int64_t)blockIdx.y * n;
+    const float* val = vals + (int64_t)blockIdx.y * 4;
     float res[2];
 #pragma unroll
     for (int which = 0; which < 2; ++which) {   // numpy _lerp
+        int prev, next; float gamma;
+        pct_rank(n, which ? q_hi : q_lo, prev, next, gamma);
         const float a = val[2 * which], b = val[2 * which + 1];
         const float diff = b - a;
-        float r = a + diff * gamma[which];
-        if (gamma[which] >= 0.5f) r = b - diff * (1.0f - gamma[which]);
+        float r = a + diff * gamma;
+        if (gamma >= 0.5f) r = b - diff * (1.0f - gamma);
         res[which] = r;
     }
-    if (threadIdx.x == 0) { sh.lohi[0] = res[0]; sh.lohi[1] = res[1]; }
-    __syncthreads();
-    const float lo = sh.lohi[0], range = sh.lohi[1] - sh.lohi[0];
-    if (REG) {
-#pragma unroll
-        for (int j = 0; j < PCT_MAXR; ++j) {
-            const int i = threadIdx.x + j * PCT_THREADS;
-            if (i < n) { const float d = key2f(keys[j]) - lo; v[i] = d / range; }
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += PCT_THREADS) { const float d = v[i] - lo; v[i] = d / range; }
-    }
+    const float lo = res[0], range = res[1] - res[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const float d = v[i] - lo; v[i] = d / range; }
 }
 
 }  // namespace
@@ -283,19 +269,36 @@ extern "C" int evr_event_tensor_normalize(float* vox, int n, int B, int H, int W
 }
 
 extern "C" size_t evr_percentile_normalize_workspace_bytes(int n, int H, int W) {
-    (void)n; (void)H; (void)W;
-    return 0;
+    (void)H; (void)W;
+    return n > 0 ? (size_t)n * 4 * sizeof(float) : 0;      // the four order statistics of every image
 }
 
 extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q_lo, float q_hi, int do_exp,
-                                        void* workspace, size_t workspace_bytes, evr_stream_t stream) {
-    (void)workspace; (void)workspace_bytes;
+                                        void* workspace, size_t workspace_bytes, evr_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     EVR_REQUIRE(n >= 0 && H >= 1 && W >= 1, "evr_percentile_normalize: bad shape");
     EVR_REQUIRE(q_lo >= 0.f && q_hi <= 100.f && q_lo <= q_hi, "evr_percentile_normalize: percentiles must be in [0,100]");
     EVR_REQUIRE((int64_t)H * W < (1LL << 30), "evr_percentile_normalize: image too large");
     if (n == 0) return EVR_OK;
     EVR_REQUIRE(img != nullptr, "evr_percentile_normalize: null image");
-    hipLaunchKernelGGL(pct_kernel<false>, dim3(n), dim3(PCT_THREADS), 0, (hipStream_t)stream, img, H * W, q_lo, q_hi, do_exp);
+    const size_t need = evr_percentile_normalize_workspace_bytes(n, H, W);
+    if (!workspace || workspace_bytes < need) {
+        evr::set_error("evr_percentile_normalize: workspace %zu B < required %zu B", workspace_bytes, need);
+        return EVR_ERR_WORKSPACE;
+    }
+    const int px = H * W;
+    if (do_exp) {
+        const int64_t total = (int64_t)n * px;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(pct_exp_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, img, total);
+        EVR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(pct_select_kernel, dim3(4, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace);
+    EVR_LAUNCH_CHECK();
+    int gx = (px + 256 * 8 - 1) / (256 * 8);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(pct_apply_kernel, dim3(gx, n), dim3(256), 0, stream, img, px, q_lo, q_hi, (const float*)workspace);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

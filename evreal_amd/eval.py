@@ -32,6 +32,7 @@ from .lib import EvrError
 from .prepost import normalize_event_tensor, post_process_normalization
 
 CHUNK = 16   # windows voxelised / frames scored per launch
+TIMINGS = []  # host seconds of every eval_method_on_sequences call {setup, enqueue, book, finalize, frames, sequences} (bench.py reads it)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -337,6 +338,8 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
         trackers[j].finalize(plans[j][2])
         out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
     _t['finalize'] = _time.perf_counter() - t1
+    TIMINGS.append(dict(_t, frames=sum(len(p[0]) for p in plans), sequences=S))
+    del TIMINGS[:-64]
     if os.environ.get('EVR_EVAL_TIMING'):
         print('[evreal_amd.eval] host seconds: ' + ', '.join(f'{k} {v:.3f}' for k, v in _t.items()) + f' ({S} sequences, {steps} steps)', file=sys.stderr)
     if hasattr(model, 'warn_if_saturated'):

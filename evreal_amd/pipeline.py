@@ -39,6 +39,7 @@ class HotPath:
             self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
             self.k = 0
         self._vox_events = None
+        self._ring, self._ring_stats, self._ring_pos, self._ring_len = None, None, 0, 0
         model.reset_states()
 
     def _side_stream(self):
@@ -85,17 +86,44 @@ class HotPath:
             self._vox_events.append((e0, e1))
         return self._rest(ref, scores_out)
 
+    # -- tensorizer look-ahead ---------------------------------------------------------------------------------------
+    # Windows do not depend on the recurrence, so the tensorizer may run for several steps at once: ONE launch over
+    # A x n_seq windows (its kernels reach a higher fraction of the HBM roof on 512 windows than on 64) fills a
+    # ring of voxel grids that the following A steps consume.
+    def prefetch_raw(self, xy, ts, pol, win_offsets, n_steps):
+        """win_offsets: int64 [n_steps * n_seq + 1], the windows of the next n_steps steps in step-major order."""
+        if self._ring is None or self._ring.shape[0] < n_steps:
+            self._ring = torch.empty((n_steps, self.n, self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
+            self._ring_stats = torch.zeros((n_steps, self.n, 3), dtype=torch.float64, device=self.dev)
+        assert int(win_offsets.numel()) == n_steps * self.n + 1
+        if self._vox_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W),
+                              out=self._ring[:n_steps].view(n_steps * self.n, self.B, self.H, self.W),
+                              stats=self._ring_stats[:n_steps].view(n_steps * self.n, 3))
+        if self._vox_events is not None:
+            e1.record()
+            self._vox_events.append((e0, e1))
+        self._ring_pos, self._ring_len = 0, n_steps
+
+    def step_ahead(self, ref=None, scores_out=None):
+        """One frame for every sequence from the next prefetched voxel grid."""
+        assert self._ring is not None and self._ring_pos < self._ring_len, "step_ahead without a prefetched window"
+        i = self._ring_pos; self._ring_pos += 1
+        return self._rest(ref, scores_out, self._ring[i], self._ring_stats[i])
+
     def step(self, x, y, t, p, win_offsets, ref=None, scores_out=None):
         self.vox.voxelize(x, y, t, p, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
         return self._rest(ref, scores_out)
 
-    def _rest_overlapped(self, ref, scores_out):
+    def _rest_overlapped(self, ref, scores_out, grid, stats):
         k = self.k; self.k ^= 1
         main = torch.cuda.current_stream(self.dev)
         img = self.imgs[k]
         if self.ev_done[k] is not None:
             main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (two frames ago)
-        self.model(self.grid, stats=self.stats if self.norm_in else None, out=img)
+        self.model(grid, stats=stats if self.norm_in else None, out=img)
         self.ev_model[k].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_model[k])
@@ -111,10 +139,12 @@ class HotPath:
             ev = torch.cuda.Event(); ev.record(self.side); self.ev_done[k] = ev
         return img, scores_out
 
-    def _rest(self, ref, scores_out):
+    def _rest(self, ref, scores_out, grid=None, stats=None):
+        grid = self.grid if grid is None else grid
+        stats = self.stats if stats is None else stats
         if self.overlap:
-            return self._rest_overlapped(ref, scores_out)
-        self.model(self.grid, stats=self.stats if self.norm_in else None, out=self.img)
+            return self._rest_overlapped(ref, scores_out, grid, stats)
+        self.model(grid, stats=stats if self.norm_in else None, out=self.img)
         im = self.img.view(self.n, self.H, self.W)
         if self.post != 'none':
             post_process_normalization(im, self.post)

@@ -29,8 +29,9 @@ def post_process_normalization(img, norm):
     v = img if img.dim() == 3 else img.unsqueeze(0)
     n, H, W = v.shape
     q = (0.0, 100.0) if norm == 'standard' else (1.0, 99.0)
+    ws = torch.empty(max(int(lib.evr_percentile_normalize_workspace_bytes(n, H, W)), 16) // 4, dtype=torch.float32, device=img.device)
     _lib.check(lib.evr_percentile_normalize(_lib.ptr(v), n, H, W, q[0], q[1], 1 if norm == 'exprobust' else 0,
-                                            None, 0, _lib.stream_ptr()), 'evr_percentile_normalize')
+                                            _lib.ptr(ws), ws.numel() * 4, _lib.stream_ptr()), 'evr_percentile_normalize')
     return img
 
 

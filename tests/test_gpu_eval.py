@@ -92,10 +92,13 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
     seen = {}
     orig = em.EvalMetricsTracker._save_pngs
 
-    def spy(self, folder, indices, imgs):          # what the tracker was asked to write, as host arrays
+    def spy(self, folder, indices, imgs, u8=None):          # what the tracker was asked to write, as host arrays
         for i, a in zip(indices, imgs.detach().cpu().numpy()):
             seen[os.path.join(folder, 'frame_{:010d}.png'.format(i))] = a.copy()
-        return orig(self, folder, indices, imgs)
+        if u8 is not None:          # the frame loop's own uint8 conversion must be the tracker's (eval_utils.py:83)
+            want = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()
+            assert np.array_equal(np.asarray(u8), want)
+        return orig(self, folder, indices, imgs, u8)
     monkeypatch.setattr(em.EvalMetricsTracker, '_save_pngs', spy)
     digests = {}
     for mode in ('async', 'sync'):
