@@ -669,7 +669,9 @@ def main():
         flops_step = net.flops_per_step()
         # `achieved` counts ALGORITHMIC (direct convolution) flops in every mode; in the split modes the matrix pipe is busy
         # for ISSUE_FACTOR x that in f16-rate cycles (mfma_issue_*); `peak` is the dense f16/bf16 (fp32: fp32) MFMA peak.
-        fp32_net = (an == 'fp32') or wl.name == 'firenet'          # FireNet's 16-channel layers run the exact fp32 MFMA in every mode
+        # FireNet's 16-channel layers run the exact fp32 MFMA in every mode (EVR_FIRENET_PAD32=1: zero-padded to one 32-channel
+        # chunk on the split kernels -- slower, kept for exercising them on trained weights; csrc/model.cpp build_firenet)
+        fp32_net = (an == 'fp32') or (wl.name == 'firenet' and os.environ.get('EVR_FIRENET_PAD32', '0') in ('', '0'))
         peak = PEAK_F32_MFMA_TFLOPS if fp32_net else PEAK_BF16_MFMA_TFLOPS
         issue = 1.0 if fp32_net else ISSUE_FACTOR[an]
         if wl.name == 'e2vid':

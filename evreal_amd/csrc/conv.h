@@ -314,7 +314,7 @@ struct HeadArgs {
     int out_packed;      // write `out` in the PACKED activation format
     int group_store;     //   as whole 64-B groups (see ConvArgs)
     const void* wfrag;   // k5/32-channel matrix-core form: weights in MFMA-fragment order (head_mfma_kernel), or null
-    float wfrag_scale, wfrag_inv_scale;   //   2^-(e_w + H2_ACT_EXP) and its inverse (head_pack_wfrag returns e_w)
+    float wfrag_scale, wfrag_inv_scale;   //   2^-e_w and its inverse (head_pack_wfrag returns e_w; the input is used unscaled)
     // head_mfma_kernel only: the prediction layer's skip term of every pixel, sum_c pred_w[c] * out[c] (fp32, before the
     // PACKED rounding), so the last decoder reads one float per pixel instead of the 32 channels (ConvArgs::pred_skip_dot)
     const float* pred_w; float* pred_dot;   // [32] / [n, hp, wp], or null
@@ -389,6 +389,7 @@ int launch_mean6(const float* const* in, float* out, int64_t rows, int out_packe
 int launch_instnorm(const float* x, const float* res, const float* skip, float* out, int n, int hw, int c, int res_packed,
                     int skip_packed, int out_packed, hipStream_t stream);
 // NHWC -> NCHW copy (debug/parity reads)
-int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream);
+// (c_stride: channels per pixel row of `src` when only its first c are wanted; 0 = c)
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream, int c_stride = 0);
 
 }  // namespace evr

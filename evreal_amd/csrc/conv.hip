@@ -464,7 +464,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
 // X3: 0 = fp32 MFMA; 2 = split arithmetic on PACKED activations (1, splitting PLAIN activations in registers, is gone:
 // VALU kernels that feed a matrix-core convolution write PACKED themselves)
 template <int KC, int WM, int NB, bool LSTM, bool GROUPED, bool REGSTAGE = false, int X3 = 0>
-__global__ __launch_bounds__(64 * WM, (X3 == 0 || WM != 4) ? 1 : (NB >= 2 ? 2 : 3)) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+__global__ __launch_bounds__(64 * WM, (X3 == 0) ? ((WM == 4 && !LSTM) ? 2 : 1) : (WM != 4 ? 1 : (NB >= 2 ? 2 : 3))) void conv_igemm_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;   // plan resident in device memory: wave-uniform -> scalar loads
     constexpr int SP = KC / 4;                 // 16-B slots per row
@@ -604,7 +604,9 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0 || WM != 4) ? 1 : (NB >= 2 ? 2 : 
     f32x16 pre[PN];   // (ext-vector like acc: a plain 2-D float array was demoted to scratch by hipcc)
     EpiCtx ec;
     // (split mode: only the ConvLSTM cell state is requested a main loop early -- see conv3x3_band_kernel)
-    constexpr bool EARLY = LSTM || X3 == 0;
+    // (fp32 mode, NB = 4: the 64 operand registers parked across the main loop pushed these kernels to 229 + 64 registers = one
+    // wave per SIMD; loaded in the epilogue instead they fit two blocks per CU -- the fp32 mode's non-ConvLSTM layers)
+    constexpr bool EARLY = LSTM || (X3 == 0 && NB < 4);
     epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, acc, pre, ec, true, EARLY);
     const int ablate = a.debug_ablate;   // timing ablation (EVR_ABLATE): results are garbage when non-zero
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;

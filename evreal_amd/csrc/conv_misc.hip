@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // Head convolution on the matrix cores (split modes, k = 5, 32 output channels; its K = 125 is too ragged for the 32-channel
-// chunks of the other layers, so this kernel has its own three-f16-product loop in BOTH split modes: x 2^4 = hi + lo,
+// chunks of the other layers, so this kernel has its own three-f16-product loop in BOTH split modes: x = hi + lo,
 // w 2^e = hi + lo in IEEE halves, acc += hi*lo + lo*hi + hi*hi -- 22 significant bits per factor): GEMM M = pixels, N = 32,
 // K = (bin, ky, kx).  The direct VALU kernel above spends 4000 FMAs per pixel (0.65 ms per 64 frames, the HBM
 // floor of its 761-MB output is 0.15 ms); here a pixel costs ~5 instructions per lane.
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
             float v = raw[it];
             const bool outside = __float_as_uint(v) == 0x7fc00001u;
             if (outside) v = 0.f; else if (norm) v = norm_apply(v, mean, sd);
-            // x 2^H2_ACT_EXP = hi + lo in two IEEE halves (22 significant bits; |v| beyond 4094 is clamped and counted)
-            const float c = __builtin_amdgcn_fmed3f(v * H2_SCALE, -65504.0f, 65504.0f);
-            if (fabsf(v) > 65504.0f / H2_SCALE && a.sat) atomicAdd(a.sat, 1u);
+            // v = hi + lo in two IEEE halves, UNSCALED: the f16 MFMA honours subnormal operands (tools/mfma_denorm_probe.hip),
+            // so small inputs keep an absolute 2^-25 and the range is the half's own +-65504 (beyond: clamped and counted)
+            const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+            if (fabsf(v) > 65504.0f && a.sat) atomicAdd(a.sat, 1u);
             const _Float16 hh = (_Float16)c;
             const _Float16 ll = (_Float16)(c - (float)hh);
             const unsigned hi = (unsigned)__builtin_bit_cast(unsigned short, hh), lo = (unsigned)__builtin_bit_cast(unsigned short, ll);
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j] * a.wfrag_inv_scale;      // products accumulate at 2^(e_w + H2_ACT_EXP)
+                for (int j = 0; j < 4; ++j) acc[4 * q + j] = bias4[q][j] * a.wfrag_inv_scale;      // products accumulate at 2^e_w
 #pragma unroll
             for (int s = 0; s < 10; ++s) {
                 unsigned e[8];
@@ -530,7 +531,7 @@ int launch_to_packed(const float* src, float* dst, int64_t n, hipStream_t stream
 }
 
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, int packed) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int h, int w, int c, int packed, int cs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)n * h * w * c;
     if (i >= total) return;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     const int y = (int)(p % h); p /= h;
     const int ch = (int)(p % c);
     const int img = (int)(p / c);
-    const float* row = src + (((int64_t)img * h + y) * w + x) * c;
+    const float* row = src + (((int64_t)img * h + y) * w + x) * cs;
     float v = row[ch];
 #if defined(__HIP_DEVICE_COMPILE__)
     if (packed) v = load1_packed(row, ch, packed);
@@ -546,10 +547,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     dst[i] = v;
 }
 
-int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream) {
-    EVR_REQUIRE(!packed || c % 16 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c);
+int launch_nhwc_to_nchw(const float* src, float* dst, int n, int h, int w, int c, int packed, hipStream_t stream, int c_stride) {
+    if (c_stride <= 0) c_stride = c;
+    EVR_REQUIRE(!packed || c_stride % 16 == 0, "nhwc_to_nchw: PACKED tensor with %d channels", c_stride);
     const int64_t total = (int64_t)n * h * w * c;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c, packed);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, dst, n, h, w, c, packed, c_stride);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

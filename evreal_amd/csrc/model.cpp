@@ -38,6 +38,7 @@ struct DevTensor {   // NHWC activation / state
     float* p = nullptr;
     int n = 0, h = 0, w = 0, c = 0;
     bool packed = false;   // PACKED activation format (conv.h): f16 hi | fp8 lo8 | fp8 x8 per 16 channels
+    int c_valid = 0;       // channels evr_model_read_tensor returns (0: all; FireNet's tensors are padded 16 -> 32)
     int64_t numel() const { return (int64_t)n * h * w * c; }
 };
 
@@ -111,6 +112,9 @@ struct evr_model {
     int pred_fused_conv = -1;
     // HyperE2VID dynamic decoder (submodules.py:100-127)
     bool dynamic = false;
+    // FireNet (16 channels) on the split kernels: every 16-channel tensor zero-padded to one 32-channel chunk (build_firenet)
+    int fire_C = 0;
+    std::vector<std::vector<float>> pad_store;
     double dyn_flops = 0.0;   // per launch of the dynamic-filter step (profile table)
     std::vector<float> ctx_w, ctx_b, fb_bases;
     float* d_ctx_w = nullptr; float* d_ctx_b = nullptr; float* d_bases = nullptr;
@@ -448,19 +452,23 @@ int conv_index(const evr_model* m, const std::string& name) {
 }
 
 // head: Conv2d(num_bins -> C, k) [B*k*k][C]; pred: 1x1 C -> 1 (+BN)
-int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::string& pred_prefix, bool pred_bn, int C, bool pred_in = false) {
+// (head_norm: prefix of a norm layer behind the head convolution -- ET-Net's ConvLayer head takes `norm`, u_trans.py:19; empty: none)
+int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::string& pred_prefix, bool pred_bn, int C, bool pred_in = false,
+                   const std::string& head_norm = std::string()) {
     const evr_model_desc& d = m->desc;
     const HostTensor* w; int rc;
     if ((rc = find(m, head_prefix + ".weight", &w))) return rc;
     const int B = d.num_bins, k = d.kernel_size;
     EVR_REQUIRE(w->ndim == 4 && w->shape[0] == C && w->shape[1] == B && w->shape[2] == k && w->shape[3] == k, "head weight shape mismatch");
     Affine af;
-    if ((rc = make_affine(m, head_prefix + ".bias", "", false, C, &af))) return rc;
+    if (head_norm.empty()) rc = make_affine(m, head_prefix + ".bias", "", false, C, &af);
+    else rc = make_affine(m, pred_bn ? std::string() : head_prefix + ".bias", head_norm, true, C, &af, !pred_in);    // ConvLayer: no conv bias with BN (submodules.py:13)
+    if (rc) return rc;
     m->head_w.assign((size_t)B * k * k * C, 0.f); m->head_b.assign(C, 0.f);
     for (int co = 0; co < C; ++co) {
         m->head_b[co] = (float)af.shift[co];
         for (int b = 0; b < B; ++b)
-            for (int t = 0; t < k * k; ++t) m->head_w[((size_t)b * k * k + t) * C + co] = w->data[((size_t)co * B + b) * k * k + t];
+            for (int t = 0; t < k * k; ++t) m->head_w[((size_t)b * k * k + t) * C + co] = (float)((double)w->data[((size_t)co * B + b) * k * k + t] * af.scale[co]);
     }
     if ((rc = find(m, pred_prefix + ".conv2d.weight", &w))) return rc;
     EVR_REQUIRE(w->numel() == C, "pred weight has %lld elements, expected %d", (long long)w->numel(), C);
@@ -544,10 +552,45 @@ int build_unet(evr_model* m) {
     return EVR_OK;
 }
 
+// FireNet's layers have 16 channels -- half a 32-channel K chunk, so they run on the exact-fp32 MFMA (kc = 16).  With
+// EVR_FIRENET_PAD32=1 (split modes) every 16-channel tensor is instead ZERO-PADDED to 32 channels at model creation: weights
+// [co, ci, k, k] get zero rows for co 16..31 and zero columns for the padded inputs (a cat(x, h) input of 16 + 16 becomes
+// 32 + 32 with h at 32..47), biases zeros.  The padded channels stay exactly zero through every layer (relu(0) = 0; ConvGRU:
+// h' = 0.5 h + 0.5 tanh(0) = 0 from the zero state), so the real channels see the reference's arithmetic, now on the split
+// kernels.  Measured at 240x180, 64 sequences: 12.0k frames/s against 14.2k on the fp32 path (4x the multiply-adds on tiles
+// sized for wider layers), so it is NOT the default; it exists because the shipped FireNet checkpoints are the only TRAINED
+// weights available offline, and this is how the split arithmetic is exercised on them (tests/test_gpu_modes.py).
+static void firenet_pad_state_dict(evr_model* m, const std::string& head, const std::string& pred) {
+    for (auto& kv : m->sd) {
+        HostTensor& t = kv.second;
+        const std::string& name = kv.first;
+        if (t.ndim == 1 && t.shape[0] == 16) {                          // biases of 16-channel layers
+            m->pad_store.emplace_back(32, 0.f);
+            memcpy(m->pad_store.back().data(), t.data, 16 * sizeof(float));
+            t.data = m->pad_store.back().data(); t.shape[0] = 32;
+        } else if (t.ndim == 4) {
+            const int co = (int)t.shape[0], ci = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+            const bool is_head = name == head + ".weight", is_pred = name.compare(0, pred.size(), pred) == 0;
+            const int co2 = (co == 16) ? 32 : co;
+            const int ci2 = is_head ? ci : (ci == 16 ? 32 : (ci == 32 ? 64 : ci));
+            if (co2 == co && ci2 == ci) continue;
+            (void)is_pred;
+            m->pad_store.emplace_back((size_t)co2 * ci2 * kk, 0.f);
+            float* dst = m->pad_store.back().data();
+            for (int o = 0; o < co; ++o)
+                for (int i = 0; i < ci; ++i) {
+                    const int i2 = (ci == 32 && !is_head) ? (i < 16 ? i : i + 16) : i;      // cat(x, h): h moves to 32..47
+                    memcpy(dst + ((size_t)o * ci2 + i2) * kk, t.data + ((size_t)o * ci + i) * kk, kk * sizeof(float));
+                }
+            t.data = dst; t.shape[0] = co2; t.shape[1] = ci2;
+        }
+    }
+}
+
 int build_firenet(evr_model* m) {
     const evr_model_desc& d = m->desc;
     const bool legacy = d.arch == EVR_ARCH_FIRENET_LEGACY;
-    const int C = d.base_num_channels;
+    int C = d.base_num_channels;
     EVR_REQUIRE(C % 16 == 0, "FireNet: base_num_channels %d unsupported", C);
     const std::string head = legacy ? "net.head.conv.conv2d" : "head.conv2d";
     const std::string g1 = legacy ? "net.head.recurrent_block" : "G1";
@@ -555,6 +598,12 @@ int build_firenet(evr_model* m) {
     const std::string g2 = legacy ? "net.resblocks.0.recurrent_block" : "G2";
     const std::string r2 = legacy ? "net.resblocks.1" : "R2";
     const std::string pred = legacy ? "net.pred" : "pred";
+    static const bool pad32 = getenv("EVR_FIRENET_PAD32") ? atoi(getenv("EVR_FIRENET_PAD32")) != 0 : false;
+    m->fire_C = C;
+    if (C == 16 && arith_mode() != 0 && pad32) {
+        firenet_pad_state_dict(m, head, pred);
+        C = m->fire_C = 32;
+    }
     int rc;
     if ((rc = prep_head_pred(m, head, pred, false, C))) return rc;
     if ((rc = add_gru(m, "g1", g1, C))) return rc;
@@ -727,13 +776,13 @@ int build_etnet(evr_model* m) {
     const bool bn = d.norm == EVR_NORM_BN, inn = d.norm == EVR_NORM_IN;
     EVR_REQUIRE(d.base_num_channels == 32 && d.kernel_size == 5, "ET-Net: 32 base channels, k5");
     int rc;
-    if ((rc = prep_head_pred(m, "head.conv2d", "pred", bn, 32, inn))) return rc;
-    // NB the head ConvLayer of mls_tpa takes `norm` too (u_trans.py:19); prep_head_pred folds none into the head:
-    EVR_REQUIRE(!bn && !inn, "ET-Net with norm != None is not supported (the head convolution would carry a norm layer)");
+    // every ConvLayer / RecurrentConvLayer / UpsampleConvLayer of mls_tpa takes `norm` (u_trans.py:16-52): BatchNorm in eval mode,
+    // or InstanceNorm2d(track_running_stats=True) = a fixed affine from the running statistics -- both folded (see build_unet)
+    if ((rc = prep_head_pred(m, "head.conv2d", "pred", bn, 32, inn, (bn || inn) ? "head.norm_layer" : ""))) return rc;
     for (int i = 0; i < 3; ++i) {
         const int cin = 32 << i, cout = 64 << i;
         const std::string p = "DownsampleConv." + std::to_string(i);
-        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", false, cin, cout, 5, 2, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, "enc" + std::to_string(i) + ".conv", p + ".conv.conv2d.weight", p + ".conv.conv2d.bias", p + ".conv.norm_layer", bn || inn, cin, cout, 5, 2, EPI_BIAS_RELU, inn, !inn))) return rc;
         if ((rc = add_lstm(m, "enc" + std::to_string(i) + ".rec", p + ".recurrent_block", cout))) return rc;
     }
     if ((rc = add_patch_conv(m, "split1", "split1", 128, 256, 2))) return rc;
@@ -767,7 +816,7 @@ int build_etnet(evr_model* m) {
     const int uin[3] = {256, 128, 64}, uout[3] = {128, 64, 32};
     for (int i = 0; i < 3; ++i) {
         const std::string p = "UpsampleConv." + std::to_string(i);
-        if ((rc = add_conv(m, "dec" + std::to_string(i), p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", false, uin[i], uout[i], 5, 1, EPI_BIAS_RELU))) return rc;
+        if ((rc = add_conv(m, "dec" + std::to_string(i), p + ".conv2d.weight", p + ".conv2d.bias", p + ".norm_layer", bn || inn, uin[i], uout[i], 5, 1, EPI_BIAS_RELU, inn, !inn))) return rc;
     }
     return EVR_OK;
 }
@@ -1048,47 +1097,57 @@ int plan_unet(evr_model* m, hipStream_t stream) {
 }
 
 int plan_firenet(evr_model* m, hipStream_t stream) {
-    const int C = m->desc.base_num_channels, n = m->n_seq, h = m->hp, w = m->wp;
+    const int C = m->fire_C, Creal = m->desc.base_num_channels, n = m->n_seq, h = m->hp, w = m->wp;
+    const int P = m->packed ? m->fmt : 0;      // (padded to 32 channels: every tensor between the convolutions is PACKED / H2)
     int rc;
     DevTensor x0, hs[2], z, hr, t, r[2];
-    if ((rc = alloc(m, &x0, n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &hs[0], n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &hs[1], n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &z, n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &hr, n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &t, n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &r[0], n, h, w, C, stream))) return rc;
-    if ((rc = alloc(m, &r[1], n, h, w, C, stream))) return rc;
-    m->head.out = x0.p;
+    if ((rc = alloc(m, &x0, n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &hs[0], n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &hs[1], n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &z, n, h, w, C, stream))) return rc;             // the update gate stays fp32 (never a GEMM operand)
+    if ((rc = alloc(m, &hr, n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &t, n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &r[0], n, h, w, C, stream, P))) return rc;
+    if ((rc = alloc(m, &r[1], n, h, w, C, stream, P))) return rc;
+    for (DevTensor* q : {&x0, &hs[0], &hs[1], &z, &hr, &t, &r[0], &r[1]}) q->c_valid = Creal;
+    m->head.out = x0.p; m->head.out_packed = P; m->head.cout = C;
     name2(m, "head", x0, x0);
     const float* x = x0.p;
     const char* gn[2] = {"g1", "g2"};
     const char* rn[2] = {"r1", "r2"};
+    const double real = (double)Creal * Creal / ((double)C * C);       // direct-conv FLOPs of the REAL channels
+    auto plan = [&](int ci, const ConvIO& io) {
+        const double before = m->flops;
+        plan_conv(m, ci, n, h, w, io, C);
+        m->convs[ci].flops *= real;
+        m->flops = before + m->convs[ci].flops;
+        push_conv(m, ci);
+    };
     for (int s = 0; s < 2; ++s) {
         ConvIO a{}, b{};
+        a.in_packed = b.in_packed = P; a.out_packed = b.out_packed = P; a.state_packed = b.state_packed = P;
         for (int p = 0; p < 2; ++p) {
             a.in0[p] = x; a.in1[p] = hs[s].p; a.out[p] = hr.p; a.state[p] = hs[s].p; a.aux0[p] = z.p;
             b.in0[p] = x; b.in1[p] = hr.p; b.out[p] = hs[s].p; b.state[p] = hs[s].p; b.aux0[p] = z.p;
         }
-        const int zi = conv_index(m, std::string(gn[s]) + ".zr"), oi = conv_index(m, std::string(gn[s]) + ".out");
-        plan_conv(m, zi, n, h, w, a, C); push_conv(m, zi);
-        plan_conv(m, oi, n, h, w, b, C); push_conv(m, oi);
+        plan(conv_index(m, std::string(gn[s]) + ".zr"), a);
+        plan(conv_index(m, std::string(gn[s]) + ".out"), b);
         name2(m, "h" + std::to_string(s), hs[s], hs[s]);
         ConvIO c1{}, c2{};
+        c1.in_packed = c2.in_packed = P; c1.out_packed = c2.out_packed = P; c2.res_packed = P;
         for (int p = 0; p < 2; ++p) {
             c1.in0[p] = hs[s].p; c1.out[p] = t.p;
             c2.in0[p] = t.p; c2.out[p] = r[s].p; c2.residual[p] = hs[s].p;
         }
-        const int i1 = conv_index(m, std::string(rn[s]) + ".conv1"), i2 = conv_index(m, std::string(rn[s]) + ".conv2");
-        plan_conv(m, i1, n, h, w, c1, C); push_conv(m, i1);
-        plan_conv(m, i2, n, h, w, c2, C); push_conv(m, i2);
+        plan(conv_index(m, std::string(rn[s]) + ".conv1"), c1);
+        plan(conv_index(m, std::string(rn[s]) + ".conv2"), c2);
         name2(m, "res" + std::to_string(s), r[s], r[s]);
         x = r[s].p;
     }
     m->pred_x[0] = m->pred_x[1] = x;
     m->pred_skip[0] = m->pred_skip[1] = nullptr;
     m->pred_c = C;
-    m->pred_x_packed = m->pred_skip_packed = 0;
+    m->pred_x_packed = P; m->pred_skip_packed = 0;
     try_fuse_pred(m, conv_index(m, "r2.conv2"), nullptr, false);
     return EVR_OK;
 }
@@ -1452,7 +1511,8 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
     m->packed = false; m->fmt = packed_fmt(arith_mode());
-    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID || m->desc.arch == EVR_ARCH_ETNET) {
+    const bool fire_padded = (m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET) && m->fire_C != m->desc.base_num_channels;
+    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID || m->desc.arch == EVR_ARCH_ETNET || fire_padded) {
         m->packed = true;
         for (const auto& c : m->convs) if (!c.x3) m->packed = false;
     }
@@ -1469,7 +1529,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->head.pad_top = m->pad_top; m->head.pad_left = m->pad_left; m->head.k = m->desc.kernel_size;
     m->head.cout = m->desc.base_num_channels; m->head.wgt = m->d_head_w; m->head.bias = m->d_head_b; m->head.relu = 1;
     m->head.sat = m->d_sat ? m->d_sat + m->convs.size() : nullptr;
-    m->head.wfrag_scale = std::ldexp(1.0f, -(m->head_wfrag_e + H2_ACT_EXP)); m->head.wfrag_inv_scale = std::ldexp(1.0f, m->head_wfrag_e + H2_ACT_EXP);
+    m->head.wfrag_scale = std::ldexp(1.0f, -m->head_wfrag_e); m->head.wfrag_inv_scale = std::ldexp(1.0f, m->head_wfrag_e);
     const bool spade = m->desc.arch == EVR_ARCH_SPADE_E2VID;
     if (spade) {      // the head convolution reads the explicit padded copy (spade.hip): no padding of its own
         m->head.H = m->hp; m->head.W = m->wp; m->head.pad_top = 0; m->head.pad_left = 0;
@@ -1478,7 +1538,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
            : (m->desc.arch == EVR_ARCH_ETNET) ? plan_etnet(m, stream) : plan_firenet(m, stream);
     if (rc) { m->release_shape(); return rc; }
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
-    m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->pred_c;
+    m->flops += 2.0 * n_seq * m->hp * m->wp * (double)(fire_padded ? m->desc.base_num_channels : m->pred_c);
     // upload the launch plans
     std::vector<ConvArgs> all;
     for (auto& c : m->convs) { c.arg_slot = (int)all.size(); all.push_back(c.args[0]); all.push_back(c.args[1]); }
@@ -1616,10 +1676,12 @@ extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst,
     auto it = m->named[p].find(name);
     if (it == m->named[p].end()) { set_error("evr_model_read_tensor: unknown tensor '%s'", name); return EVR_ERR_INVALID; }
     const DevTensor& t = it->second;
-    if (n_out) *n_out = t.numel();
+    const int cv = t.c_valid ? t.c_valid : t.c;
+    const int64_t numel = (int64_t)t.n * t.h * t.w * cv;
+    if (n_out) *n_out = numel;
     if (!dst) return EVR_OK;
-    EVR_REQUIRE(dst_elems >= t.numel(), "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)t.numel());
-    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, t.c, t.packed ? m->fmt : 0, (hipStream_t)stream);
+    EVR_REQUIRE(dst_elems >= numel, "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)numel);
+    return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, cv, t.packed ? m->fmt : 0, (hipStream_t)stream, t.c);
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }

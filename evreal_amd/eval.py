@@ -9,7 +9,7 @@ hot path on the GPU: a sequence's events live in HBM, windows are voxelised in c
 recurrent network steps frame by frame without host synchronisation, post-normalisation and MSE/SSIM run per
 chunk.  Under torch.distributed the sequences of every dataset are sharded across ranks and the per-dataset
 totals are folded with ONE all-reduce (evreal_amd.dist).  `--batch-sequences S` (or eval-config key
-`batch_sequences`) additionally advances S sequences of a rank together, one batch slot each.
+`batch_sequences`; default 8) advances S sequences of a rank together, one batch slot each.
 """
 import argparse
 import glob
@@ -32,6 +32,9 @@ from .lib import EvrError
 from .prepost import normalize_event_tensor, post_process_normalization
 
 CHUNK = 16   # windows voxelised / frames scored per launch
+# sequences of one dataset advanced together by default (same output files as one at a time -- tests/test_gpu_eval.py; a
+# batch-1 step is bound by kernel latency: 1150 frames/s against 4300 at 8).  --batch-sequences 1 is the reference's loop.
+DEFAULT_BATCH_SEQUENCES = '8'
 TIMINGS = []  # host seconds of every eval_method_on_sequences call {setup, enqueue, book, finalize, frames, sequences} (bench.py reads it)
 
 
@@ -418,7 +421,7 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
         seqs = dataset['sequences']
         try:
             mine = [seqs[i] for i in assign_sequences(sequence_costs(seqs), world)[rank]]
-            S = int(eval_config.get('batch_sequences', os.environ.get('EVREAL_BATCH_SEQUENCES', '1')))
+            S = int(eval_config.get('batch_sequences', os.environ.get('EVREAL_BATCH_SEQUENCES', DEFAULT_BATCH_SEQUENCES)))
             k = 0
             while k < len(mine):
                 # a batch = up to S consecutive sequences of one sensor size; it ends at a sequence whose loader would
@@ -502,8 +505,8 @@ def main():
     parser.add_argument('-qm', '--metrics', nargs='+', type=str,
                         help='quantitative evaluation metrics that will be used calculate scores')
     parser.add_argument('--batch-sequences', type=int, default=None,
-                        help='(extension) advance this many sequences of a dataset together, one batch slot each; '
-                             'same outputs as the default 1')
+                        help='(extension) advance this many sequences of a dataset together, one batch slot each '
+                             '(default 8; 1 = one sequence at a time as the reference; the output files are the same)')
     args = parser.parse_args()
     if args.batch_sequences:
         os.environ['EVREAL_BATCH_SEQUENCES'] = str(args.batch_sequences)

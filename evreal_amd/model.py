@@ -292,12 +292,13 @@ class EITR(_HipModel):
         self.kwargs = kw
         self.num_bins = int(kw['num_bins'])
         self.num_encoders = 3
-        if kw.get('norm') not in (None, 'none'):
-            raise _lib.EvrError(f"ET-Net with norm={kw.get('norm')!r} is not supported")
+        if kw.get('norm') not in (None, 'none', 'BN', 'IN'):
+            raise _lib.EvrError(f"ET-Net with norm={kw.get('norm')!r} is not supported (BN, IN or none)")
 
     def _desc(self):
         d = _lib.ModelDesc()
         d.arch = ARCH_ETNET
+        d.norm = {'BN': 1, 'IN': 2}.get(self.kwargs.get('norm'), 0)
         d.num_bins = self.num_bins
         d.base_num_channels = 32
         d.num_encoders = 3

@@ -458,23 +458,25 @@ def make_metrics_published():
 
 def make_etnet():
     """ET-Net (reference class EITR) with deterministic synthetic weights: 3 frames of one 64x96 sequence (96 tokens per
-    scale) -> images, the mean token map of the first frame, final ConvLSTM states."""
-    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=17)
-    net = ref_model.EITR({'num_bins': 5, 'norm': None})
-    assert list(net.state_dict().keys()) == list(sd.keys())
-    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    net.eval()
-    F, H, W = 3, 64, 96
-    vox = synth.sparse_voxels(171, F, 5, H, W, density=0.15)
-    imgs = []
-    with torch.no_grad():
-        for f in range(F):
-            imgs.append(net(torch.from_numpy(vox[f:f + 1]))['image'].numpy())
-    st = net._states
-    out = {f'h{i}_sub': st[i][0].numpy()[:, ::4] for i in range(3)}
-    out.update({f'c{i}_sub': st[i][1].numpy()[:, ::4] for i in range(3)})
-    save_npz('etnet_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([171, F, 5, H, W]), seed=np.array(17),
-             weights_sha=np.array(weights.state_dict_digest(sd)), images=np.concatenate(imgs), **out)
+    scale) -> images, final ConvLSTM states; once per `norm` the reference's ConvLayers accept (None, 'BN', 'IN';
+    u_trans.py:16-52 passes it to the head, the encoders, the decoders and the prediction layer)."""
+    for norm, tag, seed in ((None, 'etnet', 17), ('BN', 'etnet_bn', 18), ('IN', 'etnet_in', 19)):
+        sd = weights.synth_state_dict(weights.etnet_schema(norm=norm), seed=seed)
+        net = ref_model.EITR({'num_bins': 5, 'norm': norm})
+        assert list(net.state_dict().keys()) == list(sd.keys()), norm
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        net.eval()
+        F, H, W = 3, 64, 96
+        vox = synth.sparse_voxels(171, F, 5, H, W, density=0.15)
+        imgs = []
+        with torch.no_grad():
+            for f in range(F):
+                imgs.append(net(torch.from_numpy(vox[f:f + 1]))['image'].numpy())
+        st = net._states
+        out = {f'h{i}_sub': st[i][0].numpy()[:, ::4] for i in range(3)}
+        out.update({f'c{i}_sub': st[i][1].numpy()[:, ::4] for i in range(3)})
+        save_npz(f'{tag}_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([171, F, 5, H, W]), seed=np.array(seed),
+                 weights_sha=np.array(weights.state_dict_digest(sd)), images=np.concatenate(imgs), **out)
 
 
 def make_spade():

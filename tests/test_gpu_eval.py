@@ -35,8 +35,7 @@ def _parse(txt):
 
 def _evaluate_and_compare(tmp_path, monkeypatch, batch_sequences):
     from evreal_amd import eval as ev
-    if batch_sequences > 1:
-        monkeypatch.setenv('EVREAL_BATCH_SEQUENCES', str(batch_sequences))
+    monkeypatch.setenv('EVREAL_BATCH_SEQUENCES', str(batch_sequences))
     g = load_json('eval_loop.json')
     w = load_npz('firenet_weights.npz')
     ckpt = {'state_dict': {k: torch.from_numpy(w[k]) for k in w.files},

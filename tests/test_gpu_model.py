@@ -38,9 +38,11 @@ def _fire(tag, cls_name):
         np.testing.assert_allclose(img, z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f}')
     # states live on the padded grid; the golden stores a ::3 subsample of the reference's padded state
     hp, wp = ((H + 15) // 16 * 16, (W + 15) // 16 * 16) if cls_name == 'FireNet_legacy' else (H, W)
+    # (EVR_FIRENET_PAD32=1 in the default split mode: the states themselves are stored PACKED, ~2^-16 relative per product term)
+    split_mx = os.environ.get('EVR_FIRENET_PAD32', '0') not in ('', '0') and os.environ.get('EVR_ARITH', 'mx') == 'mx' and not os.environ.get('EVR_FP32')
     for i in range(2):
         h = m.read_tensor(f'h{i}').cpu().numpy().reshape(1, 16, hp, wp)
-        np.testing.assert_allclose(h[:, :, ::3, ::3], z[f'state{i}_sub'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(h[:, :, ::3, ::3], z[f'state{i}_sub'], rtol=1e-4, atol=2e-4 if split_mx else 1e-5)
 
 
 def test_firenet_legacy_real_weights():
@@ -277,15 +279,17 @@ def test_spade_e2vid_through_the_method_registry(tmp_path):
     assert img.shape == (1, 1, 60, 90) and bool(torch.isfinite(img).all())
 
 
-def test_etnet_golden():
+@pytest.mark.parametrize('norm,tag', [(None, 'etnet'), ('BN', 'etnet_bn'), ('IN', 'etnet_in')])
+def test_etnet_golden(norm, tag):
     """ET-Net (EITR, model/eitr/) against the reference class: ConvLSTM encoder, patch embeddings, sine positions, nine
     pre-norm encoder layers and six decoder layers (LayerNorm, 8-head attention, FFN), mean of the six token sets,
-    bilinear-upsample decoders."""
+    bilinear-upsample decoders; for every `norm` the reference's ConvLayers accept (u_trans.py:16-52: BatchNorm, or
+    running-statistics InstanceNorm, folded into head / encoders / decoders / prediction layer)."""
     from evreal_amd import model, synth, weights
-    z = load_npz('etnet_seq.npz')
-    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=int(z['seed']))
+    z = load_npz(f'{tag}_seq.npz')
+    sd = weights.synth_state_dict(weights.etnet_schema(norm=norm), seed=int(z['seed']))
     assert weights.state_dict_digest(sd) == str(z['weights_sha'])
-    m = model.EITR({'num_bins': 5, 'norm': None}); m.load_state_dict(sd)
+    m = model.EITR({'num_bins': 5, 'norm': norm}); m.load_state_dict(sd)
     seed, F, B, H, W = [int(v) for v in z['voxel_args']]
     vox = synth.sparse_voxels(seed, F, B, H, W, density=0.15)
     assert sha(vox) == str(z['voxel_sha'])
@@ -348,5 +352,7 @@ def test_large_activations_are_reported_not_silent():
             assert worst < 1e-4 or runs > 0, (scale, runs, layer, worst)       # never a silent degradation
             if runs:
                 assert layer != ''
-            if os.environ.get('EVR_ARITH', 'mx') == 'mx':
+            if os.environ.get('EVR_ARITH', 'mx') == 'mx' and scale < 1e4:
                 assert worst < loose, (scale, worst)   # PACKED beyond its range: the f16 half alone still carries 2^-12
+            if scale >= 1e4:
+                assert runs > 0, scale                 # inputs beyond the half-precision range itself (+-65504) are clamped: reported

@@ -52,6 +52,27 @@ def test_parity_in_fp32_equivalent_mode_on_the_band_kernels():
     _run({'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
 
 
+def _run_firenet(env_extra):
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_model.py', 'tests/test_gpu_fullsize.py', 'tests/test_gpu_eval.py',
+           '-k', 'firenet or evaluate or eval_loop', '-p', 'no:cacheprovider']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+def test_split_arithmetic_on_trained_weights():
+    """The only TRAINED checkpoints available offline are the shipped FireNet / FireNet+ models (16 channels: the fp32 path by
+    default).  EVR_FIRENET_PAD32=1 zero-pads their tensors to one 32-channel chunk, which puts every layer on the split
+    kernels: the real-weight goldens (images from the reference classes, 1e-4), the 40-frame run, the 240x180 k_events
+    sequence and the eval-loop goldens must still pass -- in the default f16 + MX-fp8 arithmetic ..."""
+    _run_firenet({'EVR_FIRENET_PAD32': '1'})
+
+
+def test_fp32_grade_arithmetic_on_trained_weights():
+    """... and in the three-f16-product mode at the tightened 1e-5 image gate."""
+    _run_firenet({'EVR_FIRENET_PAD32': '1', 'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5'})
+
+
 def test_drift_100_frames_in_fp32_equivalent_mode():
     """100 frames x 8 sequences at 346x260 in the three-f16-product mode, gate 1e-5 per pixel (measured 2.4e-7: the level
     of the exact-fp32 mode's own summation-order difference from the CPU oracle)."""

@@ -123,13 +123,17 @@ def test_spade_e2vid_oracle_golden():
         np.testing.assert_allclose(c.numpy()[:, ::4], z[f'c{i}_sub'], rtol=1e-4, atol=1e-5, err_msg=f'c{i}')
 
 
-def test_etnet_oracle_golden():
+import pytest
+
+
+@pytest.mark.parametrize('norm,tag', [(None, 'etnet'), ('BN', 'etnet_bn'), ('IN', 'etnet_in')])
+def test_etnet_oracle_golden(norm, tag):
     """ETNetOracle against the reference class EITR (model/eitr/eitr.py:4-16, u_trans.py:13-123): images and encoder
-    states of the 3-frame golden."""
-    z = load_npz('etnet_seq.npz')
-    sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=int(z['seed']))
+    states of the 3-frame goldens, for every `norm` the reference's ConvLayers accept."""
+    z = load_npz(f'{tag}_seq.npz')
+    sd = weights.synth_state_dict(weights.etnet_schema(norm=norm), seed=int(z['seed']))
     assert weights.state_dict_digest(sd) == str(z['weights_sha'])
-    m = omod.ETNetOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = omod.ETNetOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if np.asarray(v).dtype.kind == 'f'}, norm=norm)
     seed, F, B, H, W = [int(v) for v in z['voxel_args']]
     vox = synth.sparse_voxels(seed, F, B, H, W, density=0.15)
     assert sha(vox) == str(z['voxel_sha'])
