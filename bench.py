@@ -598,12 +598,14 @@ def main():
         if AHEAD == 1 or ns != n_seq:
             for s in range(s_begin, s_end):
                 h.step_raw(xy, ts, pol, offs[s][:ns + 1] if ns != n_seq else offs[s], ref, out_rows(s))
+            h.flush()
             return
         for s0 in range(s_begin, s_end, AHEAD):
             a = min(AHEAD, s_end - s0)
             h.prefetch_raw(xy, ts, pol, offs_flat[s0 * n_seq:(s0 + a) * n_seq + 1], a)
             for s in range(s0, s0 + a):
                 h.step_ahead(ref, out_rows(s))
+        h.flush()
 
     run_steps(hp, 0, Wm, refs, lambda s: scores[s])
     net.profile(pf_timed)
@@ -767,12 +769,14 @@ def main():
                 ofs = [offs[s][:ns + 1].contiguous() for s in range(K + Wm)]
                 for s in range(Wm):
                     h2.step_raw(xy, ts, pol, ofs[s], refs[:ns], sc2)
+                h2.flush()
                 torch.cuda.synchronize()
                 reps = 4
                 t1 = time.perf_counter()
                 for _ in range(reps):
                     for s in range(Wm, Wm + K):
                         h2.step_raw(xy, ts, pol, ofs[s], refs[:ns], sc2)
+                h2.flush()
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 sb[f"n_seq_{ns}"] = {"value": round(ns * K * reps / dt, 1), "ms_per_step": round(1e3 * dt / (K * reps), 4)}

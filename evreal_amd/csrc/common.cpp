@@ -64,3 +64,22 @@ extern "C" int evr_stream_destroy(evr_stream_t stream) {
     if (stream) EVR_HIP(hipStreamDestroy((hipStream_t)stream));
     return EVR_OK;
 }
+
+// HIP events through the ABI: evr_model_set_gate records one inside a model step (after a named layer), another stream waits for
+// it -- how evreal_amd.pipeline starts the evaluation half of frame t only once frame t+1 has passed its first ConvLSTM layer.
+extern "C" int evr_event_create(evr_event_t* out) {
+    EVR_REQUIRE(out != nullptr, "evr_event_create: null argument");
+    hipEvent_t e = nullptr;
+    EVR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = (evr_event_t)e;
+    return EVR_OK;
+}
+extern "C" int evr_event_destroy(evr_event_t ev) {
+    if (ev) EVR_HIP(hipEventDestroy((hipEvent_t)ev));
+    return EVR_OK;
+}
+extern "C" int evr_stream_wait_event(evr_stream_t stream, evr_event_t ev) {
+    EVR_REQUIRE(ev != nullptr, "evr_stream_wait_event: null event");
+    EVR_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return EVR_OK;
+}

@@ -104,6 +104,7 @@ struct evr_model {
     ConvArgs* d_args = nullptr;
     unsigned* d_sat = nullptr;   // [convs.size() + 1] range-guard counters of the packed producers (last: the head conv); evr_model_saturation
     int64_t frame = 0;
+    std::string gate_layer; hipEvent_t gate_event = nullptr;   // evr_model_set_gate
     double flops = 0.0;
     HeadArgs head;
     const float* pred_x[2] = {nullptr, nullptr};
@@ -1599,6 +1600,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 }
                 if ((rc = launch_conv_igemm(c.args[p], m->d_args + c.arg_slot + p, c.kc, c.wm, c.nb, stream, s.conv == m->pred_fused_conv ? img : nullptr))) return rc;
                 if (prof) { EVR_HIP(hipEventRecord(pp.b, stream)); m->prof_pending.push_back(pp); }
+                if (m->gate_event && c.name == m->gate_layer) EVR_HIP(hipEventRecord(m->gate_event, stream));
                 break;
             }
             case ST_UPSAMPLE:
@@ -1682,6 +1684,14 @@ extern "C" int evr_model_read_tensor(evr_model* m, const char* name, float* dst,
     if (!dst) return EVR_OK;
     EVR_REQUIRE(dst_elems >= numel, "evr_model_read_tensor: destination holds %lld elements, need %lld", (long long)dst_elems, (long long)numel);
     return launch_nhwc_to_nchw(t.p, dst, t.n, t.h, t.w, cv, t.packed ? m->fmt : 0, (hipStream_t)stream, t.c);
+}
+
+extern "C" int evr_model_set_gate(evr_model* m, const char* layer, evr_event_t ev) {
+    EVR_REQUIRE(m != nullptr, "evr_model_set_gate: null model");
+    if (!layer || !ev) { m->gate_layer.clear(); m->gate_event = nullptr; return EVR_OK; }
+    EVR_REQUIRE(conv_index(m, layer) >= 0, "evr_model_set_gate: the model has no layer '%s'", layer);
+    m->gate_layer = layer; m->gate_event = (hipEvent_t)ev;
+    return EVR_OK;
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }

@@ -36,6 +36,10 @@ SYMBOLS = {
     'evr_device_info': (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_char_p, c_size_t]),
     'evr_stream_create_cu_masked': (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     'evr_stream_destroy': (c_int, [c_void_p]),
+    'evr_event_create': (c_int, [ctypes.POINTER(c_void_p)]),
+    'evr_event_destroy': (c_int, [c_void_p]),
+    'evr_stream_wait_event': (c_int, [c_void_p, c_void_p]),
+    'evr_model_set_gate': (c_int, [c_void_p, c_char_p, c_void_p]),
     'evr_voxelize_workspace_bytes': (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     'evr_voxelize': (c_int, [c_void_p] * 5 + [c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),

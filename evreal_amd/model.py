@@ -146,6 +146,11 @@ class _HipModel:
             out.append(dict(name=nm, ms=ms[i], flops_per_launch=fl[i], launches=ln[i]))
         return out
 
+    def set_gate(self, layer, event_handle):
+        """Record the HIP event (a handle from evr_event_create) after `layer` in every following step; layer=None: off."""
+        _lib.check(self.lib.evr_model_set_gate(self.handle, None if layer is None else layer.encode(), event_handle),
+                   'evr_model_set_gate')
+
     def saturation(self, clear=False):
         """(runs, layer): output runs of the matrix-core layers that left the packed activation format's exact range since
         the counters were cleared, and the layer with most of them ('' when zero).  Synchronises."""

@@ -7,7 +7,9 @@ All launches go through the C ABI; nothing synchronises with the host inside a s
 cuda.synchronize() and a D2H copy per frame, eval.py:227-233).  With `overlap=True` the evaluation half of a frame
 (robust normalisation, MSE/SSIM, LPIPS) runs on a second HIP stream while the first already reconstructs the next
 frame: those kernels are small and leave most of the chip idle on their own; HIP events order the two streams and
-the image buffer is double-buffered.  Scores then land in `scores_out` asynchronously (synchronise before reading).
+the image buffer is double-buffered.  Scores then land in `scores_out` asynchronously: call flush() and synchronise
+before reading them or the (post-normalised) image -- the evaluation of the newest frame is held back until the next
+frame has been enqueued, so that it can start behind an event recorded INSIDE that frame (EVR_EVAL_GATE).
 """
 import torch
 
@@ -38,6 +40,24 @@ class HotPath:
             self.ev_model = [torch.cuda.Event(), torch.cuda.Event()]     # image k is complete (main stream)
             self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
             self.k = 0
+            # The evaluation of frame t starts only when frame t+1 has passed the layer EVR_EVAL_GATE names (the library records an
+            # event there; default res0.conv2 -- after the three ConvLSTM layers; 'none': at once, as in rounds 1-2): the
+            # evaluation kernels then share the chip with the residual blocks / decoders of the next frame instead of its head
+            # and first ConvLSTM layer (2.2 ms -> 1.5 ms for enc0.rec in the step; +1 % end to end, A/B on one box).  The scores
+            # of frame t land one step later; flush() ends a run.  Models without that layer (FireNet) are not gated.
+            import ctypes, os
+            self._gate = None
+            self._pending = None
+            g = os.environ.get('EVR_EVAL_GATE', 'res0.conv2')
+            if g and g != 'none' and hasattr(model, 'set_gate'):
+                h = ctypes.c_void_p()
+                _lib.check(_lib.load().evr_event_create(ctypes.byref(h)), 'evr_event_create')
+                try:
+                    model.set_gate(g, h)
+                    self._gate, self._gate_layer = h, g
+                    model._gate_owner = self
+                except _lib.EvrError:
+                    _lib.load().evr_event_destroy(h)
         self._vox_events = None
         self._ring, self._ring_stats, self._ring_pos, self._ring_len = None, None, 0, 0
         model.reset_states()
@@ -117,16 +137,12 @@ class HotPath:
         self.vox.voxelize(x, y, t, p, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
         return self._rest(ref, scores_out)
 
-    def _rest_overlapped(self, ref, scores_out, grid, stats):
-        k = self.k; self.k ^= 1
-        main = torch.cuda.current_stream(self.dev)
+    def _enqueue_eval(self, k, ref, scores_out, gated):
         img = self.imgs[k]
-        if self.ev_done[k] is not None:
-            main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (two frames ago)
-        self.model(grid, stats=stats if self.norm_in else None, out=img)
-        self.ev_model[k].record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev_model[k])
+            if gated:
+                _lib.check(_lib.load().evr_stream_wait_event(_lib.stream_ptr(self.side), self._gate), 'evr_stream_wait_event')
             im = img.view(self.n, self.H, self.W)
             if self.post != 'none':
                 post_process_normalization(im, self.post)
@@ -137,6 +153,30 @@ class HotPath:
                     lp = self.lpips(im, ref, clip=True)
                     scores_out[:, 2].copy_(lp)
             ev = torch.cuda.Event(); ev.record(self.side); self.ev_done[k] = ev
+
+    def flush(self):
+        """Enqueue the evaluation half still held back by EVR_EVAL_GATE (the last frame has no successor to wait for)."""
+        if self.overlap and self._pending is not None:
+            self._enqueue_eval(*self._pending, gated=False)
+            self._pending = None
+
+    def _rest_overlapped(self, ref, scores_out, grid, stats):
+        k = self.k; self.k ^= 1
+        main = torch.cuda.current_stream(self.dev)
+        img = self.imgs[k]
+        if self.ev_done[k] is not None:
+            main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (two frames ago)
+        if self._gate is not None and getattr(self.model, '_gate_owner', None) is not self:
+            self.model.set_gate(self._gate_layer, self._gate)      # (another HotPath over the same model took the gate)
+            self.model._gate_owner = self
+        self.model(grid, stats=stats if self.norm_in else None, out=img)      # (records the gate event inside, if set)
+        self.ev_model[k].record(main)
+        if self._gate is None:
+            self._enqueue_eval(k, ref, scores_out, gated=False)
+        else:
+            if self._pending is not None:              # the previous frame's evaluation, now that THIS frame's gate is enqueued
+                self._enqueue_eval(*self._pending, gated=True)
+            self._pending = (k, ref, scores_out)
         return img, scores_out
 
     def _rest(self, ref, scores_out, grid=None, stats=None):

@@ -25,6 +25,7 @@ extern "C" {
 #endif
 
 typedef void* evr_stream_t; /* hipStream_t */
+typedef void* evr_event_t;  /* hipEvent_t */
 
 enum evr_status {
     EVR_OK = 0,
@@ -46,6 +47,11 @@ int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_
  * evaluation half of a frame (eval.py:234-238) on such a stream beside the next frame's reconstruction. */
 int evr_stream_create_cu_masked(int device, int n_cus, int from_top, evr_stream_t* out);
 int evr_stream_destroy(evr_stream_t stream);
+/* HIP events for cross-stream ordering INSIDE a model step (evr_model_set_gate below records one after a named layer);
+ * the reference has a single stream and one synchronize per frame (eval.py:227). */
+int evr_event_create(evr_event_t* out);
+int evr_event_destroy(evr_event_t ev);
+int evr_stream_wait_event(evr_stream_t stream, evr_event_t ev);
 
 /* ----------------------------------------------------------------------------------------------
  * Events -> voxel grid.  Replaces utils/event_utils.py:27-59 (events_to_voxel_torch) and :4-24
@@ -170,6 +176,10 @@ int evr_model_step(evr_model* m, const float* vox, const double* stats, float* i
 int evr_model_read_tensor(evr_model* m, const char* name, float* dst, int64_t dst_elems,
                           int64_t* n_out, evr_stream_t stream);
 /* Direct-convolution FLOPs (2*MAC) of one evr_model_step at the current shape. */
+/* From now on every evr_model_step records `ev` on its stream right after launching the layer called `layer` ("enc0.rec",
+ * "g1.out", ... -- the names evr_model_profile_read reports); NULL layer or event: off.  Lets a second stream's work (the
+ * evaluation of the previous frame) start at a chosen point of the next frame instead of at its beginning. */
+int evr_model_set_gate(evr_model* model, const char* layer, evr_event_t ev);
 double evr_model_flops_per_step(const evr_model* m);
 /* Range guard of the packed activation formats the split arithmetic modes store between layers: number of output runs
  * (4 or 16 channels of one pixel) that left the format's exact range since the last clear, and the layer with most of them

@@ -23,7 +23,7 @@ def _inputs(n_seq, n_steps):
     return d(xy.reshape(-1, 2)), d(ts.reshape(-1)), d(pol.reshape(-1)), d(offs), d(refs), refs
 
 
-def _run(overlap, n_seq=3, n_steps=5):
+def _run(overlap, n_seq=3, n_steps=5, read_every_frame=True):
     from evreal_amd import model, weights
     from evreal_amd.lpips import LPIPS
     from evreal_amd.pipeline import HotPath
@@ -38,9 +38,21 @@ def _run(overlap, n_seq=3, n_steps=5):
     imgs = []
     for s in range(n_steps):
         img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scores[s])
-        torch.cuda.synchronize()                      # (the test reads every frame; bench.py never synchronises)
-        imgs.append(img.clone().cpu().numpy())
-    return np.stack(imgs), scores.cpu().numpy(), refs_h
+        if read_every_frame:
+            hp.flush()                                # the evaluation half of THIS frame (held back for the next frame's gate otherwise)
+            torch.cuda.synchronize()                  # (the test reads every frame; bench.py never synchronises)
+            imgs.append(img.clone().cpu().numpy())
+    hp.flush()
+    torch.cuda.synchronize()
+    return (np.stack(imgs) if imgs else None), scores.cpu().numpy(), refs_h
+
+
+def test_gated_evaluation_stream_gives_the_same_scores():
+    """Default two-stream flow: the evaluation of frame t is enqueued one step later, behind an event the library records inside
+    frame t+1 (after res0.conv2); scores land in the rows they were given, identical to the single-stream run."""
+    _, sc1, _ = _run(False, n_steps=7)
+    _, sc2, _ = _run(True, n_steps=7, read_every_frame=False)
+    np.testing.assert_array_equal(sc1, sc2)
 
 
 def test_two_stream_step_equals_single_stream_and_the_oracle_metrics():
