@@ -101,6 +101,8 @@ struct ConvArgs {
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
     unsigned* sat;            // optional device counter: output runs beyond the packed format's exact range (packed.h sat_note)
+    int no_band5;             // keep a 5x5 stride-1 convolution on the implicit GEMM (LPIPS conv2: on the evaluation stream the band form's
+                              //   three 51-KB blocks per CU crowd the reconstruction stream's work-groups out: 6.0k vs 6.8k frames/s)
 };
 
 // Division of n < 2^31 by an invariant d >= 1 as (umulhi(n, mul) + n) >> sh (Granlund-Montgomery, round-up form):
@@ -348,8 +350,9 @@ struct CtxArgs {
 int launch_ctx_down(const CtxArgs& a, hipStream_t stream);
 // HyperE2VID per-pixel dynamic filtering (hyper_dynamic.py:50-57,83-88): atoms = coeff[6,12] x bases[12,25];
 // out[pix][c*6+m] = sum_l atoms[m][l] * x[pix + offset(l)][c] over the 5x5 neighbourhood (zero padded).
+// (out_fmt: 0 PLAIN, 1 PACKED, 2 H2 -- the format of `out`, written directly)
 int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w,
-                          int c, hipStream_t stream);
+                          int c, hipStream_t stream, int out_fmt = 0);
 
 // Bilinear x2 (align_corners=False) of (x + skip): NHWC [n,h,w,c] -> [n,2h,2w,c]  (submodules.py:88)
 // (x_packed / skip_packed / out_packed: tensor formats)

@@ -938,6 +938,181 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Band kernel for the 5x5 stride-1 'same' convolutions (UpsampleConvLayer decoders of the E2VID+ / SSL-E2VID / HyperE2VID /
+// ET-Net layouts, submodules.py:69-97; LPIPS conv2) in the split arithmetics on PACKED / H2 inputs.
+//
+// The implicit GEMM fetches an A tile [128 px x 32 ch] for EVERY one of the 25 taps: per K step 16 KB (A) + 4..16 KB (B) go
+// L2 -> LDS for 128..512 matrix cycles per wave, and with the 2..4 blocks a CU holds that is 62 / 94 / 156 B/clk/CU at
+// N = 128 / 64 / 32 columns against a path of 64 B/clk -- the k5 decoders were bound by LDS-DMA, not by the matrix cores.
+// Here, as in conv3x3_band_kernel, the TM + 4 source pixels of one (chunk, dy) are ONE contiguous run of pixel rows (a band,
+// double-buffered) that the FIVE dx taps read at row offsets 0..4: 3.5 KB of band per step instead of 16 KB of A tile
+// (38 / 45 / 58 B/clk/CU).  Walk: chunk x dy x dx; weight tiles through a 2-slot ring, requested one step ahead; counted
+// vmcnt + bare s_barrier; invalid neighbours (image borders, neighbouring images of the batch) read a zero row.
+// NB = 32-column blocks per wave (N tile = 32 NB): 4 / 2 / 1 for 128 / 64 / 32 output channels.
+template <int NB>
+__global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, SP = 8, KW = 5, HALO = 2;
+    constexpr int TM = 32 * WM;
+    constexpr int A_ROWS = TM + 8;                  // TM + 4 source pixels needed; whole 8-row (1-KiB) DMA pieces
+    constexpr int A_PIECES = A_ROWS / 8;            // 17
+    constexpr int A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
+    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;   // 5 / 4 band pieces per wave
+    constexpr int B_PIECES = B_F4 / 64;             // 16 / 8 / 4 weight-tile pieces
+    constexpr int NBW = (B_PIECES + WM - 1) / WM;   // per wave: 4 / 2 / 1
+    static_assert(NA_MIN == 4 && B_PIECES % WM == 0, "tile bookkeeping");
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + 2 * B_F4 + SP];   // [band 0 | band 1 | weight slot 0 | 1 | a zero row]
+    constexpr int ZOFF = 2 * A_F4 + 2 * B_F4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.win, H = a.hin;
+    const int hw = H * W;
+    const int M = a.n * hw;
+    const int ntiles = a.cout / (32 * NB);
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;       // band row 0 = source pixel m0 - 2 (+ dy*W)
+    const int c0 = a.c0;
+    const int nchunks = c0 / 32;
+    const int ktot = KW * KW * nchunks * 32;
+    const unsigned in_pix = (unsigned)M;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
+
+    int a_pix[NA_MAX]; unsigned a_v0[NA_MAX];
+#pragma unroll
+    for (int jj = 0; jj < NA_MAX; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        a_pix[jj] = m0 - HALO + row;
+        a_v0[jj] = ((unsigned)(a_pix[jj] * c0) + (unsigned)((((lane & 7) ^ swz<32>(row)) * 4))) * 4u;
+    }
+    unsigned b_off[NBW];
+#pragma unroll
+    for (int jj = 0; jj < NBW; ++jj) {
+        const int row = 8 * (wmi + jj * WM) + (lane >> 3);
+        b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 7) ^ swz<32>(row)) * 4));
+    }
+    auto issue_band = [&](int cc, int dyi, int buf) {
+        const int shift = (dyi - HALO) * W;
+        const unsigned uni = (unsigned)((shift * c0 + cc * 32) * 4);      // wave-uniform part of the byte offset
+#pragma unroll
+        for (int jj = 0; jj < NA_MAX; ++jj) {
+            if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
+                const int pix = a_pix[jj] + shift;
+                unsigned voff = OOB_OFFSET;
+                if ((unsigned)pix < in_pix) voff = a_v0[jj] + uni;
+                lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int t, int cc, int slot) {
+        const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
+#pragma unroll
+        for (int jj = 0; jj < NBW; ++jj) {
+            lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, (b_off[jj] + kofs) * 4u, 0, 0, 0);
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<32>(r);
+    f32x16 acc[NB];
+    f32x16 pre[NB];
+    EpiCtx ec;
+    const int idx = wmi * 32 + r;                          // lane's row of the tile; its output pixel is m0 + idx
+    epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec, true, false);   // operands are loaded in the epilogue
+
+    unsigned vmask = 0;      // validity of the 25 neighbours of this lane's pixel (bit t = tap (t/5 - 2, t%5 - 2))
+    {
+        const int m = m0 + idx;
+        if (m < M) {
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;
+            const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * W;
+#pragma unroll
+            for (int t = 0; t < KW * KW; ++t) {
+                const int yy = py + t / KW - HALO, xx = px + t % KW - HALO;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vmask |= 1u << t;
+            }
+        }
+    }
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
+    if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    issue_band(0, 0, 0);
+    issue_w(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int pa = c & 1;        // bands per chunk and taps per chunk are both odd: band parity (c + dy) & 1, ring slot (c + t) & 1
+#pragma unroll
+        for (int t = 0; t < KW * KW; ++t) {
+            {   // the weight tile of step s + 1 (first, so that the counted wait below can leave the band in flight)
+                const int t2 = (t + 1) % (KW * KW);
+                int c2 = c + (t + 1) / (KW * KW);
+                if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into the free slot
+                issue_w(t2, c2, pa ^ ((t + 1) & 1));
+            }
+            if (t % KW == 0) {      // at the first tap of a band: request the NEXT band
+                const int d2 = (t / KW + 1) % KW;
+                int c2 = c + (t / KW + 1) / KW;
+                if (c2 >= nchunks) c2 = nchunks - 1;
+                issue_band(c2, d2, pa ^ ((t / KW + 1) & 1));
+            }
+            const int ab = pa ^ ((t / KW) & 1);
+            const int i = idx + (t % KW);                   // band row of the lane's (dx) neighbour
+            const int swi = swz<32>(i);
+            const bool keep = (vmask >> t) & 1u;
+            const float4* la = &lds[keep ? ab * A_F4 + i * SP : ZOFF];
+            const float4* lb = &lds[2 * A_F4 + (pa ^ (t & 1)) * B_F4 + r * SP];
+            const SplitFrag xa = ld_split(la, h, swi);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+                acc[nb] = mma_split(acc[nb], wb, xa, mx_sb, mx_sa);
+            }
+            // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in flight
+            if (t % KW == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    epi_prefetch<NB, false, false>(a, n0, h, pre, ec);
+    epi_finish<NB, false, false, true>(a, ec, n0, h, acc, pre, img_out);
+#endif
+}
+
+template <int NB>
+static int launch_band5(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int M = a.n * a.hm * a.wm;
+    const int total = ((M + 127) / 128) * (a.cout / (32 * NB));
+    hipLaunchKernelGGL((conv5x5_band_kernel<NB>), dim3(total), dim3(256), 0, stream, d_args, img);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+// split arithmetic on PACKED inputs, 5x5 taps in row-major order, stride 1 on the input's own grid, a single source, plain epilogues
+static bool band5_eligible(const ConvArgs& a, int kc) {
+    static const bool off = getenv("EVR_NO_BAND") != nullptr || (getenv("EVR_BAND5") && atoi(getenv("EVR_BAND5")) == 0);
+    if (off) return false;
+    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ntaps == 25 && a.stride == 1 && a.tp.ngroups == 1 && a.in_mode == IN_SINGLE) || a.no_band5) return false;
+    if (a.hm != a.hin || a.wm != a.win || a.os != 1 || a.hout != a.hm || a.wout != a.wm || a.cout % 32 != 0) return false;
+    if (a.epi != EPI_BIAS && a.epi != EPI_BIAS_RELU && a.epi != EPI_RESIDUAL_RELU && a.epi != EPI_BIAS_TANH) return false;
+    for (int t = 0; t < 25; ++t)
+        if (a.tp.tap[t] != (((t / 5 - 2) & 0xffff) | ((t % 5 - 2) * 65536))) return false;
+    const int nb = (a.cout % 128 == 0) ? 4 : (a.cout % 64 == 0) ? 2 : 1;
+    if (a.pred_w && a.cout != 32 * nb) return false;      // a fused prediction needs a single N tile
+    const int64_t M = (int64_t)a.n * a.hm * a.wm;
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : (getenv("EVR_BAND5_MIN") ? atoi(getenv("EVR_BAND5_MIN")) : 256);
+    return ((M + 127) / 128) * (a.cout / (32 * nb)) >= min_blocks;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Band kernel, 256 pixels x 256 columns per block ("wide band").
 //
 // With the split arithmetic at 2/3 of the matrix cycles, conv3x3_band_kernel's 32-pixel x 128-column wave tile reads
@@ -1396,6 +1571,11 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
     if (band_prog_eligible(a, kc)) {
         if (a.cout % 128 == 0) return launch_band_prog<4>(a, d_args, stream, img);
         return launch_band_prog<2>(a, d_args, stream, img);
+    }
+    if (band5_eligible(a, kc)) {
+        if (a.cout % 128 == 0) return launch_band5<4>(a, d_args, stream, img);
+        if (a.cout % 64 == 0) return launch_band5<2>(a, d_args, stream, img);
+        return launch_band5<1>(a, d_args, stream, img);
     }
     if (band_eligible(a, kc)) {
         // 128 x 128 tiles: 4 waves x 2-slot ring, two blocks per CU (one block's epilogue and barrier bubbles hide under the

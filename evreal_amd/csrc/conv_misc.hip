@@ -396,12 +396,15 @@ int launch_ctx_down(const CtxArgs& a, hipStream_t stream) {
 
 // Per-pixel dynamic 5x5 filtering.  One block = 8 consecutive pixels of a row; thread = channel (c <= 256,
 // coalesced NHWC reads).  The pixel's 6x25 atoms are built in LDS from its 72 coefficients and the 12x25 bases.
+// out_fmt != 0: the c*6 outputs of a pixel are staged in LDS and written in the packed format of the 1x1 convolution that
+// consumes them (4-channel runs, st4_any) -- the separate PLAIN -> PACKED pass over the 1536-channel tensor is gone.
 __global__ __launch_bounds__(256) void dynamic_filter_kernel(const float* __restrict__ x, const float* __restrict__ coeff,
                                                               const float* __restrict__ bases, float* __restrict__ out,
-                                                              int n, int h, int w, int c) {
+                                                              int n, int h, int w, int c, int out_fmt) {
     constexpr int PX = 8, NA = 6, NBAS = 12, KK = 25;
     __shared__ float sb[NBAS * KK];
-    __shared__ float atoms[PX][NA * KK];
+    __shared__ __attribute__((aligned(16))) float atoms[PX][KK * 8];      // [tap][atom, padded 6 -> 8]: a tap's six atoms are two 16-B LDS reads
+    __shared__ __attribute__((aligned(16))) float stage[2][256 * NA];
     const int tid = threadIdx.x;
     const int wblk = (w + PX - 1) / PX;
     const int bx = blockIdx.x % wblk, row = blockIdx.x / wblk;   // row over n*h
@@ -415,13 +418,14 @@ __global__ __launch_bounds__(256) void dynamic_filter_kernel(const float* __rest
             const float* cf = coeff + (((int64_t)img * h + py) * w + px0 + p) * (NA * NBAS) + m * NBAS;
             for (int k = 0; k < NBAS; ++k) s = fmaf(cf[k], sb[k * KK + l], s);      // einsum 'bmkhw,kl->bmlhw'
         }
-        atoms[p][r] = s;
+        atoms[p][l * 8 + m] = s;
     }
     __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
-        for (int p = 0; p < PX && px0 + p < w; ++p) {
+    for (int p = 0; p < PX && px0 + p < w; ++p) {          // (block-uniform trip count)
+        const int px = px0 + p;
+        float* orow = out + (((int64_t)img * h + py) * w + px) * (int64_t)(c * NA);
+        for (int ch = tid; ch < c; ch += 256) {
             float acc[NA] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int px = px0 + p;
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
                 const int yy = py + ky - 2;
@@ -431,21 +435,33 @@ __global__ __launch_bounds__(256) void dynamic_filter_kernel(const float* __rest
                     float v = 0.f;
                     if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) v = x[(((int64_t)img * h + yy) * w + xx) * c + ch];
                     const int l = ky * 5 + kx;
-#pragma unroll
-                    for (int m = 0; m < NA; ++m) acc[m] = fmaf(atoms[p][m * KK + l], v, acc[m]);   // 'bmlhw,bclhw->bcmhw'
+                    const float4 a0 = *(const float4*)&atoms[p][l * 8];
+                    const float2 a1 = *(const float2*)&atoms[p][l * 8 + 4];
+                    acc[0] = fmaf(a0.x, v, acc[0]); acc[1] = fmaf(a0.y, v, acc[1]); acc[2] = fmaf(a0.z, v, acc[2]);   // 'bmlhw,bclhw->bcmhw'
+                    acc[3] = fmaf(a0.w, v, acc[3]); acc[4] = fmaf(a1.x, v, acc[4]); acc[5] = fmaf(a1.y, v, acc[5]);
                 }
             }
-            float* o = out + (((int64_t)img * h + py) * w + px) * (int64_t)(c * NA) + ch * NA;
+            if (out_fmt == 0) {
 #pragma unroll
-            for (int m = 0; m < NA; ++m) o[m] = acc[m];
+                for (int m = 0; m < NA; ++m) orow[ch * NA + m] = acc[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < NA; ++m) stage[p & 1][ch * NA + m] = acc[m];        // (c <= 256 here: one channel per thread)
+            }
+        }
+        if (out_fmt != 0) {
+            __syncthreads();      // (the other stage buffer is rewritten only after the NEXT iteration's barrier)
+            for (int run = tid; run < c * NA / 4; run += 256)
+                st4_any(orow, run * 4, *(const float4*)&stage[p & 1][run * 4], out_fmt);
         }
     }
 }
 
 int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w, int c,
-                          hipStream_t stream) {
+                          hipStream_t stream, int out_fmt) {
+    EVR_REQUIRE(out_fmt == 0 || (c <= 256 && (c * 6) % 16 == 0), "dynamic_filter: packed output needs c <= 256 and c*6 %% 16 == 0 (c = %d)", c);
     const int wblk = (w + 7) / 8;
-    hipLaunchKernelGGL(dynamic_filter_kernel, dim3((unsigned)(wblk * n * h)), dim3(256), 0, stream, x, coeff, bases, out, n, h, w, c);
+    hipLaunchKernelGGL(dynamic_filter_kernel, dim3((unsigned)(wblk * n * h)), dim3(256), 0, stream, x, coeff, bases, out, n, h, w, c, out_fmt);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

@@ -1042,8 +1042,9 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             for (int p = 0; p < 2; ++p) { a1.in0[p] = ctxf.p; a1.out[p] = t1.p; a2.in0[p] = t1.p; a2.out[p] = coef.p; a3.in0[p] = inter.p; }
             plan_conv(m, b1, n, h, w, a1, 64); push_conv(m, b1);
             plan_conv(m, b2, n, h, w, a2, 72); push_conv(m, b2);
-            { Step s; s.kind = ST_DYN; s.a[0] = s.a[1] = up.p; s.b[0] = s.b[1] = coef.p; s.out = inter.p; s.h = h; s.w = w; s.c = cin; m->steps.push_back(s); }
-            if (P) { Step s; s.kind = ST_TOPACKED; s.out = inter.p; s.h = h; s.w = w; s.c = cin * 6; m->steps.push_back(s); }
+            { Step s; s.kind = ST_DYN; s.a[0] = s.a[1] = up.p; s.b[0] = s.b[1] = coef.p; s.out = inter.p; s.h = h; s.w = w; s.c = cin; s.out_packed = (cin <= 256) ? P : 0; m->steps.push_back(s); }
+            // (the filter kernel writes its output in the 1x1 convolution's operand format itself when it can: c <= 256)
+            if (P && cin > 256) { Step s; s.kind = ST_TOPACKED; s.out = inter.p; s.h = h; s.w = w; s.c = cin * 6; m->steps.push_back(s); }
             if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             for (int p = 0; p < 2; ++p) a3.out[p] = o.p;
             plan_conv(m, di, n, h, w, a3, cout); push_conv(m, di);
@@ -1622,7 +1623,7 @@ extern "C" int evr_model_step(evr_model* m, const float* vox, const double* stat
                 if ((rc = launch_to_packed(s.out, s.out, (int64_t)m->n_seq * s.h * s.w * s.c, stream, m->fmt))) return rc;
                 break;
             case ST_DYN:
-                if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream))) return rc;
+                if ((rc = launch_dynamic_filter(s.a[p], s.b[p], m->d_bases, s.out, m->n_seq, s.h, s.w, s.c, stream, s.out_packed))) return rc;
                 break;
             case ST_INORM:
                 if ((rc = launch_instnorm(s.a[p], s.b[p], nullptr, s.out, m->n_seq, s.h * s.w, s.c, s.b_packed, 0, s.out_packed, stream))) return rc;
