@@ -938,7 +938,7 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Band kernel for the 5x5 stride-1 'same' convolutions (UpsampleConvLayer decoders of the E2VID+ / SSL-E2VID / HyperE2VID /
+// Band kernel for the 5x5 (and narrow 3x3) stride-1 'same' convolutions (UpsampleConvLayer decoders of the E2VID+ / SSL-E2VID / HyperE2VID /
 // ET-Net layouts, submodules.py:69-97; LPIPS conv2) in the split arithmetics on PACKED / H2 inputs.
 //
 // The implicit GEMM fetches an A tile [128 px x 32 ch] for EVERY one of the 25 taps: per K step 16 KB (A) + 4..16 KB (B) go
@@ -949,11 +949,12 @@ static bool band_eligible(const ConvArgs& a, int kc) {
 // (38 / 45 / 58 B/clk/CU).  Walk: chunk x dy x dx; weight tiles through a 2-slot ring, requested one step ahead; counted
 // vmcnt + bare s_barrier; invalid neighbours (image borders, neighbouring images of the batch) read a zero row.
 // NB = 32-column blocks per wave (N tile = 32 NB): 4 / 2 / 1 for 128 / 64 / 32 output channels.
-template <int NB>
-__global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+template <int KW, int NB>
+__global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv_bandk_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
-    constexpr int WM = 4, SP = 8, KW = 5, HALO = 2;
+    constexpr int WM = 4, SP = 8, HALO = KW / 2;
+    static_assert(KW == 3 || KW == 5, "3x3 or 5x5 taps");
     constexpr int TM = 32 * WM;
     constexpr int A_ROWS = TM + 8;                  // TM + 4 source pixels needed; whole 8-row (1-KiB) DMA pieces
     constexpr int A_PIECES = A_ROWS / 8;            // 17
@@ -979,19 +980,22 @@ __global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(co
     }
     const int ntile = lin % ntiles, mtile = lin / ntiles;
     const int m0 = mtile * TM, n0 = ntile * 32 * NB;       // band row 0 = source pixel m0 - 2 (+ dy*W)
-    const int c0 = a.c0;
-    const int nchunks = c0 / 32;
+    const int c0 = a.c0, c1 = a.c1;
+    const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 32;
     const int ktot = KW * KW * nchunks * 32;
     const unsigned in_pix = (unsigned)M;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
 
-    int a_pix[NA_MAX]; unsigned a_v0[NA_MAX];
+    int a_pix[NA_MAX]; unsigned a_v0[NA_MAX], a_v1[NA_MAX];
 #pragma unroll
     for (int jj = 0; jj < NA_MAX; ++jj) {
         const int row = 8 * (wmi + jj * WM) + (lane >> 3);
         a_pix[jj] = m0 - HALO + row;
-        a_v0[jj] = ((unsigned)(a_pix[jj] * c0) + (unsigned)((((lane & 7) ^ swz<32>(row)) * 4))) * 4u;
+        const unsigned q = (unsigned)((((lane & 7) ^ swz<32>(row)) * 4));
+        a_v0[jj] = ((unsigned)(a_pix[jj] * c0) + q) * 4u;
+        a_v1[jj] = ((unsigned)(a_pix[jj] * c1) + q) * 4u;
     }
     unsigned b_off[NBW];
 #pragma unroll
@@ -1000,16 +1004,21 @@ __global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(co
         b_off[jj] = (unsigned)((n0 + row) * ktot + (((lane & 7) ^ swz<32>(row)) * 4));
     }
     auto issue_band = [&](int cc, int dyi, int buf) {
+        int coff = cc * 32;
+        const bool second = coff >= c0;                                   // cat(x, h): the chunk comes from the second source
+        const int csrc = second ? c1 : c0;
+        if (second) coff -= c0;
         const int shift = (dyi - HALO) * W;
-        const unsigned uni = (unsigned)((shift * c0 + cc * 32) * 4);      // wave-uniform part of the byte offset
+        const unsigned uni = (unsigned)((shift * csrc + coff) * 4);      // wave-uniform part of the byte offset
 #pragma unroll
         for (int jj = 0; jj < NA_MAX; ++jj) {
             if (jj < NA_MIN || wmi + jj * WM < A_PIECES) {      // wave-uniform
                 const int pix = a_pix[jj] + shift;
                 unsigned voff = OOB_OFFSET;
-                if ((unsigned)pix < in_pix) voff = a_v0[jj] + uni;
+                if ((unsigned)pix < in_pix) voff = (second ? a_v1[jj] : a_v0[jj]) + uni;
                 lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + (wmi + jj * WM) * 64];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
             }
         }
     };
@@ -1030,7 +1039,7 @@ __global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(co
     const int idx = wmi * 32 + r;                          // lane's row of the tile; its output pixel is m0 + idx
     epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec, true, false);   // operands are loaded in the epilogue
 
-    unsigned vmask = 0;      // validity of the 25 neighbours of this lane's pixel (bit t = tap (t/5 - 2, t%5 - 2))
+    unsigned vmask = 0;      // validity of the KW x KW neighbours of this lane's pixel (bit t = tap (t/KW - HALO, t%KW - HALO))
     {
         const int m = m0 + idx;
         if (m < M) {
@@ -1087,24 +1096,27 @@ __global__ __launch_bounds__(256, (NB == 4) ? 2 : 3) void conv5x5_band_kernel(co
 #endif
 }
 
-template <int NB>
-static int launch_band5(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+template <int KW, int NB>
+static int launch_bandk(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int total = ((M + 127) / 128) * (a.cout / (32 * NB));
-    hipLaunchKernelGGL((conv5x5_band_kernel<NB>), dim3(total), dim3(256), 0, stream, d_args, img);
+    hipLaunchKernelGGL((conv_bandk_kernel<KW, NB>), dim3(total), dim3(256), 0, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
 
-// split arithmetic on PACKED inputs, 5x5 taps in row-major order, stride 1 on the input's own grid, a single source, plain epilogues
-static bool band5_eligible(const ConvArgs& a, int kc) {
+// split arithmetic on PACKED inputs, kw x kw taps in row-major order, stride 1 on the input's own grid; every epilogue but the
+// ConvLSTM one (which needs 128-column tiles: conv3x3_band_kernel / conv3x3_wide_kernel).  kw = 5: the upsample-conv decoders;
+// kw = 3: the 3x3 layers whose N is not a multiple of 128 (ConvGRU layouts, HyperE2VID's bases_net, FireNet padded to 32 channels)
+static bool bandk_eligible(const ConvArgs& a, int kc, int kw) {
     static const bool off = getenv("EVR_NO_BAND") != nullptr || (getenv("EVR_BAND5") && atoi(getenv("EVR_BAND5")) == 0);
     if (off) return false;
-    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ntaps == 25 && a.stride == 1 && a.tp.ngroups == 1 && a.in_mode == IN_SINGLE) || a.no_band5) return false;
+    if (!(a.x3 && a.in_packed && kc == 32 && a.tp.ntaps == kw * kw && a.stride == 1 && a.tp.ngroups == 1) || a.no_band5) return false;
     if (a.hm != a.hin || a.wm != a.win || a.os != 1 || a.hout != a.hm || a.wout != a.wm || a.cout % 32 != 0) return false;
-    if (a.epi != EPI_BIAS && a.epi != EPI_BIAS_RELU && a.epi != EPI_RESIDUAL_RELU && a.epi != EPI_BIAS_TANH) return false;
-    for (int t = 0; t < 25; ++t)
-        if (a.tp.tap[t] != (((t / 5 - 2) & 0xffff) | ((t % 5 - 2) * 65536))) return false;
+    if (a.epi == EPI_LSTM) return false;
+    if (kw == 3 && a.cout % 128 == 0) return false;       // the 128-column kernels take those
+    for (int t = 0; t < kw * kw; ++t)
+        if (a.tp.tap[t] != (((t / kw - kw / 2) & 0xffff) | ((t % kw - kw / 2) * 65536))) return false;
     const int nb = (a.cout % 128 == 0) ? 4 : (a.cout % 64 == 0) ? 2 : 1;
     if (a.pred_w && a.cout != 32 * nb) return false;      // a fused prediction needs a single N tile
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
@@ -1572,10 +1584,14 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
         if (a.cout % 128 == 0) return launch_band_prog<4>(a, d_args, stream, img);
         return launch_band_prog<2>(a, d_args, stream, img);
     }
-    if (band5_eligible(a, kc)) {
-        if (a.cout % 128 == 0) return launch_band5<4>(a, d_args, stream, img);
-        if (a.cout % 64 == 0) return launch_band5<2>(a, d_args, stream, img);
-        return launch_band5<1>(a, d_args, stream, img);
+    if (bandk_eligible(a, kc, 5)) {
+        if (a.cout % 128 == 0) return launch_bandk<5, 4>(a, d_args, stream, img);
+        if (a.cout % 64 == 0) return launch_bandk<5, 2>(a, d_args, stream, img);
+        return launch_bandk<5, 1>(a, d_args, stream, img);
+    }
+    if (bandk_eligible(a, kc, 3)) {
+        if (a.cout % 64 == 0) return launch_bandk<3, 2>(a, d_args, stream, img);
+        return launch_bandk<3, 1>(a, d_args, stream, img);
     }
     if (band_eligible(a, kc)) {
         // 128 x 128 tiles: 4 waves x 2-slot ring, two blocks per CU (one block's epilogue and barrier bubbles hide under the
