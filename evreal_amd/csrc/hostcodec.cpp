@@ -18,3 +18,25 @@ extern "C" int evr_fastdiv_magic(unsigned d, unsigned* mul, unsigned* shift) {
     fastdiv_magic(d, mul, shift);
     return EVR_OK;
 }
+
+// The H2 format of the fp32-grade mode (conv.h): activations (fixed exponent H2_ACT_EXP), weights (per-tensor exponent), decode.
+extern "C" int evr_h2_pack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_h2_pack: n = %lld must be a multiple of 16", (long long)n);
+    std::vector<float> w(src, src + n);
+    pack_h2_act(w);
+    memcpy(dst, w.data(), (size_t)n * sizeof(float));
+    return EVR_OK;
+}
+extern "C" int evr_h2_pack_weights(const float* src, float* dst, int64_t n, int* exponent) {
+    EVR_REQUIRE(src && dst && exponent && n >= 0 && n % 16 == 0, "evr_h2_pack_weights: n = %lld must be a multiple of 16", (long long)n);
+    std::vector<float> w(src, src + n);
+    *exponent = pack_h2_weights(w);
+    memcpy(dst, w.data(), (size_t)n * sizeof(float));
+    return EVR_OK;
+}
+extern "C" int evr_h2_unpack(const float* src, float* dst, int64_t n, int exponent) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_h2_unpack: n = %lld must be a multiple of 16", (long long)n);
+    unpack_h2(src, dst, (size_t)n, exponent);
+    return EVR_OK;
+}
+extern "C" int evr_h2_act_exponent(void) { return H2_ACT_EXP; }

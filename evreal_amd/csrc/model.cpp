@@ -1773,6 +1773,11 @@ extern "C" int evr_split_pack_device(const float* src, float* dst, int64_t n, ev
     return launch_to_packed(src, dst, n, (hipStream_t)stream, 1);
 }
 
+extern "C" int evr_h2_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_h2_pack_device: n = %lld must be a multiple of 16", (long long)n);
+    return launch_to_packed(src, dst, n, (hipStream_t)stream, 2);
+}
+
 extern "C" int evr_split_unpack(const float* src, float* dst, int64_t n) {
     EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_split_unpack: n = %lld must be a multiple of 16", (long long)n);
     unpack_split_act(src, dst, (size_t)n);

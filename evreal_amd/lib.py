@@ -80,6 +80,11 @@ SYMBOLS = {
     'evr_split_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
     'evr_split_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'evr_split_pack_weights': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_h2_pack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_h2_pack_weights': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_h2_unpack': (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    'evr_h2_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_h2_act_exponent': (c_int, []),
     'evr_fastdiv_magic': (c_int, [ctypes.c_uint, c_void_p, c_void_p]),
 }
 

@@ -272,6 +272,14 @@ int evr_split_pack_device(const float* src, float* dst, int64_t n, evr_stream_t 
  * e4m3 RNE((w - hi) * 2^(e + 12)), e = the largest exponent with max|w| * 2^e <= 224, returned in *exponent -- and the
  * constants of n / d = (umulhi(n, mul) + n) >> shift (n < 2^31) the launch plans carry for the kernels' pixel decode */
 int evr_split_pack_weights(const float* src, float* dst, int64_t n, int* exponent);
+/* The H2 storage format of the fp32-grade arithmetic mode (EVR_ARITH=h3): every 16 values -> 16 IEEE halves hi = RNE(v 2^e)
+ * (saturating) | 16 halves lo = RNE(v 2^e - hi).  Activations use the fixed exponent evr_h2_act_exponent(); weights a per-tensor
+ * exponent that brings max|w| to [2^13, 2^14) (returned).  Host codec + the device twin, as for the default format above. */
+int evr_h2_pack(const float* src, float* dst, int64_t n);
+int evr_h2_pack_weights(const float* src, float* dst, int64_t n, int* exponent);
+int evr_h2_unpack(const float* src, float* dst, int64_t n, int exponent);
+int evr_h2_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
+int evr_h2_act_exponent(void);
 int evr_fastdiv_magic(unsigned d, unsigned* mul, unsigned* shift);
 
 #ifdef __cplusplus

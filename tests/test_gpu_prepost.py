@@ -124,3 +124,21 @@ def test_device_split_codec_matches_host_bit_for_bit():
     _lib.check(L.evr_split_pack_device(_lib.ptr(d), _lib.ptr(d), x.size, _lib.stream_ptr()), 'evr_split_pack_device')
     got = d.cpu().numpy()
     np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_h2_codec_device_equals_host_bit_for_bit():
+    """The H2 codec of the fp32-grade mode as the kernels run it (two v_cvt_f16_f32 per value after the clamp, subnormal halves
+    kept) against the host codec that tests/test_split_codec.py pins to numpy's float16."""
+    import ctypes
+    from evreal_amd import lib as _lib
+    L = _lib.load()
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.standard_normal(1 << 16) * 10.0 ** rng.integers(-9, 4, 1 << 16),
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 0.5, 255.0, 4093.9, 4094.0, 4095.0, 65504.0, 7e4, 2.0 ** -14, 2.0 ** -28]]).astype(np.float32)
+    x = np.resize(x, (x.size // 16) * 16)
+    want = np.empty_like(x)
+    assert L.evr_h2_pack(x.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), x.size) == 0
+    d = torch.from_numpy(x).cuda()
+    _lib.check(L.evr_h2_pack_device(_lib.ptr(d), _lib.ptr(d), x.size, _lib.stream_ptr()), 'evr_h2_pack_device')
+    got = d.cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))

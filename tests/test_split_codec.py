@@ -78,6 +78,43 @@ def test_weight_packing_matches_numpy_and_keeps_both_fp8_pieces_in_range():
         assert np.abs(back - g).max() <= mx * 2.0 ** -15
 
 
+def test_h2_codec_matches_numpy_and_keeps_22_bits():
+    """The fp32-grade mode's H2 format (EVR_ARITH=h3): hi = f16(v 2^e), lo = f16(v 2^e - hi), both IEEE halves (subnormals kept:
+    the f16 MFMA honours them, tools/mfma_denorm_probe.hip).  Bit-for-bit against numpy's float16, then the precision claim."""
+    L = _lib.load()
+    a = L.evr_h2_act_exponent()
+    assert a == 4
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4096) * 10.0 ** rng.integers(-8, 3, 4096),
+                        [0.0, -0.0, 1.0, -1.0, 4093.9, 4094.0, 4095.0, 1e5, -1e5, 2.0 ** -20, 2.0 ** -28, 3e-9, 0.1, 255.0, 1e-30, 65504.0]]).astype(np.float32)
+    got = _call('evr_h2_pack', x)
+    c = np.clip(x.reshape(-1, 16) * np.float32(2.0 ** a), -65504.0, 65504.0).astype(np.float32)
+    hi = c.astype(np.float16)
+    lo = (c - hi.astype(np.float32)).astype(np.float16)
+    want = np.concatenate([hi.view(np.uint8).reshape(-1, 32), lo.view(np.uint8).reshape(-1, 32)], axis=1).reshape(-1)
+    np.testing.assert_array_equal(got.view(np.uint8), want)
+    # decode: 22 significant bits wherever lo is a normal half (|v| >= 2^-7), an absolute 2^-29 below, clamp at +-4094
+    y = np.empty_like(x)
+    assert L.evr_h2_unpack(got.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), x.size, a) == 0
+    inside = np.abs(x) <= 4094.0
+    big = inside & (np.abs(x) >= 2.0 ** -7)
+    assert (np.abs(y[big] - x[big]) / np.abs(x[big])).max() <= 2.0 ** -21
+    assert np.abs(y[inside & ~big] - x[inside & ~big]).max() <= 2.0 ** -28
+    assert np.abs(y[~inside]).max() <= 65504.0 / 16 + 1
+    # weights: per-tensor exponent brings the largest magnitude to [2^13, 2^14); every weight keeps 2^-21 of it or better
+    for scale in (1e-3, 0.05, 1.0, 300.0):
+        w = (rng.uniform(-1, 1, 4096) * scale).astype(np.float32)
+        got = np.empty_like(w); e = ctypes.c_int(0)
+        assert L.evr_h2_pack_weights(w.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p), w.size, ctypes.byref(e)) == 0
+        mx = float(np.abs(w).max())
+        assert 2.0 ** 13 <= mx * 2.0 ** e.value < 2.0 ** 14
+        back = np.empty_like(w)
+        assert L.evr_h2_unpack(got.ctypes.data_as(ctypes.c_void_p), back.ctypes.data_as(ctypes.c_void_p), w.size, e.value) == 0
+        nz = np.abs(w) > mx * 2.0 ** -10
+        assert (np.abs(back[nz] - w[nz]) / np.abs(w[nz])).max() <= 2.0 ** -21
+        assert np.abs(back - w).max() <= mx * 2.0 ** -31 * 2 ** 10
+
+
 def test_fastdiv_constants_divide_exactly():
     L = _lib.load()
     rng = np.random.default_rng(3)
