@@ -23,6 +23,7 @@ quoted on):
     hyper    HyperE2VID layout (dynamic decoder, the reference's Fourier-Bessel table), 346x260, 4 sequences
     color    ColorNet over the E2VID+ layout, 970x624 (BS-ERGB's 970x625 cropped to even sides: the reference's ColorNet
              raises on odd sides), 50k events/window, 1 sequence = 5 recurrent streams; no metrics (the reference skips them)
+    e2vidplus / etnet / spade   the other methods of the reference's registry (E2VID+ = SSL-E2VID layout, ET-Net, SPADE-E2VID), 346x260
 Arithmetic (csrc/conv.h): default split f16 + MX-fp8 ("mx"); EVR_ARITH=h3 three f16 products, fp32-grade; EVR_FP32=1
 exact fp32 MFMA.
 
@@ -151,6 +152,30 @@ class Workload:
             self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **{k: kw[k] for k in OKEYS})
             self.norm_in, self.post, self.enc, self.color = False, 'none', kw['num_encoders'], True
             self.title = "ColorNet over the E2VID+ layout (synthetic weights): 4 Bayer streams at half + 1 grayscale stream at full resolution"
+        elif name == 'etnet':
+            self.W, self.H, self.n_seq, self.k = 346, 260, 8, 15000
+            self.sd = weights.synth_state_dict(weights.etnet_schema(norm=None), seed=27)
+            self.net = model.EITR({'num_bins': 5, 'norm': None})
+            fsd = {k: v for k, v in self.sd.items() if np.asarray(v).dtype.kind == 'f'}
+            self.make_oracle = lambda: omod.ETNetOracle(t(fsd))
+            self.norm_in, self.post, self.enc = False, 'none', 3            # config/method/ET-Net.json; eval.py:152-153
+            self.title = "ET-Net (EITR: ConvLSTM encoder + three token scales through 9 encoder / 6 decoder transformer layers; synthetic weights)"
+        elif name == 'spade':
+            self.W, self.H, self.n_seq, self.k = 346, 260, 8, 15000
+            self.sd = weights.synth_state_dict(weights.spade_e2vid_schema(), seed=26)
+            self.net = model.SpadeE2vid()
+            fsd = {k: v for k, v in self.sd.items() if np.asarray(v).dtype.kind == 'f'}
+            self.make_oracle = lambda: omod.SpadeE2vidOracle(t(fsd))
+            self.norm_in, self.post, self.enc = False, 'none', 3            # config/method/SPADE-E2VID.json; eval.py:130-133
+            self.title = "SPADE-E2VID (full-resolution ConvLSTM encoder, pixel-shuffle decoders with SPADE normalisation; synthetic weights)"
+        elif name == 'e2vidplus':
+            self.W, self.H, self.n_seq, self.k = 346, 260, 64, 15000
+            kw = dict(weights.E2VID_PLUS_KWARGS)
+            self.sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=23)
+            self.net = model.E2VIDRecurrent(kw)
+            self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **{k: kw[k] for k in OKEYS})
+            self.norm_in, self.post, self.enc = False, 'none', kw['num_encoders']   # config/method/E2VID+.json
+            self.title = "E2VID+ / SSL-E2VID layout (no norm, bilinear-upsample + k5 conv decoders; synthetic weights)"
         else:
             raise SystemExit(f"bench.py: unknown --config {name}")
         if sensor is not None:
@@ -505,7 +530,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='e2vid', choices=['e2vid', 'firenet', 'hyper', 'color', 'eval_cli'])
+    ap.add_argument('--config', default='e2vid', choices=['e2vid', 'firenet', 'hyper', 'color', 'etnet', 'spade', 'e2vidplus', 'eval_cli'])
     ap.add_argument('--n-seq', type=int, default=0, help='independent sequences advanced together per GPU (0: the config default)')
     ap.add_argument('--sensor', default='', help='sensor WxH of the synthetic streams (default: the config; e2vid also 640x480)')
     ap.add_argument('--cpu-frames', type=int, default=200, help='frames of the CPU baseline (0 disables)')
@@ -693,7 +718,7 @@ def main():
         traffic, traffic_note = measured_traffic() if (an == 'mx' and wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
         sel = set(p['name'] for p in lstm)
         out = {
-            "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID'}[wl.name], W_, H_),
+            "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID', 'etnet': 'ET-Net', 'spade': 'SPADE-E2VID', 'e2vidplus': 'E2VID+'}[wl.name], W_, H_),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": 'f32' if fp32_net else DTYPE[an], "data": "synthetic",
@@ -842,6 +867,10 @@ def main():
             "3 (FireNet 240x180, k_events)": brief(sub_run(['--config', 'firenet'], {}, K, Wm)),
             "4 (HyperE2VID 346x260, 4 sequences)": brief(sub_run(['--config', 'hyper'], {}, K, Wm)),
             "5 (ColorNet E2VID+ 970x624, 50k events/window)": brief(sub_run(['--config', 'color'], {}, max(K // 2, 4), Wm, timeout=600)),
+            # the rest of the reference's method registry (eval.py:124-158), same step, not BASELINE configurations
+            "extra (E2VID+ / SSL-E2VID layout 346x260, 64 sequences)": brief(sub_run(['--config', 'e2vidplus'], {}, K, Wm)),
+            "extra (ET-Net 346x260, 8 sequences)": brief(sub_run(['--config', 'etnet'], {}, K, Wm, timeout=600)),
+            "extra (SPADE-E2VID 346x260, 8 sequences)": brief(sub_run(['--config', 'spade'], {}, K, Wm, timeout=600)),
         }
         out["eval_cli"] = sub_run(['--config', 'eval_cli'], {}, K, Wm, timeout=600)
     if rank == 0:
