@@ -933,7 +933,9 @@ static bool band_eligible(const ConvArgs& a, int kc) {
     for (int t = 0; t < 9; ++t)
         if (a.tp.tap[t] != (((t / 3 - 1) & 0xffff) | ((t % 3 - 1) * 65536))) return false;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
-    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 512;   // tests lower it
+    // (round 3: no fill threshold any more -- for launches that do not fill the chip the band form still beats the implicit GEMM,
+    // whose 9-fold A re-fetch is the cost either way: +16-17 % end to end at 1 / 4 / 8 / 16 sequences.  EVR_BAND_MIN restores one.)
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 1;
     return ((M + 127) / 128) * (a.cout / 128) >= min_blocks;     // blocks of the default 128-pixel tiles
 }
 
@@ -1120,7 +1122,7 @@ static bool bandk_eligible(const ConvArgs& a, int kc, int kw) {
     const int nb = (a.cout % 128 == 0) ? 4 : (a.cout % 64 == 0) ? 2 : 1;
     if (a.pred_w && a.cout != 32 * nb) return false;      // a fused prediction needs a single N tile
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
-    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : (getenv("EVR_BAND5_MIN") ? atoi(getenv("EVR_BAND5_MIN")) : 256);
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : (getenv("EVR_BAND5_MIN") ? atoi(getenv("EVR_BAND5_MIN")) : 1);
     return ((M + 127) / 128) * (a.cout / (32 * nb)) >= min_blocks;
 }
 
@@ -1535,7 +1537,7 @@ static bool band_prog_eligible(const ConvArgs& a, int kc) {
     if (a.cout % 128 == 0 && !all) return false;
     const int nb = (a.cout % 128 == 0) ? 4 : 2;
     const int64_t M = (int64_t)a.n * a.hm * a.wm;
-    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 512;
+    static const int min_blocks = getenv("EVR_BAND_MIN") ? atoi(getenv("EVR_BAND_MIN")) : 1;
     return ((M + 127) / 128) * (a.cout / (32 * nb)) >= min_blocks;
 }
 

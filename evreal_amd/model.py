@@ -332,6 +332,8 @@ class ColorNet:
         self.half._shape = None
         self.half.load_state_dict(model._sd)
         self.lib = _lib.load()
+        import os
+        self._side = torch.cuda.Stream(device=model.device) if os.environ.get('EVR_COLOR_STREAMS', '2') != '1' else None
         self.reset_states()
 
     @property
@@ -350,8 +352,20 @@ class ColorNet:
         n, B, H, W = ev.shape
         split = torch.empty((4 * n, B, H // 2, W // 2), dtype=torch.float32, device=ev.device)
         _lib.check(self.lib.evr_bayer_split(_lib.ptr(ev), n, B, H, W, _lib.ptr(split), _lib.stream_ptr()), 'evr_bayer_split')
-        planes = self.half(split)['image'].view(n, 4, H // 2, W // 2)
-        gray = self.model(ev)['image']
+        # the four half-resolution streams and the full-resolution stream are independent: two HIP streams, so that the deep
+        # (small) layers of one executor run beside the other's (EVR_COLOR_STREAMS=1: one after the other)
+        main = torch.cuda.current_stream(ev.device)
+        if self._side is None:
+            planes = self.half(split)['image'].view(n, 4, H // 2, W // 2)
+            gray = self.model(ev)['image']
+        else:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                planes = self.half(split)['image'].view(n, 4, H // 2, W // 2)
+            split.record_stream(self._side)
+            gray = self.model(ev)['image']
+            main.wait_stream(self._side)
+            planes.record_stream(main)
         bgr = torch.empty((n, H, W, 3), dtype=torch.uint8, device=ev.device)
         _lib.check(self.lib.evr_color_merge(_lib.ptr(planes), _lib.ptr(gray), n, H, W, _lib.ptr(bgr), _lib.stream_ptr()),
                    'evr_color_merge')

@@ -30,6 +30,12 @@ def test_parity_with_band_kernel_on_small_shapes():
     _run({'EVR_BAND_MIN': '1', 'EVR_BAND_PROG_ALL': '0', 'EVR_WIDE': '0'})
 
 
+def test_parity_on_the_implicit_gemm():
+    # since round 3 the band kernels take every eligible launch (no fill threshold): the split implicit-GEMM kernels -- still the
+    # path of 1x1 layers, strided / grouped shapes the band forms do not cover, and of EVR_NO_BAND=1 -- get their own pass
+    _run({'EVR_NO_BAND': '1'})
+
+
 def test_parity_with_wide_band_kernel_on_small_shapes():
     # the 256 x 256-tile ConvLSTM kernel the 64-sequence bench runs (conv3x3_wide_kernel), on the golden sequences
     _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '3'})
