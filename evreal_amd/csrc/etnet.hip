@@ -10,6 +10,7 @@
 // path and are written PACKED (conv.h) only where a matrix-core GEMM consumes them.
 #include "conv.h"
 #include "packed.h"
+#include <cstdlib>
 
 namespace evr {
 
@@ -108,6 +109,145 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention on the matrix cores (round 3; EVR_ATTN_VALU=1 keeps the kernel above).  Flash-style over 64-key tiles;
+// a wave owns 32 queries of one (sequence, head).  Both GEMMs run TRANSPOSED so that a lane is a query (conv.hip's C^T trick):
+//   S^T [key][query] = K . Q^T        A operand = K rows (keys), B operand = Q (queries): acc lane = query, registers = keys
+//   O^T [d][query]  += V^T . P^T      A operand = V^T rows (d),   B operand = P (queries): acc lane = query, registers = d
+// so a query's running max / sum / rescale are per-lane scalars (its 32 keys of a block live in the lane pair r, r + 32: one
+// shuffle for the max), and the probabilities go from the S accumulator straight into the B operand of the second GEMM -- the
+// k order inside an MFMA is free as long as both operands agree, so V^T is staged in LDS with its keys in the accumulator's
+// order (registers 8s .. 8s+7 of half h = keys 16s + 4h + {0..3}, 16s + 8 + 4h + {0..3} of the 32-key block).
+// Arithmetic: every factor (q / sqrt(d), k, v, p) is hi + lo in two IEEE halves and every product three f16 MFMAs
+// (hi hi + hi lo + lo hi, fp32 accumulate) -- 22 bits per factor, as in the fp32-grade convolution mode; exp in fp32.
+typedef _Float16 at_h8 __attribute__((ext_vector_type(8)));
+typedef float at_f16 __attribute__((ext_vector_type(16)));
+typedef unsigned at_u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 at_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void at_split8(const float (&v)[8], at_u4& hi, at_u4& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const at_h2 a = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]};
+        const at_h2 b = {(_Float16)(v[2 * k] - (float)a[0]), (_Float16)(v[2 * k + 1] - (float)a[1])};
+        hi[k] = __builtin_bit_cast(unsigned, a); lo[k] = __builtin_bit_cast(unsigned, b);
+    }
+}
+__device__ __forceinline__ at_f16 at_mma3(at_f16 acc, at_u4 ah, at_u4 al, at_u4 bh, at_u4 bl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_h8, al), __builtin_bit_cast(at_h8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_h8, ah), __builtin_bit_cast(at_h8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_h8, ah), __builtin_bit_cast(at_h8, bh), acc, 0, 0, 0);
+#endif
+    return acc;
+}
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // K tile [key][32 d] and V^T tile [d][64 keys in accumulator order], each as a hi and a lo plane of halves (4 KB per plane)
+    __shared__ __attribute__((aligned(16))) _Float16 sKh[AT_KT * AT_D], sKl[AT_KT * AT_D], sVh[AT_D * AT_KT], sVl[AT_D * AT_KT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int qi = (blockIdx.x * 4 + wv) * 32 + r;
+    const bool qok = qi < a.Lq;
+    const float scale = 0.17677669529663687f;      // 1 / sqrt(32)
+    // Q fragments (B operand of S^T): lane (query r, half hh) supplies d = 16 s + 8 hh .. + 7 of slab s
+    at_u4 qh[2], ql[2];
+    {
+        const float* qp = a.q + ((int64_t)n * a.Lq + (qok ? qi : 0)) * a.ldq + a.qo + h * AT_D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 t0 = *(const float4*)(qp + 16 * s + 8 * hh), t1 = *(const float4*)(qp + 16 * s + 8 * hh + 4);
+            const float v[8] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale, t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
+            at_split8(v, qh[s], ql[s]);
+        }
+    }
+    at_f16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    float m = -1e30f, l = 0.f;                       // (l: this lane's half of the row sum; the pair is added at the end)
+    const float* kb = a.k + (int64_t)n * a.Lk * a.ldk + a.ko + h * AT_D;
+    const float* vb = a.v + (int64_t)n * a.Lk * a.ldv + a.vo + h * AT_D;
+    // staging: thread -> key tid / 4 of the tile, d segment (tid % 4) * 8
+    const int skey = tid >> 2, sd = (tid & 3) * 8;
+    const int kk = skey & 31;                        // position of the key inside its 32-key block -> its slot in accumulator order
+    const int vslot = (skey >> 5) * 32 + ((kk >> 4) * 16) + (((kk >> 2) & 1) * 8) + (((kk >> 3) & 1) * 4) + (kk & 3);
+    for (int k0 = 0; k0 < a.Lk; k0 += AT_KT) {
+        __syncthreads();
+        {
+            const int kr = k0 + skey;
+            float kv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (kr < a.Lk) {
+                const float4 k0v = *(const float4*)(kb + (int64_t)kr * a.ldk + sd), k1v = *(const float4*)(kb + (int64_t)kr * a.ldk + sd + 4);
+                const float4 v0v = *(const float4*)(vb + (int64_t)kr * a.ldv + sd), v1v = *(const float4*)(vb + (int64_t)kr * a.ldv + sd + 4);
+                kv[0] = k0v.x; kv[1] = k0v.y; kv[2] = k0v.z; kv[3] = k0v.w; kv[4] = k1v.x; kv[5] = k1v.y; kv[6] = k1v.z; kv[7] = k1v.w;
+                vv[0] = v0v.x; vv[1] = v0v.y; vv[2] = v0v.z; vv[3] = v0v.w; vv[4] = v1v.x; vv[5] = v1v.y; vv[6] = v1v.z; vv[7] = v1v.w;
+            }
+            at_u4 khi, klo;
+            at_split8(kv, khi, klo);
+            *(at_u4*)&sKh[skey * AT_D + sd] = khi; *(at_u4*)&sKl[skey * AT_D + sd] = klo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 vh = (_Float16)vv[e];
+                sVh[(sd + e) * AT_KT + vslot] = vh;
+                sVl[(sd + e) * AT_KT + vslot] = (_Float16)(vv[e] - (float)vh);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {                 // the tile's two 32-key blocks
+            if (k0 + 32 * b >= a.Lk) break;           // (block-uniform)
+            at_f16 sacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {             // A = K rows: lane (key r, half hh) supplies d = 16 s + 8 hh .. + 7
+                const at_u4 ah = *(const at_u4*)&sKh[(32 * b + r) * AT_D + 16 * s + 8 * hh];
+                const at_u4 al = *(const at_u4*)&sKl[(32 * b + r) * AT_D + 16 * s + 8 * hh];
+                sacc = at_mma3(sacc, ah, al, qh[s], ql[s]);
+            }
+            // register i of half hh = key 8 (i >> 2) + 4 hh + (i & 3) of the block
+            float mx = m;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = k0 + 32 * b + 8 * (i >> 2) + 4 * hh + (i & 3);
+                sacc[i] = (key < a.Lk) ? sacc[i] : -1e30f;
+                mx = fmaxf(mx, sacc[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // the other half of the query's keys
+            const float alpha = __expf(m - mx);
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] *= alpha;
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = k0 + 32 * b + 8 * (i >> 2) + 4 * hh + (i & 3);
+                p[i] = (key < a.Lk) ? __expf(sacc[i] - mx) : 0.f;
+                l += p[i];
+            }
+            m = mx;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {             // B = P: registers 8 s .. 8 s + 7 are this lane's 8 k-values of slab s
+                const float pv[8] = {p[8 * s], p[8 * s + 1], p[8 * s + 2], p[8 * s + 3], p[8 * s + 4], p[8 * s + 5], p[8 * s + 6], p[8 * s + 7]};
+                at_u4 ph, pl;
+                at_split8(pv, ph, pl);
+                const at_u4 vh = *(const at_u4*)&sVh[r * AT_KT + 32 * b + 16 * s + 8 * hh];      // A = V^T rows: lane (d r, half hh)
+                const at_u4 vl = *(const at_u4*)&sVl[r * AT_KT + 32 * b + 16 * s + 8 * hh];
+                o = at_mma3(o, vh, vl, ph, pl);
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qok) {
+        const float inv = 1.0f / l;
+        float* op = a.out + ((int64_t)n * a.Lq + qi) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                   // register 4 q + j = d 8 q + 4 hh + j
+            st4_any(op, h * AT_D + 8 * q + 4 * hh, make_float4(o[4 * q] * inv, o[4 * q + 1] * inv, o[4 * q + 2] * inv, o[4 * q + 3] * inv), a.out_packed);
+    }
+#endif
+}
+
 __global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ out,
                                                        int64_t total4, int L, int x_packed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one 4-channel run
@@ -140,7 +280,9 @@ int launch_layernorm256(const float* x, const float* w, const float* b, float* o
 }
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
     EVR_REQUIRE(a.heads * AT_D == 256 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: 8 heads of 32 channels, 16-B aligned rows");
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((a.Lq + 255) / 256), a.heads, a.n), dim3(256), 0, stream, a);
+    static const bool valu = getenv("EVR_ATTN_VALU") != nullptr && atoi(getenv("EVR_ATTN_VALU")) != 0;
+    if (valu) hipLaunchKernelGGL(attention_kernel, dim3((unsigned)((a.Lq + 255) / 256), a.heads, a.n), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)((a.Lq + 127) / 128), a.heads, a.n), dim3(256), 0, stream, a);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
