@@ -696,9 +696,14 @@ def main():
         flops_step = net.flops_per_step()
         # `achieved` counts ALGORITHMIC (direct convolution) flops in every mode; in the split modes the matrix pipe is busy
         # for ISSUE_FACTOR x that in f16-rate cycles (mfma_issue_*); `peak` is the dense f16/bf16 (fp32: fp32) MFMA peak.
-        # FireNet's 16-channel layers run the exact fp32 MFMA in every mode (EVR_FIRENET_PAD32=1: zero-padded to one 32-channel
-        # chunk on the split kernels -- slower, kept for exercising them on trained weights; csrc/model.cpp build_firenet)
-        fp32_net = (an == 'fp32') or (wl.name == 'firenet' and os.environ.get('EVR_FIRENET_PAD32', '0') in ('', '0'))
+        # FireNet's 16-channel layers: three f16 products on unpadded H2 tensors in BOTH split modes (csrc/conv.hip
+        # conv3x3_c16_kernel); EVR_FIRENET_H3=0 keeps them on the exact fp32 MFMA, EVR_FIRENET_PAD32=1 pads them to 32 channels
+        # and runs the global mode's kernels (csrc/model.cpp build_firenet)
+        pad32 = os.environ.get('EVR_FIRENET_PAD32', '0') not in ('', '0')
+        fire_fp32 = wl.name == 'firenet' and not pad32 and os.environ.get('EVR_FIRENET_H3', '1') == '0'
+        fp32_net = (an == 'fp32') or fire_fp32
+        if wl.name == 'firenet' and not fp32_net and not pad32:
+            an = 'h3'
         peak = PEAK_F32_MFMA_TFLOPS if fp32_net else PEAK_BF16_MFMA_TFLOPS
         issue = 1.0 if fp32_net else ISSUE_FACTOR[an]
         if wl.name == 'e2vid':

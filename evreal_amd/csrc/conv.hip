@@ -1126,6 +1126,153 @@ static bool bandk_eligible(const ConvArgs& a, int kc, int kw) {
     return ((M + 127) / 128) * (a.cout / (32 * nb)) >= min_blocks;
 }
 
+#if EVR_ARITH == 3
+// ---------------------------------------------------------------------------------------------------
+// FireNet's 3x3 layers (16 channels; ConvGRU gates over cat(x, h), residual-block convs) in the three-f16-product arithmetic.
+//
+// v_mfma_f32_32x32x16_f16 contracts 16 k -- exactly one 16-channel H2 group (64 B: 16 hi | 16 lo halves) per tap, so these layers
+// need no channel padding: a (tap, source) step is three MFMAs (lo_w hi_x + hi_w lo_x + hi_w hi_x).  The whole weight matrix of
+// an N tile is tiny (32 rows x 9 taps x <= 2 sources x 64 B = 36 KB), so the kernel is WEIGHT-STATIONARY and persistent: a block
+// loads it into LDS once, then walks M tiles of 128 pixels; per tile 3 x (1 | 2) bands of TM + 2 pixel rows (64 B each) stream
+// through two buffers, one barrier per band; the next tile's first band is requested before the current tile's epilogue (bias /
+// ReLU / residual / ConvGRU update / fused prediction: the shared epi_finish), which therefore runs under that DMA.
+// The exact-fp32 MFMA these layers used before runs at 1/16 of the f16 rate; the padded-to-32-channels route (EVR_FIRENET_PAD32)
+// doubles every tensor's bytes in a network that is HBM-bound (28 tensor passes of 64 B per pixel per frame).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, SP = 4, TM = 32 * WM;         // SP: 16-B slots per 64-B row (hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15)
+    constexpr int A_ROWS = TM + 16, A_PIECES = A_ROWS / 16, A_F4 = A_ROWS * SP;      // a DMA piece = 16 rows
+    constexpr int W_ROWS = 32 * NB, W_F4 = W_ROWS * SP, W_PIECES = W_ROWS / 16;      // one (tap, source) weight tile
+    constexpr int MAX_TC = 18;                           // 9 taps x 2 sources
+    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + MAX_TC * W_F4 + SP];   // [band 0 | band 1 | weights | a zero row]
+    constexpr int WOFF = 2 * A_F4, ZOFF = 2 * A_F4 + MAX_TC * W_F4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.win, H = a.hin;
+    const int hw = H * W;
+    const int M = a.n * hw;
+    const int c0 = a.c0, c1 = (a.in_mode == IN_CAT) ? a.c1 : 0;
+    const int nsrc = c1 ? 2 : 1;                         // 16-channel chunks of K per tap
+    const int ntc = 9 * nsrc;
+    const int ktot = ntc * 16;
+    const int ntiles_n = a.cout / (32 * NB);
+    const int mtiles = (M + TM - 1) / TM;
+    const unsigned in_pix = (unsigned)M;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * 16u * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
+    const int r = lane & 31, hh = lane >> 5;
+    const int idx = wmi * 32 + r;
+
+    // N tile of this block (persistent over M): blocks b, b + ntiles_n, ... share it -- with one N tile (every FireNet layer) all do
+    const int ntile = blockIdx.x % ntiles_n, n0 = ntile * 32 * NB;
+    const int mstart = blockIdx.x / ntiles_n, mstep = gridDim.x / ntiles_n;
+    // ---- weights: all (tap, source) tiles of the N tile, once
+    for (int p = wmi; p < ntc * W_PIECES; p += WM) {
+        const int tc = p / W_PIECES, row = (p % W_PIECES) * 16 + (lane >> 2);
+        const unsigned off = (unsigned)((n0 + row) * ktot + tc * 16 + (((lane & 3) ^ swz<16>(row)) * 4));
+        lds_ptr_t dst = (lds_ptr_t)&lds[WOFF + tc * W_F4 + (p % W_PIECES) * 64];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, off * 4u, 0, 0, 0);
+    }
+    if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto issue_band = [&](int m0, int bi, int buf) {      // band bi = (source bi / 3, dy = bi % 3 - 1) of the tile at m0
+        const bool second = bi >= 3;
+        const int shift = (bi % 3 - 1) * W;
+        for (int p = wmi; p < A_PIECES; p += WM) {
+            const int row = p * 16 + (lane >> 2);
+            const int pix = m0 - 1 + row + shift;
+            unsigned voff = OOB_OFFSET;
+            if ((unsigned)pix < in_pix) voff = ((unsigned)pix * 16u + (unsigned)(((lane & 3) ^ swz<16>(row)) * 4)) * 4u;
+            lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + p * 64];
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+        }
+    };
+    const int nbands = 3 * nsrc;
+    int mt = mstart;
+    int cur = 0;                                          // band buffer of the band being multiplied; toggles with every band, across tiles
+    if (mt < mtiles) issue_band(mt * TM, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int sw = swz<16>(r);
+    for (; mt < mtiles; mt += mstep) {
+        const int m0 = mt * TM;
+        f32x16 acc[NB];
+        f32x16 pre[NB];
+        EpiCtx ec;
+        epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, hh, acc, pre, ec, true, false);
+        unsigned vmask = 0;
+        {
+            const int m = m0 + idx;
+            if (m < M) {
+                const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;
+                const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * W;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) vmask |= 1u << t;
+                }
+            }
+        }
+        for (int bi = 0; bi < nbands; ++bi) {
+            const int buf = cur;
+            cur ^= 1;
+            // the next band of this tile -- or, during the last band, the first band of the block's NEXT tile
+            if (bi + 1 < nbands) issue_band(m0, bi + 1, buf ^ 1);
+            else if (mt + mstep < mtiles) issue_band((mt + mstep) * TM, 0, buf ^ 1);
+            const int src = bi / 3, dy = bi % 3;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int t = dy * 3 + dx;
+                const int i = idx + dx;
+                const bool keep = (vmask >> t) & 1u;
+                const float4* la = &lds[keep ? buf * A_F4 + i * SP : ZOFF];
+                const int swi = swz<16>(i);
+                const u32x4_t xh = __builtin_bit_cast(u32x4_t, la[hh ^ swi]), xl = __builtin_bit_cast(u32x4_t, la[(2 + hh) ^ swi]);
+                const float4* lb = &lds[WOFF + (t * nsrc + src) * W_F4 + r * SP];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const u32x4_t wh = __builtin_bit_cast(u32x4_t, lb[nb * 32 * SP + (hh ^ sw)]), wl = __builtin_bit_cast(u32x4_t, lb[nb * 32 * SP + ((2 + hh) ^ sw)]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, xh), acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xl), acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc[nb], 0, 0, 0);
+                }
+            }
+            if (bi + 1 < nbands) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the next tile's band stays in flight under the epilogue
+        }
+        epi_prefetch<NB, false, false>(a, n0, hh, pre, ec);
+        epi_finish<NB, false, false, true>(a, ec, n0, hh, acc, pre, img_out);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                  // ... and has landed for everyone before the next tile reads it
+    }
+#endif
+}
+
+template <int NB>
+static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int M = a.n * a.hm * a.wm;
+    const int mtiles = (M + 127) / 128, ntiles_n = a.cout / (32 * NB);
+    int per_n = 256 * 2;                                  // persistent: two blocks per CU (55 KB of LDS each) walk the M tiles
+    if (per_n > mtiles) per_n = mtiles;
+    hipLaunchKernelGGL((conv3x3_c16_kernel<NB>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), 0, stream, d_args, img);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+static bool c16_eligible(const ConvArgs& a, int kc) {
+    if (!(a.x3 == 3 && a.in_packed && kc == 16 && a.tp.ntaps == 9 && a.stride == 1 && a.tp.ngroups == 1)) return false;
+    if (a.c0 != 16 || !(a.in_mode == IN_SINGLE || a.c1 == 16)) return false;
+    if (a.hm != a.hin || a.wm != a.win || a.os != 1 || a.hout != a.hm || a.wout != a.wm || a.cout != 32) return false;      // (one N tile of 32 columns: every FireNet layer)
+    if (a.epi == EPI_LSTM) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.tp.tap[t] != (((t / 3 - 1) & 0xffff) | ((t % 3 - 1) * 65536))) return false;
+    return true;
+}
+#endif   // EVR_ARITH == 3
+
 // ---------------------------------------------------------------------------------------------------
 // Band kernel, 256 pixels x 256 columns per block ("wide band").
 //
@@ -1562,6 +1709,12 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");
     EVR_REQUIRE((int64_t)a.n * a.hm * a.wm < (1LL << 31), "conv_igemm: M too large");
+#if EVR_ARITH == 3
+    if (c16_eligible(a, kc)) {
+        EVR_REQUIRE(a.acc_scale > 0.f && a.div_hw_sh < 32, "conv3x3_c16: plan without accumulator scale / fastdiv");
+        return launch_c16<1>(a, d_args, stream, img);
+    }
+#endif
     EVR_REQUIRE(!a.x3 || kc == 32, "conv_igemm: the split path needs 32-channel chunks");
     EVR_REQUIRE(a.n_valid % 4 == 0 && a.cout_total % 4 == 0, "conv_igemm: output channels %d/%d not multiples of 4 (16-B epilogue accesses)", a.n_valid, a.cout_total);
     EVR_REQUIRE(a.epi != EPI_LSTM || (a.os == 1 && a.hout == a.hm && a.wout == a.wm && a.hidden % 32 == 0),

@@ -353,6 +353,13 @@ int finish_conv(evr_model* m, Conv& c) {
     int rc;
     // arithmetic mode: split (f16 + MX-fp8 corrections, conv.h) for the 32-channel-chunk convolutions unless EVR_FP32=1
     c.x3 = (c.kc == 32) ? arith_mode() : 0;
+    // 16-channel 3x3 layers (FireNet): v_mfma_f32_32x32x16_f16 contracts exactly one 16-channel H2 group, so in the split modes they
+    // run the three-f16-product arithmetic on UNPADDED tensors (conv.hip conv3x3_c16_kernel) whatever the mode of the 32-channel
+    // layers -- fp32-grade (the goldens hold 1e-5), and no longer the 1/16-rate fp32 MFMA.  EVR_FIRENET_H3=0: the exact-fp32 path.
+    static const bool fire_h3 = getenv("EVR_FIRENET_H3") ? atoi(getenv("EVR_FIRENET_H3")) != 0 : true;
+    if (c.kc == 16 && arith_mode() != 0 && fire_h3 && c.k == 3 && c.stride == 1 && !c.transposed && c.cin0 == 16 && (c.cin1 == 0 || c.cin1 == 16) &&
+        (m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET) && c.n_gemm == 32)
+        c.x3 = 3;
     if (c.x3 && c.k == 5 && c.stride == 2 && !c.transposed && c.cin1 == 0 && c.n_gemm % 64 == 0 && 25 * (c.cin0 / 32) < BAND_PROG_MAX - 2) {
         prep_s2d(c);
         const int e2 = pack_weights_for(c.x3, c.w2);      // (the same values rearranged: the same exponent as c.w below)
@@ -1513,10 +1520,12 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
     m->packed = false; m->fmt = packed_fmt(arith_mode());
-    const bool fire_padded = (m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET) && m->fire_C != m->desc.base_num_channels;
-    if (m->desc.arch == EVR_ARCH_UNET_RECURRENT || m->desc.arch == EVR_ARCH_SPADE_E2VID || m->desc.arch == EVR_ARCH_ETNET || fire_padded) {
-        m->packed = true;
+    const bool firenet = m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET;
+    const bool fire_padded = firenet && m->fire_C != m->desc.base_num_channels;
+    {   // every tensor between the matrix-core convolutions is packed when ALL of them run a split arithmetic
+        m->packed = !m->convs.empty();
         for (const auto& c : m->convs) if (!c.x3) m->packed = false;
+        if (m->packed) m->fmt = packed_fmt(m->convs[0].x3);      // (FireNet's 16-channel layers: H2 whatever the global mode)
     }
     // CropParameters (utils/util.py:30-59)
     const int f = 1 << m->desc.pad_multiple_log2;
