@@ -101,6 +101,7 @@ struct ConvArgs {
     int debug_ablate;         // timing ablation only (EVR_ABLATE env): bit0 skip barriers, bit1 skip DMA, bit2 skip epilogue math
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
     unsigned* sat;            // optional device counter: output runs beyond the packed format's exact range (packed.h sat_note)
+    int band_lds_pad;         // conv_bandk_kernel: extra dynamic LDS bytes per block (caps the blocks per CU; host-side only)
     int no_band5;             // keep a 5x5 stride-1 convolution on the implicit GEMM (LPIPS conv2: on the evaluation stream the band form's
                               //   three 51-KB blocks per CU crowd the reconstruction stream's work-groups out: 6.0k vs 6.8k frames/s)
 };

@@ -1102,7 +1102,8 @@ template <int KW, int NB>
 static int launch_bandk(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int total = ((M + 127) / 128) * (a.cout / (32 * NB));
-    hipLaunchKernelGGL((conv_bandk_kernel<KW, NB>), dim3(total), dim3(256), 0, stream, d_args, img);
+    // (a.band_lds_pad: extra dynamic LDS per block -- caps the blocks a CU holds, for launches that share the chip with another stream)
+    hipLaunchKernelGGL((conv_bandk_kernel<KW, NB>), dim3(total), dim3(256), (size_t)a.band_lds_pad, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

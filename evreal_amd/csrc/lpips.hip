@@ -474,7 +474,11 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.tp.ntaps = L.k * L.k; a.tp.ngroups = 1; a.tp.grp_cols = L.cout;
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
-        a.epi = EPI_BIAS_RELU; a.x3 = L.x3; a.no_band5 = 1;
+        a.epi = EPI_BIAS_RELU; a.x3 = L.x3;
+        {   // experiment switch: EVR_LPIPS_BAND5=<KB of LDS padding> puts conv2 on the band kernel with that padding; unset: implicit GEMM
+            const char* e = getenv("EVR_LPIPS_BAND5");
+            a.no_band5 = e ? 0 : 1; a.band_lds_pad = e ? atoi(e) * 1024 : 0;
+        }
         a.acc_scale = (L.x3 == 3) ? std::ldexp(1.0f, -(L.mx_e + H2_ACT_EXP)) : 1.0f;
         a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED (H2 in mode 3) in the split modes
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
