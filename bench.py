@@ -38,7 +38,7 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Besides `roofline
   configs             BASELINE configs 3, 4, 5 (`--config firenet|hyper|color` sub-processes), each with frames/s, dominant
                       layer + roofline fraction and an oracle comparison
   eval_cli            the drop-in `evreal_amd.eval.evaluate` on a synthetic dataset tree (8 sequences), images on / off
-  small_batch         1, 4 and 8 sequences per GPU (the reference's regime is batch 1)
+  small_batch         1, 4, 8, 16 and 32 sequences per GPU (the reference's regime is batch 1; evreal_amd.eval defaults to 8)
   steady_state        >= 2 s of back-to-back steps (the timed region of a 20-step run is 0.25 s)
 """
 import argparse
@@ -720,6 +720,16 @@ def main():
         rl_ms = sum(p['ms'] for p in lstm)
         rl_launches = sum(p['launches'] for p in lstm)
         achieved = rl_flops / (rl_ms * 1e-3) / 1e12 if rl_ms > 0 else 0.0
+        hbm_block = None
+        if wl.name == 'firenet' and an == 'h3' and not pad32 and rl_ms > 0:
+            # the unpadded 16-channel kernel makes FireNet's gate convolutions HBM-bound: algorithmic bytes = the 16-channel tensors
+            # (64 B per padded pixel) a launch reads and writes once -- zr: x, h in, z, h*r out; out: x, h*r, z, h in, h out
+            hp_, wp_ = -(-H_ // 16) * 16, -(-W_ // 16) * 16
+            per = {'g1.zr': 4, 'g1.out': 5, 'g2.zr': 4, 'g2.out': 5}
+            nbytes = sum(per.get(p_['name'], 0) * p_['launches'] for p_ in lstm) * n_seq * hp_ * wp_ * 64.0
+            gbs = nbytes / (rl_ms * 1e-3) / 1e9
+            hbm_block = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "bytes_per_launch": round(nbytes / max(rl_launches, 1)), "note": "ConvGRU gate convolutions: 4 (zr) / 5 (out) passes over 16-channel tensors"}
         traffic, traffic_note = measured_traffic() if (an == 'mx' and wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
         sel = set(p['name'] for p in lstm)
         out = {
@@ -760,6 +770,10 @@ def main():
                          "layers": layer_table(prof)},
             "steady_state": steady,
         }
+        if hbm_block is not None:      # report the binding roof; the matrix-core view stays under roofline_mfma
+            hbm_block.update({k: out["roofline"][k] for k in ("kernel", "share_of_bracketed_time", "avg_launch_us", "launches", "layers", "traffic", "arithmetic")})
+            out["roofline_mfma"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "mfma_issue_frac")}
+            out["roofline"] = hbm_block
 
         # ---- tensorizer roofline: algorithmic bytes 13 N + 4 B H W per window (raw form) ----
         vz = Voxelizer(str(device))
@@ -791,7 +805,7 @@ def main():
         if side:
             # ---- small batches (the reference's regime is one sequence at a time) ----
             sb = {}
-            for ns in (1, 4, 8):
+            for ns in (1, 4, 8, 16, 32):
                 if ns >= n_seq:
                     continue
                 h2 = mk(ns)
@@ -845,7 +859,7 @@ def main():
         wl.net = None
         torch.cuda.empty_cache()
         pick = lambda d, keys: {k: d.get(k) for k in keys}
-        rl_keys = ('achieved', 'peak', 'frac', 'avg_launch_us', 'kernel', 'share_of_bracketed_time', 'mfma_issue_frac')
+        rl_keys = ('bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'kernel', 'share_of_bracketed_time', 'mfma_issue_frac')
         par_keys = ('frames', 'image_max_abs_err', 'image_gate', 'image_gate_ok', 'all_3sf')
 
         def brief(d, extra=()):

@@ -1,8 +1,11 @@
 """The model parity suite again under the kernel-selection switches the default run does not reach.
 
-* EVR_BAND_MIN=1 (+ EVR_BAND_PROG_ALL=0: the implicit GEMM instead of the space-to-depth form for the 128/256-column encoders) -- the band kernel (3x3 stride-1 convolutions with the input rows resident in LDS) normally
-  takes only launches that fill the chip; the golden sequences are small, so the threshold is lowered here, once with the
-  128 x 128-tile kernel for every layer (EVR_WIDE=0) and once with the 256 x 256-tile ConvLSTM kernel (EVR_WIDE_MIN=1).
+* EVR_BAND_MIN=1 (+ EVR_BAND_PROG_ALL=0: the implicit GEMM instead of the space-to-depth form for the 128/256-column encoders) -- the band
+  kernels (3x3 / 5x5 stride-1 convolutions with the input rows resident in LDS; since round 3 they take every eligible launch), once
+  with the 128 x 128-tile kernel for every layer (EVR_WIDE=0) and once with the 256 x 256-tile ConvLSTM kernel (EVR_WIDE_MIN=1:
+  the golden sequences are small, so its fill threshold is lowered).
+* EVR_NO_BAND=1 -- the split implicit-GEMM kernels for every layer.
+* EVR_FIRENET_PAD32=1 -- FireNet's trained checkpoints on the 32-channel split kernels (default: the unpadded 16-channel h3 kernel).
 * EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations instead of split (f16 + MX-fp8) / PACKED.
 * EVR_ARITH=h3    -- the fp32-grade split mode: three f16 products per term on H2 tensors (csrc/conv.h); the whole suite again
                      with the image gate tightened from 1e-4 to 1e-5.
