@@ -308,55 +308,6 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
         if (gru) {
             // ConvGRU (submodules.py:281-285), hidden % 4 == 0 checked at launch
             const int C = a.hidden;
-            if constexpr (FMT == 2 && NB == 1 && !GROUPED) {
-                // FireNet (16 hidden channels, H2 state): after the lane exchange half h of a pixel owns columns 16h .. 16h + 15 --
-                // for the update|reset GEMM the whole update gate (h = 0) or the whole reset gate (h = 1), for the candidate GEMM all
-                // 16 channels (h = 0) -- so every operand is ONE 64-B access per lane (the 4-channel pieces below are 8-B ones in H2:
-                // these layers are bound by their tensor passes, conv3x3_c16_kernel)
-                if (C == 16 && a.group_store && a.state_packed && ec.direct && (epi == EPI_GRU_OUT || a.out_packed)) {
-                    float w16[16];
-                    xchg16(acc[0], w16);
-                    if (!mvalid) return;
-                    const unsigned row = (unsigned)m * 16u;
-                    if (epi == EPI_GRU_ZR) {
-                        if (h == 0) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                f4 z;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<FAST>(w16[4 * q + j]);
-                                *(f4*)(a.aux0 + row + 4 * q) = z;                                  // update gate z (fp32)
-                            }
-                        } else {
-                            unsigned g[16];
-                            const u32x4_t* gp = (const u32x4_t*)(a.state + row);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { const u32x4_t t = gp[q]; g[4 * q] = t[0]; g[4 * q + 1] = t[1]; g[4 * q + 2] = t[2]; g[4 * q + 3] = t[3]; }
-                            float hp[16], hr[16];
-                            unpack16_h2(g, hp);
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) hr[k] = hp[k] * sigmoid_t<FAST>(w16[k]);
-                            store16_fmt<FMT>(a.out, row, 0, hr);                                   // h * reset
-                        }
-                    } else if (h == 0) {
-                        unsigned g[16];
-                        const u32x4_t* gp = (const u32x4_t*)(a.state + row);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { const u32x4_t t = gp[q]; g[4 * q] = t[0]; g[4 * q + 1] = t[1]; g[4 * q + 2] = t[2]; g[4 * q + 3] = t[3]; }
-                        float hp[16], hn[16];
-                        unpack16_h2(g, hp);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f4 z = *(const f4*)(a.aux0 + row + 4 * q);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
-                                hn[4 * q + j] = __fadd_rn(__fmul_rn(hp[4 * q + j], 1.0f - z[j]), __fmul_rn(tanh_t<FAST>(w16[4 * q + j]), z[j]));
-                        }
-                        store16_fmt<FMT>(a.state, row, 0, hn);
-                    }
-                    return;
-                }
-            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 unsigned opx; int cgb, oy, ox;

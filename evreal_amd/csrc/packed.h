@@ -184,15 +184,6 @@ __device__ __forceinline__ void unpack16_xchg_h2(const unsigned (&g)[16], f32x16
         v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
     }
 }
-// one H2 group as loaded (hi 8 dwords | lo 8 dwords) -> its 16 values, in channel order (no lane exchange)
-__device__ __forceinline__ void unpack16_h2(const unsigned (&g)[16], float (&w)[16]) {
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-        const h2_t hh = __builtin_bit_cast(h2_t, g[d]), ll = __builtin_bit_cast(h2_t, g[8 + d]);
-        w[2 * d] = ((float)hh[0] + (float)ll[0]) * H2_INV;
-        w[2 * d + 1] = ((float)hh[1] + (float)ll[1]) * H2_INV;
-    }
-}
 template <int FMT> __device__ __forceinline__ void store16_fmt(float* p, unsigned row_off, int cg, const float (&w)[16]) {
     if constexpr (FMT == 2) store16_h2(p, row_off, cg, w); else store16_packed(p, row_off, cg, w);
 }
