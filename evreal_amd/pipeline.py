@@ -62,6 +62,31 @@ class HotPath:
         self._ring, self._ring_stats, self._ring_pos, self._ring_len = None, None, 0, 0
         model.reset_states()
 
+    def close(self):
+        """Release the HIP objects this HotPath created through the C ABI (gate event, CU-masked stream)."""
+        lib = _lib.load()
+        gate = getattr(self, '_gate', None)
+        if gate is not None:
+            try:
+                torch.cuda.synchronize(self.dev)
+                if getattr(self.model, '_gate_owner', None) is self and getattr(self.model, 'handle', None) is not None:
+                    self.model.set_gate(None, None)          # the model must not record into a destroyed event
+                    self.model._gate_owner = None
+                lib.evr_event_destroy(gate)
+            finally:
+                self._gate = None
+        side = getattr(self, '_side_handle', None)
+        if side is not None:
+            torch.cuda.synchronize(self.dev)
+            lib.evr_stream_destroy(side)
+            self._side_handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _side_stream(self):
         """The evaluation stream.  EVR_SIDE_CUS=n restricts it to n compute units spread over the XCDs
         (hipExtStreamCreateWithCUMask through the C ABI); unset / 0: an ordinary stream."""
