@@ -505,7 +505,7 @@ int build_unet(evr_model* m) {
     // eval mode (eval.py:112) is a fixed per-channel affine from the running statistics -> folded like BatchNorm (gamma = 1,
     // beta = 0, conv bias kept); the residual blocks carry a TRUE InstanceNorm2d (:160-162) -> ST_INORM steps
     const bool inn = d.norm == EVR_NORM_IN;
-    EVR_REQUIRE(!inn || !((d.reserved[1] & 1)), "norm='IN' with the dynamic decoder is not supported");
+    // (the dynamic decoder combines with either norm: DynamicUpsampleLayer, submodules.py:100-127, carries no norm layer)
     const int E = d.num_encoders, base = d.base_num_channels, k = d.kernel_size;
     EVR_REQUIRE(E >= 1 && E <= 6 && base % 32 == 0, "UNetRecurrent: num_encoders %d / base_num_channels %d unsupported", E, base);
     int rc;

@@ -72,8 +72,10 @@ def _e2vid(tag, n_seq=1):
         if n_seq > 1:   # replicate the sequence: every replica must reproduce the golden
             x = x.repeat(n_seq, 1, 1, 1)
         img = m(x)['image'].cpu().numpy()
+        # (a tightened gate of the fp32-grade modes never goes below 8x the reference's own fp32-vs-float64 image spread)
+        img_atol = max(IMG_ATOL, 8.0 * float(z['cond.images'])) if 'cond.images' in z.files else IMG_ATOL
         for s in range(n_seq):
-            np.testing.assert_allclose(img[s:s + 1], z['images'][f:f + 1], rtol=0, atol=IMG_ATOL, err_msg=f'frame {f} seq {s}')
+            np.testing.assert_allclose(img[s:s + 1], z['images'][f:f + 1], rtol=0, atol=img_atol, err_msg=f'frame {f} seq {s}')
         if f == 0 and n_seq == 1:
             for k in [k for k in z.files if k.startswith('tap.')]:
                 name = k[4:]
@@ -84,7 +86,11 @@ def _e2vid(tag, n_seq=1):
                 want = z[k]
                 got = got.reshape(1, -1, want.shape[2], want.shape[3])
                 got = got[:, ::4] if got.shape[1] >= 32 else got
-                np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5, err_msg=k)
+                # norm='IN' goldens carry the reference's own fp32-vs-float64 spread per tap (make_golden.py): behind a true
+                # InstanceNorm2d over an 8 x 12 map a 1e-7 difference in the ConvLSTM state becomes 1e-4, for the reference as
+                # for us -- those taps get a multiple of that spread; the IMAGE gate above is the same for every layout
+                cond = float(z['cond.' + name]) if ('cond.' + name) in z.files else 0.0
+                np.testing.assert_allclose(got, want, rtol=1e-4, atol=max(2e-5, 64.0 * cond), err_msg=k)
     for i in range(kw['num_encoders']):
         want = z[f'h{i}_sub']
         h = m.read_tensor(f'h{i}').cpu().numpy().reshape(n_seq, -1, want.shape[2], want.shape[3])
@@ -114,6 +120,13 @@ def test_e2vid_instance_norm_layout():
 
 def test_e2vid_hyper_dynamic_decoder():
     _e2vid('e2vid_hyper')
+
+
+def test_e2vid_hyper_instance_norm_layout():
+    """use_dynamic_decoder with norm='IN': IN-folded encoders / decoders 1-2, true InstanceNorm2d residual blocks feeding the
+    dynamic decoder (submodules.py:100-127 carries no norm)."""
+    _e2vid('e2vid_hyper_in')
+    _e2vid('e2vid_hyper_in', n_seq=2)
 
 
 def test_e2vid_hyper_batched_sequences():

@@ -103,6 +103,11 @@ def test_e2vid_instance_norm_layout():
     _run_e2vid('e2vid_in')
 
 
+def test_e2vid_hyper_instance_norm_layout():
+    """The dynamic decoder beside norm='IN' layers (DynamicUpsampleLayer carries no norm itself, submodules.py:100-127)."""
+    _run_e2vid('e2vid_hyper_in')
+
+
 def test_spade_e2vid_oracle_golden():
     """SpadeE2vidOracle against the reference class SpadeE2vid (model/spade_e2v.py:113-179): images, the 3-channel
     prev_recs and every ConvLSTM state of the 4-frame golden."""
