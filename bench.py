@@ -69,20 +69,25 @@ OKEYS = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks',
 def arith_name():
     if os.environ.get('EVR_FP32') or os.environ.get('EVR_ARITH') == 'fp32':
         return 'fp32'
-    return 'h3' if os.environ.get('EVR_ARITH') == 'h3' else 'mx'
+    e = os.environ.get('EVR_ARITH')
+    return 'h3' if e == 'h3' else ('mx6' if e == 'mx6' else 'mx')
 
 
-DTYPE = {'mx': 'f16+mxfp8', 'h3': 'f16x3', 'fp32': 'f32'}
+DTYPE = {'mx': 'f16+mxfp8', 'mx6': 'f16+mxfp6', 'h3': 'f16x3', 'fp32': 'f32'}
 ARITH_TEXT = {
     'mx': ("split: x = hi + lo8*2^-12, w = hi + wlo8*2^-(e+12) (f16 hi, fp8 e4m3 residuals); per 32 k acc += hi_w*hi_x on 2 x "
            "v_mfma_f32_32x32x16_f16 + (w8*lo8 + wlo8*x8) on 1 x v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; activations "
            "stored PACKED (f16 hi | fp8 lo8 | fp8 x8 per 16 channels) by the producer"),
+    'mx6': ("split: x = hi + lo, w 2^e = hi + wlo (f16 hi); per 32 k acc += hi_w*hi_x on 2 x v_mfma_f32_32x32x16_f16 + (wlo*x6 + w6*lo6) "
+            "on 1 x v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 (fp6) operands and one E8M0 scale per 16-channel group (8 passes instead "
+            "of fp8's 16), fp32 accumulate; activations stored P6 (16 f16 hi | 32 e2m3 codes [x/S, lo 2^11/S] | scale byte per 16 "
+            "channels) by the producer; layouts with VALU producers of packed tensors run 'mx'"),
     'h3': ("three f16 products: x 2^4 = hi + lo, w 2^e = hi + lo (f16 halves: 22 significant bits); per 16 k acc += lo_w*hi_x + "
            "hi_w*lo_x + hi_w*hi_x on 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (the dropped lo*lo term is 2^-22 of a product); "
            "activations stored H2 (16 f16 hi | 16 f16 lo per 16 channels) by the producer"),
     'fp32': "v_mfma_f32_32x32x2_f32 (exact fp32 fma chain)"}
 # matrix cycles per algorithmic flop relative to one f16 product (what mfma_issue_* reports against the f16 peak)
-ISSUE_FACTOR = {'mx': 2.0, 'h3': 3.0, 'fp32': 1.0}
+ISSUE_FACTOR = {'mx': 2.0, 'mx6': 1.5, 'h3': 3.0, 'fp32': 1.0}
 
 
 # ------------------------------------------------------------------------------------------------ launch

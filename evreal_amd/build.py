@@ -34,7 +34,7 @@ PER_FILE = {
 NO_SCRATCH = {'conv.hip', 'lpips.hip'}
 # sources compiled more than once: (object tag, extra flags).  conv.hip carries one split arithmetic per object
 # (csrc/conv.h arith_mode): mode 2 (f16 + MX-fp8, plus the exact-fp32 kernels) and mode 3 (three f16 products, fp32-grade)
-VARIANTS = {'conv.hip': [('', ['-DEVR_ARITH=2']), ('.h3', ['-DEVR_ARITH=3'])]}
+VARIANTS = {'conv.hip': [('', ['-DEVR_ARITH=2']), ('.h3', ['-DEVR_ARITH=3']), ('.m6', ['-DEVR_ARITH=4'])]}
 
 
 def _check_no_scratch(fname, remarks):

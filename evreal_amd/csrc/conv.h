@@ -102,6 +102,8 @@ struct ConvArgs {
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
     unsigned* sat;            // optional device counter: output runs beyond the packed format's exact range (packed.h sat_note)
     int band_lds_pad;         // conv_bandk_kernel: extra dynamic LDS bytes per block (caps the blocks per CU; host-side only)
+    int pred_prescaled;       // modes 3 / 4 with a fused prediction and no other consumer: pred_w already carries acc_scale (ReLU commutes
+                              //   with a positive scale), the epilogue skips its 16 multiplies per block
     int no_band5;             // keep a 5x5 stride-1 convolution on the implicit GEMM (LPIPS conv2: on the evaluation stream the band form's
                               //   three 51-KB blocks per CU crowd the reconstruction stream's work-groups out: 6.0k vs 6.8k frames/s)
 };
@@ -274,23 +276,126 @@ inline int pack_h2_weights(std::vector<float>& w) {
     }
     return e;
 }
+// ---- P6: the third PACKED format (f16 + MX-fp6 arithmetic, EVR_ARITH=mx6).  Per 16 values (64 B):
+//   bytes  0-31  16 f16 hi = RNE_f16(v) (saturating)
+//   bytes 32-55  32 e2m3 codes (6 bits each, element j at bits 6j): element 2i = v_i / S, element 2i + 1 = (v_i - hi_i) 2^11 / S
+//                with the GROUP's own scale S = 2^(E - 2), E = floor(log2 max|v|): the largest value lands in [4, 8) (e2m3
+//                saturates at 7.5), a residual -- at most 2^-11 of its value -- below that
+//   byte  56     the E8M0 scale byte (biased exponent of S, at least 1; weights: of S 2^-11), bytes 57-63 zero
+// conv.hip multiplies hi hi on v_mfma_f32_32x32x16_f16 and the two cross terms of 32 channels on ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 operands -- 8 passes instead of the 16 of the fp8 form -- whose per-lane scale
+// registers are these bytes: a lane half holds one group, i.e. its 32 k-values [v_0/S, lo_0, v_1/S, lo_1, ...] against the
+// weight group's [wlo_0, w_0/S, ...] (note the swapped order).  Weights are pre-multiplied by 2^e (max|w| 2^e in [2^13, 2^14),
+// as for H2) so that small weights keep a normal f16 half; the epilogue multiplies by ConvArgs::acc_scale = 2^-e.
+constexpr int P6_LO_EXP = 11;
+// fp32 -> e2m3 code (bias 1, 3 mantissa bits, no inf/NaN, max 7.5): round to nearest even, saturating -- what
+// v_cvt_scalef32_2xpk16_fp6_f32 does (tools/fp6_cvt_probe.hip)
+inline unsigned char e2m3_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned char sign = (unsigned char)((u >> 26) & 0x20u);
+    u &= 0x7fffffffu;
+    float af; memcpy(&af, &u, 4);
+    if (!(af == af)) return (unsigned char)(sign | 0x1fu);
+    if (af >= 7.5f) return (unsigned char)(sign | 0x1fu);
+    float q;            // the value in units of its binade's step
+    unsigned base;
+    if (af < 1.0f) { q = af * 8.0f; base = 0; }                               // subnormals and the first binade share step 1/8
+    else if (af < 2.0f) { q = (af - 1.0f) * 8.0f; base = 8; }
+    else if (af < 4.0f) { q = (af - 2.0f) * 4.0f; base = 16; }
+    else { q = (af - 4.0f) * 2.0f; base = 24; }
+    unsigned code = base + (unsigned)__builtin_nearbyintf(q);                  // RNE; a carry walks into the next binade's code
+    if (code > 0x1fu) code = 0x1fu;
+    return (unsigned char)(sign | code);
+}
+inline float e2m3_to_f32(unsigned char c) {
+    const unsigned m = c & 31u;
+    const float f = m < 8u ? (float)m * 0.125f : __builtin_ldexpf((float)(8u | (m & 7u)), (int)(m >> 3) - 4);
+    return (c & 32u) ? -f : f;
+}
+// (v scaled by 2^e first; `weights`: elements swapped and the scale byte lowered by P6_LO_EXP)
+inline void pack_group16_p6(const float* v, int e, bool weights, unsigned char* dst) {
+    unsigned short hi[16]; float c[16], lo[16]; float mx = 0.f;
+    for (int k = 0; k < 16; ++k) {
+        c[k] = clampf(__builtin_ldexpf(v[k], e), 65504.0f);
+        if (!(c[k] == c[k])) c[k] = 0.f;
+        hi[k] = f16_rne(c[k]);
+        lo[k] = __builtin_ldexpf(c[k] - f16_to_f32(hi[k]), P6_LO_EXP);
+        const float a = c[k] < 0 ? -c[k] : c[k];
+        if (a > mx) mx = a;
+    }
+    unsigned mu; memcpy(&mu, &mx, 4);
+    int eb = (int)(mu >> 23);
+    eb = eb > 3 ? eb - 2 : 1;
+    unsigned char codes[32];
+    for (int k = 0; k < 16; ++k) {
+        const unsigned char cv = e2m3_rne(__builtin_ldexpf(c[k], 127 - eb)), cl = e2m3_rne(__builtin_ldexpf(lo[k], 127 - eb));
+        codes[2 * k] = weights ? cl : cv; codes[2 * k + 1] = weights ? cv : cl;
+    }
+    memset(dst + 32, 0, 32);
+    for (int j = 0; j < 32; ++j) {
+        const int bit = 6 * j;
+        const unsigned v16 = (unsigned)codes[j] << (bit & 7);
+        dst[32 + (bit >> 3)] |= (unsigned char)v16;
+        if ((bit & 7) > 2) dst[32 + (bit >> 3) + 1] |= (unsigned char)(v16 >> 8);
+    }
+    int sb = weights ? eb - P6_LO_EXP : eb;
+    if (sb < 1) sb = 1;
+    dst[56] = (unsigned char)sb;
+    memcpy(dst, hi, 32);
+}
+inline void pack_p6_act(std::vector<float>& x) {
+    for (size_t base = 0; base + 16 <= x.size(); base += 16) {
+        unsigned char g[64];
+        pack_group16_p6(&x[base], 0, false, g);
+        memcpy(&x[base], g, 64);
+    }
+}
+inline void unpack_p6(const float* src, float* dst, size_t n) {      // activations (hi + residual)
+    for (size_t base = 0; base + 16 <= n; base += 16) {
+        unsigned char g[64]; memcpy(g, src + base, 64);
+        unsigned short hi[16]; memcpy(hi, g, 32);
+        for (int k = 0; k < 16; ++k) {
+            const int bit = 6 * (2 * k + 1);
+            const unsigned w = (unsigned)g[32 + (bit >> 3)] | ((unsigned)g[32 + (bit >> 3) + 1] << 8);
+            dst[base + k] = f16_to_f32(hi[k]) + __builtin_ldexpf(e2m3_to_f32((unsigned char)((w >> (bit & 7)) & 63u)), (int)g[56] - 127 - P6_LO_EXP);
+        }
+    }
+}
+// weights -> P6 groups; returns the exponent e (max|w| 2^e in [2^13, 2^14))
+inline int pack_p6_weights(std::vector<float>& w) {
+    float mx = 0.f;
+    for (float v : w) { const float a = v < 0 ? -v : v; if (a == a && a > mx) mx = a; }
+    int e = 0;
+    if (mx > 0.f) { int ex; (void)__builtin_frexpf(16384.0f / mx, &ex); e = ex - 1; if (__builtin_ldexpf(mx, e) >= 16384.0f) --e; }
+    if (e > 40) e = 40;
+    if (e < -40) e = -40;
+    for (size_t base = 0; base + 16 <= w.size(); base += 16) {
+        unsigned char g[64];
+        pack_group16_p6(&w[base], e, true, g);
+        memcpy(&w[base], g, 64);
+    }
+    return e;
+}
 // arithmetic mode of the 32-channel-chunk convolutions (ConvArgs::x3):
 //   2  split f16 + MX-fp8 corrections on PACKED tensors (default);
+//   4  split f16 + MX-fp6 corrections on P6 tensors (EVR_ARITH=mx6; layouts whose packed tensors are all written as whole
+//      groups by matrix-core epilogues -- model.cpp decides, the others run mode 2);
 //   3  three f16 products on H2 tensors, fp32-grade (EVR_ARITH=h3);
 //   0  exact fp32 MFMA on PLAIN tensors (EVR_FP32=1 or EVR_ARITH=fp32)
 inline int arith_mode() {
     if (getenv("EVR_FP32")) return 0;
     const char* e = getenv("EVR_ARITH");
     if (!e || !*e || !strcmp(e, "mx")) return 2;
+    if (!strcmp(e, "mx6")) return 4;
     if (!strcmp(e, "h3")) return 3;
     if (!strcmp(e, "fp32")) return 0;
     return 2;
 }
 inline bool use_split_mode() { return arith_mode() != 0; }
-// value of the `packed` flags for tensors of a mode: 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2
-inline int packed_fmt(int mode) { return mode == 3 ? 2 : (mode == 2 ? 1 : 0); }
+// value of the `packed` flags for tensors of a mode: 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2, 3 P6
+inline int packed_fmt(int mode) { return mode == 3 ? 2 : (mode == 2 ? 1 : (mode == 4 ? 3 : 0)); }
 // weights (K contiguous, multiples of 16) -> the mode's split layout in place; returns the tensor exponent
-inline int pack_weights_for(int mode, std::vector<float>& w) { return mode == 3 ? pack_h2_weights(w) : pack_split_weights(w); }
+inline int pack_weights_for(int mode, std::vector<float>& w) { return mode == 3 ? pack_h2_weights(w) : (mode == 4 ? pack_p6_weights(w) : pack_split_weights(w)); }
 // (A/B switch for the whole-group PACKED stores)
 inline int use_group_store() { const char* e = getenv("EVR_GROUP_STORE"); return e ? atoi(e) : 1; }
 
@@ -301,6 +406,7 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
 // (conv.hip is compiled once per split arithmetic: mode 2 + the fp32 kernels, and mode 3; launch_conv_igemm dispatches on a.x3)
 int launch_conv_igemm_mx(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 int launch_conv_igemm_h3(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
+int launch_conv_igemm_m6(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 // picks (wm, nb) for the shape: fills the 256 CUs when M is small
 void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);
 

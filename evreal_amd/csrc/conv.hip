@@ -52,6 +52,9 @@
 #if EVR_ARITH == 3
 #define EVR_ANS h3
 #define EVR_LAUNCH_NAME launch_conv_igemm_h3
+#elif EVR_ARITH == 4
+#define EVR_ANS m6
+#define EVR_LAUNCH_NAME launch_conv_igemm_m6
 #else
 #define EVR_ANS mx
 #define EVR_LAUNCH_NAME launch_conv_igemm_mx
@@ -60,7 +63,7 @@
 namespace evr {
 namespace EVR_ANS {
 [[maybe_unused]] constexpr int ARITH = EVR_ARITH;
-[[maybe_unused]] constexpr int FMT = (EVR_ARITH == 3) ? 2 : 1;      // format of this build's packed tensors (packed.h)
+[[maybe_unused]] constexpr int FMT = (EVR_ARITH == 3) ? 2 : (EVR_ARITH == 4 ? 3 : 1);      // format of this build's packed tensors (packed.h)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -72,13 +75,23 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 //   slots 0,1 = f16 hi of k 0-15, slot 2 = fp8 lo8 (w8) of k 0-15, slot 3 = fp8 x8 (wlo8) of k 0-15, slots 4-7 = k 16-31.
 // Lane half h takes slot 4s + h for the f16 MFMA of group s, and slots 2 + h, 6 + h for the fp8 MFMA: its 32 k-values
 // there are [lo8 of k 0-31] (h = 0) against [w8] or [x8 of k 0-31] (h = 1) against [wlo8].
-struct SplitFrag { u32x4_t h0, h1, f0, f1; };
+struct SplitFrag { u32x4_t h0, h1, f0, f1; unsigned sc; };      // (sc: mode 4 only -- the group's E8M0 scale byte)
 __device__ __forceinline__ SplitFrag ld_split(const float4* row, int h, int sw) {
     SplitFrag f;
     f.h0 = __builtin_bit_cast(u32x4_t, row[(h) ^ sw]);
     f.h1 = __builtin_bit_cast(u32x4_t, row[(4 + h) ^ sw]);
-    f.f0 = __builtin_bit_cast(u32x4_t, row[(2 + h) ^ sw]);
-    f.f1 = __builtin_bit_cast(u32x4_t, row[(6 + h) ^ sw]);
+    if constexpr (ARITH == 4) {
+        // P6 rows: slots 2,3 of a group = its 32 e2m3 codes (24 B) | scale byte | spare: lane half h takes the codes of group h whole
+        // (a 64-bit + 32-bit read of slot 3 -- which hipcc fuses into ds_read_b96 -- would spare the two v_mov per fragment that put
+        // f1[0..1] next to f0, but measured 3-6 % slower on every layer: the 96-bit LDS read is the slow one)
+        f.f0 = __builtin_bit_cast(u32x4_t, row[(4 * h + 2) ^ sw]);
+        f.f1 = __builtin_bit_cast(u32x4_t, row[(4 * h + 3) ^ sw]);
+        f.sc = f.f1[2];
+    } else {
+        f.sc = 0u;
+        f.f0 = __builtin_bit_cast(u32x4_t, row[(2 + h) ^ sw]);
+        f.f1 = __builtin_bit_cast(u32x4_t, row[(6 + h) ^ sw]);
+    }
     return f;
 }
 __device__ __forceinline__ i32x8 cat8(u32x4_t p, u32x4_t q) {
@@ -97,6 +110,12 @@ __device__ __forceinline__ f32x16 mma_split(f32x16 acc, const SplitFrag& w, cons
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.f1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.f1), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+    } else if constexpr (ARITH == 4) {
+        // f16 hi hi + ONE fp6 (e2m3) MFMA for both cross terms of the lane half's group: 8 passes instead of fp8's 16; the six code
+        // registers are f0 | f1[0..1], the group's E8M0 scale byte sits in f1[2] (byte 0, op_sel 0) -- per lane, i.e. per (row, group)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat8(w.f0, w.f1), cat8(x.f0, x.f1), acc, 2, 2, 0, (int)w.sc, 0, (int)x.sc);
     } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h0), __builtin_bit_cast(f16x8, x.h0), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.h1), __builtin_bit_cast(f16x8, x.h1), acc, 0, 0, 0);
@@ -222,7 +241,7 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
                     if (cg < nvalid) {               // (a 16-channel tail block: only the lower half of the lane pair loads)
                         const f4* gp = (const f4*)(pre_ptr + row + (unsigned)cg);
                         g0 = gp[0]; g1 = gp[1]; g2 = gp[2];
-                        if constexpr (FMT == 2) g3 = gp[3];      // H2: hi 32 B | lo 32 B
+                        if constexpr (FMT >= 2) g3 = gp[3];      // H2: hi 32 B | lo 32 B; P6: the codes' tail and the scale byte
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { pre[nb][j] = g0[j]; pre[nb][4 + j] = g1[j]; pre[nb][8 + j] = g2[j]; pre[nb][12 + j] = g3[j]; }
@@ -237,7 +256,9 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
                 } else {
                     const int c4 = cgb + 8 * q;
                     if (c4 - 4 * h < nvalid) {                        // wave-uniform (n_valid is a multiple of 8 or the run is whole)
-                        if (pk) {
+                        if (pk && FMT == 3) {
+                            v = load4_fmt<FMT>(pre_ptr, row, c4);      // (P6 off the group path: decoded here, not parked raw)
+                        } else if (pk) {
                             const float* qp = pre_ptr + pk_off(row, c4);
                             f4 hi_lo = {qp[0], qp[1], 0.f, 0.f};                   // 8-B hi piece + ...
                             if constexpr (FMT == 2) { hi_lo[2] = qp[8]; hi_lo[3] = qp[9]; }      // ... the 8-B lo piece 32 B on (H2)
@@ -261,12 +282,14 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
     const int epi = a.epi;
     const int m = ec.m;
     const bool mvalid = ec.mvalid;
-    if constexpr (ARITH == 3 && FAST) {      // (FAST = a split kernel) products were accumulated at 2^(e_w + H2_ACT_EXP)
-        const float sc = a.acc_scale;
+    if constexpr ((ARITH == 3 || ARITH == 4) && FAST) {      // (FAST = a split kernel) products were accumulated at 2^(e_w + H2_ACT_EXP) / 2^e_w
+        if (!a.pred_prescaled) {      // (block-uniform)
+            const float sc = a.acc_scale;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][i] *= sc;
+                for (int i = 0; i < 16; ++i) acc[nb][i] *= sc;
+        }
     }
     if constexpr (LSTM) {
         static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");
@@ -385,16 +408,32 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
             const bool pre_group = has_pre && pre_pk && a.group_store;
             f32x16 pvall = pre[nb];
             if (pre_group) {      // whole-group operand (epi_prefetch): decode, back to the accumulator order (all lanes take part)
-                if constexpr (FMT == 2) {
+                if constexpr (FMT >= 2) {
                     unsigned g[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) g[i] = __float_as_uint(pre[nb][i]);
-                    unpack16_xchg_h2(g, pvall);
+                    if constexpr (FMT == 3) unpack16_xchg_p6(g, pvall); else unpack16_xchg_h2(g, pvall);
                 } else {
                     unsigned g[12];
 #pragma unroll
                     for (int i = 0; i < 12; ++i) g[i] = __float_as_uint(pre[nb][i]);
                     unpack16_xchg(g, pvall);
+                }
+            }
+            // P6: a fused skip beside a residual (the last residual block) is loaded and decoded as the lane's whole group too -- the
+            // 4-channel P6 reader decodes its codes by hand
+            [[maybe_unused]] f32x16 padd_all;
+            // (NB == 4: the residual blocks' kernels; the narrower tiles of conv_bandk_kernel have no registers to spare for it)
+            [[maybe_unused]] const bool padd_group = FMT == 3 && NB == 4 && res && a.post_add && a.padd_packed;
+            if constexpr (FMT == 3 && NB == 4) {
+                if (padd_group) {      // (block-uniform; every lane takes part in the exchange)
+                    unsigned g[16];
+                    const int cg = cgb - 4 * h + 16 * h;
+                    const bool ld = mvalid && cg < nvalid;
+                    const u32x4_t* gp = (const u32x4_t*)(a.post_add + (ld ? opx * ct + (unsigned)cg : 0u));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const u32x4_t t = gp[i]; g[4 * i] = t[0]; g[4 * i + 1] = t[1]; g[4 * i + 2] = t[2]; g[4 * i + 3] = t[3]; }
+                    unpack16_xchg_p6(g, padd_all);
                 }
             }
 #pragma unroll
@@ -407,7 +446,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     const unsigned orow = opx * ct;
                     // the prefetched operand (raw bits from epi_setup), decoded if PACKED
                     f4 pv = {pvall[4 * q], pvall[4 * q + 1], pvall[4 * q + 2], pvall[4 * q + 3]};
-                    if (has_pre && pre_pk && !pre_group) {
+                    if (has_pre && pre_pk && !pre_group && FMT != 3) {
                         const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])};
                         if constexpr (FMT == 2) { const uint2 plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])}; pv = unpack4_h2(phi, plo); }
                         else pv = unpack4(phi, __float_as_uint(pv[2]));
@@ -418,7 +457,10 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                     if (pw && a.out) st4(a.out, orow, c4, v, a.out_packed);        // debug copy of the layer's own output
                     // skip_sum fused into the producer (model_util.py:4-5); prefetched unless the residual took the slot
                     if (a.post_add) {
-                        if (res) { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
+                        if (res) {
+                            if (padd_group) v += f4{padd_all[4 * q], padd_all[4 * q + 1], padd_all[4 * q + 2], padd_all[4 * q + 3]};
+                            else { const f4 s4 = ld4(a.post_add, orow, c4, a.padd_packed); v += s4; }
+                        }
                         else v += pv;
                     }
                     if (group_store) {
@@ -1726,11 +1768,18 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
     EVR_REQUIRE(!a.x3 || a.in_packed, "conv_igemm: the split kernels take PACKED inputs");
     EVR_REQUIRE(a.x3 != 2 || (a.mx_sa > 0 && a.mx_sb > 0), "conv_igemm: split mode without block scales");
     EVR_REQUIRE(a.x3 != 3 || a.acc_scale > 0.f, "conv_igemm: three-product mode without the accumulator scale");
-    EVR_REQUIRE(a.x3 == 0 || a.x3 == 2 || a.x3 == 3, "conv_igemm: unknown arithmetic mode %d", a.x3);
+    EVR_REQUIRE(a.x3 == 0 || a.x3 == 2 || a.x3 == 3 || a.x3 == 4, "conv_igemm: unknown arithmetic mode %d", a.x3);
 #if EVR_ARITH == 3
     EVR_REQUIRE(a.x3 == 3, "conv_igemm: this object carries the three-f16-product kernels only (mode %d requested)", a.x3);
+#elif EVR_ARITH == 4
+    EVR_REQUIRE(a.x3 == 4, "conv_igemm: this object carries the f16 + fp6 kernels only (mode %d requested)", a.x3);
+    EVR_REQUIRE(a.acc_scale > 0.f, "conv_igemm: f16 + fp6 mode without the accumulator scale");
+    // P6 tensors have a scale per 16-channel group: they are written as whole groups only
+    EVR_REQUIRE(a.group_store && a.epi != EPI_GRU_ZR && a.epi != EPI_GRU_OUT && a.epi != EPI_BIAS_TANH && !(a.pred_w && a.out && a.out_packed),
+                "conv_igemm: the f16 + fp6 mode writes whole 64-B groups only (epilogue %d)", a.epi);
+    EVR_REQUIRE(!a.out_packed || (a.n_valid % 16 == 0 && a.cout_total % 16 == 0), "conv_igemm: P6 output needs channel counts that are multiples of 16");
 #else
-    EVR_REQUIRE(a.x3 != 3, "conv_igemm: the three-f16-product kernels live in the other object");
+    EVR_REQUIRE(a.x3 != 3 && a.x3 != 4, "conv_igemm: the three-f16-product / f16 + fp6 kernels live in the other objects");
 #endif
     EVR_REQUIRE(a.div_hw_sh < 32 && a.div_w_sh < 32 && (a.div_hw_mul || (unsigned)(a.hm * a.wm) == (1u << a.div_hw_sh)) && (a.div_w_mul || (unsigned)a.wm == (1u << a.div_w_sh)),
                 "conv_igemm: plan without set_fastdiv()");

@@ -16,6 +16,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // -DEVR_ARITH=3 the three-f16-product kernels on H2 tensors.
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
     if (a.x3 == 3) return launch_conv_igemm_h3(a, d_args, kc, wm, nb, stream, img);
+    if (a.x3 == 4) return launch_conv_igemm_m6(a, d_args, kc, wm, nb, stream, img);
     return launch_conv_igemm_mx(a, d_args, kc, wm, nb, stream, img);
 }
 
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
                 float w16[16];
                 xchg16(acc, w16);
                 if (oy < a.hp && ox < a.wp) {
-                    if (a.out_packed == 2) { sat_check16<2>(a.sat, w16); store16_h2(o, 0u, 16 * h, w16); }
+                    if (a.out_packed == 3) { sat_check16<3>(a.sat, w16); store16_p6(o, 0u, 16 * h, w16); }
+                    else if (a.out_packed == 2) { sat_check16<2>(a.sat, w16); store16_h2(o, 0u, 16 * h, w16); }
                     else { sat_check16<1>(a.sat, w16); store16_packed(o, 0u, 16 * h, w16); }
                 }
             } else if (oy < a.hp && ox < a.wp) {
@@ -303,6 +305,8 @@ int head_pack_wfrag(const float* w, int B, std::vector<unsigned>& out) {
 }
 
 int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
+    EVR_REQUIRE(a.out_packed != 3 || (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5 && a.group_store),
+                "head_conv: a P6 output is written by the matrix-core head kernel only (5 bins, k5, 32 channels, whole-group stores)");
     if (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5) {
         const HeadArgs& a2 = a;
         const int ntiles = a.n * ((a.hp + 7) / 8) * ((a.wp + 31) / 32);
@@ -534,6 +538,13 @@ __global__ __launch_bounds__(256) void to_packed_kernel(const float* __restrict_
         const float4* sp = (const float4*)(src + g * 16);
         const float4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
         float* d = dst + g * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (fmt == 3) {      // P6: the group's scale needs all 16 values
+            const float w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+            store16_p6(d, 0u, 0, w);
+            continue;
+        }
+#endif
         st4_any(d, 0, v0, fmt); st4_any(d, 4, v1, fmt); st4_any(d, 8, v2, fmt); st4_any(d, 12, v3, fmt);
     }
 }

@@ -40,3 +40,24 @@ extern "C" int evr_h2_unpack(const float* src, float* dst, int64_t n, int expone
     return EVR_OK;
 }
 extern "C" int evr_h2_act_exponent(void) { return H2_ACT_EXP; }
+
+// The P6 format of the f16 + MX-fp6 mode (conv.h): activations, weights (swapped code order, per-tensor exponent), decode.
+extern "C" int evr_p6_pack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_p6_pack: n = %lld must be a multiple of 16", (long long)n);
+    std::vector<float> w(src, src + n);
+    pack_p6_act(w);
+    memcpy(dst, w.data(), (size_t)n * sizeof(float));
+    return EVR_OK;
+}
+extern "C" int evr_p6_pack_weights(const float* src, float* dst, int64_t n, int* exponent) {
+    EVR_REQUIRE(src && dst && exponent && n >= 0 && n % 16 == 0, "evr_p6_pack_weights: n = %lld must be a multiple of 16", (long long)n);
+    std::vector<float> w(src, src + n);
+    *exponent = pack_p6_weights(w);
+    memcpy(dst, w.data(), (size_t)n * sizeof(float));
+    return EVR_OK;
+}
+extern "C" int evr_p6_unpack(const float* src, float* dst, int64_t n) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_p6_unpack: n = %lld must be a multiple of 16", (long long)n);
+    unpack_p6(src, dst, (size_t)n);
+    return EVR_OK;
+}

@@ -424,6 +424,7 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
             for (int co = 0; co < cout[l]; ++co) for (int ci = 0; ci < cin[l]; ++ci) for (int t = 0; t < taps; ++t)
                 L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
             L.x3 = arith_mode();          // conv2..conv5 run on the same implicit-GEMM family as the networks, in their mode
+            if (L.x3 == 4) L.x3 = 2;      // (P6 tensors have no 4-channel writer -- the max pools, conv1's epilogue: LPIPS keeps the fp8 form)
             if (L.x3) L.mx_e = pack_weights_for(L.x3, L.w);
             if (L.x3 == 3) for (float& bv : L.b) bv = std::ldexp(bv, L.mx_e + H2_ACT_EXP);      // (model.cpp finish_conv)
             if ((rc = up(L.w, &L.d_w))) break;

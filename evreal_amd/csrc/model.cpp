@@ -90,12 +90,14 @@ struct evr_model {
     std::vector<float> head_w, head_b, pred_w;
     float pred_b = 0.f;
     float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
+    float* d_pred_w_scaled = nullptr;   // pred_w times the fused decoder's acc_scale (modes 3 / 4, ConvArgs::pred_prescaled)
     unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split modes, k5 x 5 bins x 32 channels)
     int head_wfrag_e = 0;               //   and their exponent (head_pack_wfrag)
     // shape-dependent
     int n_seq = 0, H = 0, W = 0, hp = 0, wp = 0, pad_top = 0, pad_left = 0, iy0 = 0, ix0 = 0;
+    int arith = 2;         // arithmetic mode of the 32-channel-chunk convolutions (conv.h arith_mode, narrowed by p6_eligible)
     bool packed = false;   // split mode: tensors between matrix-core convolutions use the PACKED format
-    int fmt = 0;           //   value of the `packed` flags of those tensors (conv.h packed_fmt: 1 PACKED, 2 H2)
+    int fmt = 0;           //   value of the `packed` flags of those tensors (conv.h packed_fmt: 1 PACKED, 2 H2, 3 P6)
     int pred_x_packed = 0, pred_skip_packed = 0;
     std::vector<std::pair<float*, size_t>> allocs;   // (pointer, bytes): state and activations, zeroed by every reset
     std::vector<float*> shape_consts;                // per-shape constant tables (ET-Net sine table): freed with the shape, never zeroed
@@ -149,7 +151,7 @@ struct evr_model {
                    if (d_head_wfrag) (void)hipFree(d_head_wfrag); if (d_sat) (void)hipFree(d_sat);
                    for (auto& pr : et_ln) { (void)hipFree(pr.first); (void)hipFree(pr.second); }
                    for (float* q : sp_seg_dw) (void)hipFree(q); for (float* q : sp_seg_db) (void)hipFree(q); if (d_sp_pred_w) (void)hipFree(d_sp_pred_w);
-                   if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
+                   if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); if (d_pred_w_scaled) (void)hipFree(d_pred_w_scaled); }
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
         allocs.clear();
@@ -352,7 +354,7 @@ void prep_s2d(Conv& c) {
 int finish_conv(evr_model* m, Conv& c) {
     int rc;
     // arithmetic mode: split (f16 + MX-fp8 corrections, conv.h) for the 32-channel-chunk convolutions unless EVR_FP32=1
-    c.x3 = (c.kc == 32) ? arith_mode() : 0;
+    c.x3 = (c.kc == 32) ? m->arith : 0;
     // 16-channel 3x3 layers (FireNet): v_mfma_f32_32x32x16_f16 contracts exactly one 16-channel H2 group, so in the split modes they
     // run the three-f16-product arithmetic on UNPADDED tensors (conv.hip conv3x3_c16_kernel) whatever the mode of the 32-channel
     // layers -- fp32-grade (the goldens hold 1e-5), and no longer the 1/16-rate fp32 MFMA.  EVR_FIRENET_H3=0: the exact-fp32 path.
@@ -373,6 +375,7 @@ int finish_conv(evr_model* m, Conv& c) {
     // mode 3 accumulates products scaled by 2^(e_w + H2_ACT_EXP): the accumulators start at the bias in that scale (exact:
     // a power of two) and the epilogue multiplies by ConvArgs::acc_scale
     if (c.x3 == 3) for (float& b : c.b) b = std::ldexp(b, c.mx_e + H2_ACT_EXP);
+    if (c.x3 == 4) for (float& b : c.b) b = std::ldexp(b, c.mx_e);      // (mode 4: weights scaled by 2^e_w, activations unscaled)
     if ((rc = upload(c.w, &c.d_w))) return rc;
     if ((rc = upload(c.b, &c.d_b))) return rc;
     m->convs.push_back(std::move(c));
@@ -864,7 +867,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.out = io.out[p]; a.cout_total = cout_total;
         a.epi = c.epi; a.residual = io.residual[p]; a.post_add = io.post_add[p];
         a.state = io.state[p]; a.aux0 = io.aux0[p]; a.hidden = c.hidden; a.x3 = c.x3;
-        a.acc_scale = (c.x3 == 3) ? std::ldexp(1.0f, -(c.mx_e + H2_ACT_EXP)) : 1.0f;
+        a.acc_scale = (c.x3 == 3) ? std::ldexp(1.0f, -(c.mx_e + H2_ACT_EXP)) : (c.x3 == 4 ? std::ldexp(1.0f, -c.mx_e) : 1.0f);
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
         a.sat = m->d_sat ? m->d_sat + ci : nullptr;
@@ -904,6 +907,16 @@ void try_fuse_pred(evr_model* m, int ci, const float* skip, bool skip_packed, fl
         a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
         a.prev_rec = m->prev_rec;
         if (!(m->desc.reserved[0] & 1)) a.out = nullptr;
+    }
+    // modes 3 / 4 accumulate at 2^e: relu(acc s) . w = relu(acc) . (s w) -- with the skip term arriving as one float per pixel nothing
+    // else in this epilogue needs the true scale, so the weights carry it (EVR_PRED_PRESCALE=0: the 16 multiplies per block instead)
+    static const bool prescale = getenv("EVR_PRED_PRESCALE") ? atoi(getenv("EVR_PRED_PRESCALE")) != 0 : true;
+    if (prescale && (c.x3 == 3 || c.x3 == 4) && by_dot && c.epi == EPI_BIAS_RELU && !(m->desc.reserved[0] & 1)) {
+        std::vector<float> ws(m->pred_w);
+        for (float& v : ws) v *= c.args[0].acc_scale;
+        if (!m->d_pred_w_scaled && hipMalloc((void**)&m->d_pred_w_scaled, ws.size() * sizeof(float)) != hipSuccess) return;
+        if (hipMemcpy(m->d_pred_w_scaled, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return;
+        for (int p = 0; p < 2; ++p) { c.args[p].pred_w = m->d_pred_w_scaled; c.args[p].pred_prescaled = 1; }
     }
     m->pred_fused_conv = ci;
 }
@@ -1101,6 +1114,11 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     DevTensor hdot;      // sum_c pred_w[c] * head[c] per pixel, written by the matrix-core head kernel (try_fuse_pred)
     if ((rc = alloc(m, &hdot, n, m->hp, m->wp, 1, stream))) return rc;
     try_fuse_pred(m, conv_index(m, "dec" + std::to_string(E - 1)), head.p, P, hdot.p);
+    if (P == 3 && m->pred_fused_conv >= 0 && (d.reserved[0] & 1)) {
+        // the debug copy of the last decoder's own output is written run by run (4 channels): PLAIN in the P6 mode
+        const std::string dn = "dec" + std::to_string(E - 1);
+        for (int p = 0; p < 2; ++p) { m->convs[m->pred_fused_conv].args[p].out_packed = 0; m->named[p][dn].packed = 0; }
+    }
     EVR_REQUIRE(!m->dynamic || m->pred_fused_conv >= 0, "dynamic decoder: the prediction layer could not be fused (prev_recs needs it)");
     return EVR_OK;
 }
@@ -1488,6 +1506,18 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
         for (int k = 0; k < t.ndim; ++k) t.shape[k] = tensors[i].shape[k];
         m->sd[tensors[i].name] = t;
     }
+    // EVR_ARITH=mx6 (f16 + MX-fp6, P6 tensors): P6 groups carry their own scale and are written WHOLE, by matrix-core epilogues.
+    // That covers the layouts whose packed tensors all come from such epilogues -- UNetRecurrent with ConvLSTM blocks, transposed-conv
+    // decoders, BatchNorm or no norm, and the 5-bin k5 32-channel head of the shipped E2VID checkpoints (the BASELINE configuration);
+    // layouts with VALU producers of packed tensors (bilinear upsampling, the dynamic decoder, InstanceNorm, ConvGRU's 4-channel
+    // epilogue, SPADE, ET-Net, FireNet) keep the f16 + MX-fp8 mode.
+    m->arith = arith_mode();
+    if (m->arith == 4) {
+        const evr_model_desc& d = *desc;
+        const bool ok = d.arch == EVR_ARCH_UNET_RECURRENT && d.recurrent_block == EVR_REC_CONVLSTM && !d.use_upsample_conv && !(d.reserved[1] & 1) &&
+                        d.norm != EVR_NORM_IN && d.base_num_channels == 32 && d.kernel_size == 5 && d.num_bins == 5 && use_group_store();
+        if (!ok) m->arith = 2;
+    }
     int rc;
     if (desc->arch == EVR_ARCH_UNET_RECURRENT) rc = build_unet(m);
     else if (desc->arch == EVR_ARCH_FIRENET_LEGACY || desc->arch == EVR_ARCH_FIRENET) rc = build_firenet(m);
@@ -1519,7 +1549,7 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     EVR_HIP(hipStreamSynchronize(stream));
     m->release_shape();
     m->n_seq = n_seq; m->H = H; m->W = W; m->frame = 0; m->flops = 0.0;
-    m->packed = false; m->fmt = packed_fmt(arith_mode());
+    m->packed = false; m->fmt = packed_fmt(m->arith);
     const bool firenet = m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET;
     const bool fire_padded = firenet && m->fire_C != m->desc.base_num_channels;
     {   // every tensor between the matrix-core convolutions is packed when ALL of them run a split arithmetic
@@ -1785,6 +1815,11 @@ extern "C" int evr_split_pack_device(const float* src, float* dst, int64_t n, ev
 extern "C" int evr_h2_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream) {
     EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_h2_pack_device: n = %lld must be a multiple of 16", (long long)n);
     return launch_to_packed(src, dst, n, (hipStream_t)stream, 2);
+}
+
+extern "C" int evr_p6_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream) {
+    EVR_REQUIRE(src && dst && n >= 0 && n % 16 == 0, "evr_p6_pack_device: n = %lld must be a multiple of 16", (long long)n);
+    return launch_to_packed(src, dst, n, (hipStream_t)stream, 3);
 }
 
 extern "C" int evr_split_unpack(const float* src, float* dst, int64_t n) {

@@ -87,12 +87,62 @@ __device__ __forceinline__ void store4_h2(float* p, unsigned row_off, int c4, f4
     float* q = p + pk_off(row_off, c4);
     *(uint2*)q = hi; *(uint2*)(q + 8) = lo;
 }
+// ---- the third PACKED format, "P6" (conv.h): per 16 channels 16 f16 hi | 32 e2m3 codes [x_0/S, lo_0, x_1/S, lo_1, ...] with the
+// group's own scale S = 2^(E - 2) | its E8M0 byte.  Written as WHOLE groups only (the scale needs the group's maximum):
+// store16_p6 from a matrix-core epilogue; 4-channel readers decode by hand (debug copies, VALU consumers).
+typedef unsigned v6u_t __attribute__((ext_vector_type(6)));
+typedef float f32x16v_t __attribute__((ext_vector_type(16)));
+typedef float f32x32v_t __attribute__((ext_vector_type(32)));
+constexpr float P6_LO_SCALE = 2048.0f, P6_LO_INV = 1.0f / 2048.0f;      // 2^P6_LO_EXP (conv.h)
+__device__ __forceinline__ float e2m3_dec(unsigned v) {
+    const unsigned m = v & 31u;
+    const unsigned mag = m < 8u ? m : ((8u | (m & 7u)) << ((m >> 3) - 1u));
+    const float f = (float)mag * 0.125f;
+    return (v & 32u) ? -f : f;
+}
+__device__ __forceinline__ f4 load4_p6(const float* p, unsigned row_off, int c4) {
+    const float* g = p + row_off + (unsigned)(c4 & ~15);
+    const int q = (c4 & 15) >> 2;
+    const uint2 hi = *(const uint2*)(g + 2 * q);
+    const unsigned short* s = (const unsigned short*)(g + 8) + 3 * q;      // 4 channels = 8 codes = 48 bits
+    const unsigned long long bits = (unsigned long long)s[0] | ((unsigned long long)s[1] << 16) | ((unsigned long long)s[2] << 32);
+    const float sc = __uint_as_float((__float_as_uint(g[14]) & 0xffu) << 23) * P6_LO_INV;
+    const h2_t h0 = __builtin_bit_cast(h2_t, hi.x), h1 = __builtin_bit_cast(h2_t, hi.y);
+    f4 v;
+    v[0] = fmaf(e2m3_dec((unsigned)(bits >> 6) & 63u), sc, (float)h0[0]);
+    v[1] = fmaf(e2m3_dec((unsigned)(bits >> 18) & 63u), sc, (float)h0[1]);
+    v[2] = fmaf(e2m3_dec((unsigned)(bits >> 30) & 63u), sc, (float)h1[0]);
+    v[3] = fmaf(e2m3_dec((unsigned)(bits >> 42) & 63u), sc, (float)h1[1]);
+    return v;
+}
+// 16 consecutive channels -> one P6 group
+__device__ __forceinline__ void store16_p6(float* p, unsigned row_off, int cg, const float (&w)[16]) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    f32x16v_t c, lo;
+    u4 hi0, hi1;
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { c[k] = __builtin_amdgcn_fmed3f(w[k], -65504.0f, 65504.0f); mx = fmaxf(mx, fabsf(c[k])); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const h2_t a = {(_Float16)c[2 * k], (_Float16)c[2 * k + 1]}, b = {(_Float16)c[8 + 2 * k], (_Float16)c[8 + 2 * k + 1]};
+        hi0[k] = __builtin_bit_cast(unsigned, a); hi1[k] = __builtin_bit_cast(unsigned, b);
+        lo[2 * k] = (c[2 * k] - (float)a[0]) * P6_LO_SCALE; lo[2 * k + 1] = (c[2 * k + 1] - (float)a[1]) * P6_LO_SCALE;
+        lo[8 + 2 * k] = (c[8 + 2 * k] - (float)b[0]) * P6_LO_SCALE; lo[8 + 2 * k + 1] = (c[8 + 2 * k + 1] - (float)b[1]) * P6_LO_SCALE;
+    }
+    unsigned eb = __float_as_uint(mx) >> 23;
+    eb = eb > 3u ? eb - 2u : 1u;
+    // (v_cvt_scalef32_2xpk16_fp6_f32: element 2i = src0[i] / 2^k, element 2i + 1 = src1[i] / 2^k, RNE, saturating at 7.5)
+    const v6u_t pk = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(c, lo, __uint_as_float(eb << 23));
+    u4* q = (u4*)(p + row_off + (unsigned)cg);
+    q[0] = hi0; q[1] = hi1; q[2] = u4{pk[0], pk[1], pk[2], pk[3]}; q[3] = u4{pk[4], pk[5], eb, 0u};
+}
 // Range guard of the packed formats.  PACKED: the fp8 residual lo8 = (x - hi) 2^12 saturates from |x| >= 256 on (and the fp8
 // copy x8 at 448): beyond that a value keeps only its f16 half (2^-12 relative).  H2: x 2^4 saturates at +-65504, i.e.
 // |x| > 4094 is CLAMPED.  Producers count the 4- / 16-channel runs that cross the limit in a per-layer counter
 // (evr_model_saturation); the test is a handful of v_max per run and the atomic fires only when it trips.
 template <int FMT> __device__ __forceinline__ void sat_note(unsigned* sat, float mx) {
-    constexpr float LIM = (FMT == 2) ? 65504.0f / H2_SCALE : 256.0f;
+    constexpr float LIM = (FMT == 2) ? 65504.0f / H2_SCALE : (FMT == 3 ? 65504.0f : 256.0f);      // (P6 scales per group: only the f16 half can clamp)
     if (sat && mx > LIM) atomicAdd(sat, 1u);
 }
 template <int FMT> __device__ __forceinline__ void sat_check4(unsigned* sat, f4 v) {
@@ -106,10 +156,14 @@ template <int FMT> __device__ __forceinline__ void sat_check16(unsigned* sat, co
 }
 // compile-time format selection for the matrix-core kernels (FMT: 1 = the f16 | fp8 | fp8 format above, 2 = H2)
 template <int FMT> __device__ __forceinline__ f4 load4_fmt(const float* p, unsigned row_off, int c4) {
-    if constexpr (FMT == 2) return load4_h2(p, row_off, c4); else return load4_packed(p, row_off, c4);
+    if constexpr (FMT == 3) return load4_p6(p, row_off, c4);
+    else if constexpr (FMT == 2) return load4_h2(p, row_off, c4);
+    else return load4_packed(p, row_off, c4);
 }
 template <int FMT> __device__ __forceinline__ void store4_fmt(float* p, unsigned row_off, int c4, f4 v) {
-    if constexpr (FMT == 2) store4_h2(p, row_off, c4, v); else store4_packed(p, row_off, c4, v);
+    if constexpr (FMT == 3) __builtin_trap();      // P6 has no 4-channel writer (launch_conv_igemm_m6 refuses such plans)
+    else if constexpr (FMT == 2) store4_h2(p, row_off, c4, v);
+    else store4_packed(p, row_off, c4, v);
 }
 // ---- whole-group stores from the MFMA accumulator layout ----------------------------------------------------------
 // A lane of the 32x32 MFMA result holds, of a 32-channel block, v[4q + j] = channel 8q + 4h + j (h = lane >> 5, lanes l
@@ -184,8 +238,29 @@ __device__ __forceinline__ void unpack16_xchg_h2(const unsigned (&g)[16], f32x16
         v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
     }
 }
+// (P6: dwords 0-7 hi | 8-13 codes | 14 scale byte)
+__device__ __forceinline__ void unpack16_xchg_p6(const unsigned (&g)[16], f32x16_t& v) {
+    float w[16];
+    const v6u_t pk = {g[8], g[9], g[10], g[11], g[12], g[13]};
+    const f32x32v_t un = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(pk, __uint_as_float((g[14] & 0xffu) << 23));
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const h2_t hh = __builtin_bit_cast(h2_t, g[d]);
+        w[2 * d] = fmaf(un[4 * d + 1], P6_LO_INV, (float)hh[0]);
+        w[2 * d + 1] = fmaf(un[4 * d + 3], P6_LO_INV, (float)hh[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[j]), __float_as_uint(w[4 + j]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[8 + j]), __float_as_uint(w[12 + j]), false, false);
+        v[j] = __uint_as_float(a[0]); v[8 + j] = __uint_as_float(a[1]);
+        v[4 + j] = __uint_as_float(b[0]); v[12 + j] = __uint_as_float(b[1]);
+    }
+}
 template <int FMT> __device__ __forceinline__ void store16_fmt(float* p, unsigned row_off, int cg, const float (&w)[16]) {
-    if constexpr (FMT == 2) store16_h2(p, row_off, cg, w); else store16_packed(p, row_off, cg, w);
+    if constexpr (FMT == 3) store16_p6(p, row_off, cg, w);
+    else if constexpr (FMT == 2) store16_h2(p, row_off, cg, w);
+    else store16_packed(p, row_off, cg, w);
 }
 // the reverse: one PACKED group as loaded (hi 8 dwords | lo8 4 dwords) -> its 16 values -> the accumulator order of the
 // lane pair (the same swaps: v_permlane32_swap is its own inverse on a register pair)
@@ -213,6 +288,12 @@ __device__ __forceinline__ float load1_packed(const float* row, int ch, int fmt 
     const unsigned char* g = (const unsigned char*)(row + (ch & ~15));
     const int k = ch & 15;
     if (fmt == 2) return ((float)((const _Float16*)g)[k] + (float)((const _Float16*)g)[16 + k]) * H2_INV;
+    if (fmt == 3) {
+        const int bit = 12 * k + 6;
+        const unsigned short* s = (const unsigned short*)(g + 32) + (bit >> 4);
+        const unsigned code = (((unsigned)s[0] | ((unsigned)s[1] << 16)) >> (bit & 15)) & 63u;
+        return fmaf(e2m3_dec(code), __uint_as_float((unsigned)g[56] << 23) * P6_LO_INV, (float)((const _Float16*)g)[k]);
+    }
     return fmaf(__builtin_amdgcn_cvt_f32_fp8((int)g[32 + k], 0), PK_LO_INV, (float)((const _Float16*)g)[k]);
 }
 #endif
@@ -220,6 +301,7 @@ __device__ __forceinline__ float load1_packed(const float* row, int ch, int fmt 
 // 4 consecutive channels (c4 % 4 == 0) of the pixel row at `row`: packed = 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2
 __device__ __forceinline__ float4 ld4_any(const float* row, int c4, int packed) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (packed == 3) { const f4 t = load4_p6(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
     if (packed == 2) { const f4 t = load4_h2(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
     if (packed) { const f4 t = load4_packed(row, 0u, c4); return make_float4(t[0], t[1], t[2], t[3]); }
 #endif
@@ -227,6 +309,7 @@ __device__ __forceinline__ float4 ld4_any(const float* row, int c4, int packed) 
 }
 __device__ __forceinline__ void st4_any(float* row, int c4, float4 v, int packed) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (packed == 3) __builtin_trap();      // P6 tensors are written as whole groups only (packed.h store16_p6)
     if (packed == 2) { const f4 t = {v.x, v.y, v.z, v.w}; store4_h2(row, 0u, c4, t); return; }
     if (packed) { const f4 t = {v.x, v.y, v.z, v.w}; store4_packed(row, 0u, c4, t); return; }
 #endif

@@ -84,6 +84,10 @@ SYMBOLS = {
     'evr_h2_pack_weights': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'evr_h2_unpack': (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     'evr_h2_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_p6_pack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_p6_pack_weights': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'evr_p6_unpack': (c_int, [c_void_p, c_void_p, c_int64]),
+    'evr_p6_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'evr_h2_act_exponent': (c_int, []),
     'evr_fastdiv_magic': (c_int, [ctypes.c_uint, c_void_p, c_void_p]),
 }

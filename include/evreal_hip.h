@@ -280,6 +280,15 @@ int evr_h2_pack_weights(const float* src, float* dst, int64_t n, int* exponent);
 int evr_h2_unpack(const float* src, float* dst, int64_t n, int exponent);
 int evr_h2_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
 int evr_h2_act_exponent(void);
+/* The P6 storage format of the f16 + MX-fp6 arithmetic mode (EVR_ARITH=mx6): every 16 values -> 16 IEEE halves hi = RNE(v) |
+ * 32 e2m3 codes (6 bits, element j at bits 6j of bytes 32-55): element 2i = v_i / S, element 2i + 1 = (v_i - hi_i) 2^11 / S,
+ * S = 2^(floor(log2 max|v|) - 2) the group's own scale | its E8M0 byte (byte 56).  Weights: values times 2^e (max|w| 2^e in
+ * [2^13, 2^14), e returned), the two elements of a pair swapped, the scale byte lowered by 11.  evr_p6_unpack decodes an
+ * ACTIVATION tensor (hi + residual).  Host codec + the device twin (v_cvt_scalef32_2xpk16_fp6_f32), as for the formats above. */
+int evr_p6_pack(const float* src, float* dst, int64_t n);
+int evr_p6_pack_weights(const float* src, float* dst, int64_t n, int* exponent);
+int evr_p6_unpack(const float* src, float* dst, int64_t n);
+int evr_p6_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
 int evr_fastdiv_magic(unsigned d, unsigned* mul, unsigned* shift);
 
 #ifdef __cplusplus

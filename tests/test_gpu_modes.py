@@ -61,6 +61,20 @@ def test_parity_in_fp32_equivalent_mode_on_the_band_kernels():
     _run({'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
 
 
+def test_parity_in_f16_fp6_mode():
+    # EVR_ARITH=mx6: the E2VID-type layouts (ConvLSTM, transposed decoders, 5-bin k5 head) run f16 + MX-fp6 on P6 tensors; every
+    # other layout of these files falls back to the default mode inside the same process (model.cpp evr_model_create)
+    _run({'EVR_ARITH': 'mx6'})
+
+
+def test_parity_in_f16_fp6_mode_on_the_band_kernels():
+    _run({'EVR_ARITH': 'mx6', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
+
+
+def test_parity_in_f16_fp6_mode_on_the_implicit_gemm():
+    _run({'EVR_ARITH': 'mx6', 'EVR_NO_BAND': '1'})
+
+
 def _run_firenet(env_extra):
     env = dict(os.environ, **env_extra)
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_model.py', 'tests/test_gpu_fullsize.py', 'tests/test_gpu_eval.py',

@@ -142,3 +142,22 @@ def test_h2_codec_device_equals_host_bit_for_bit():
     _lib.check(L.evr_h2_pack_device(_lib.ptr(d), _lib.ptr(d), x.size, _lib.stream_ptr()), 'evr_h2_pack_device')
     got = d.cpu().numpy()
     np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+def test_p6_codec_device_equals_host_bit_for_bit():
+    """The P6 codec of the f16 + MX-fp6 mode as the kernels run it (v_cvt_f16_f32 + ONE v_cvt_scalef32_2xpk16_fp6_f32 per group with
+    the group's own scale) against the host codec that tests/test_split_codec.py pins to numpy."""
+    import ctypes
+    from evreal_amd import lib as _lib
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.standard_normal(1 << 16) * 10.0 ** rng.integers(-9, 4, 1 << 16), rng.standard_normal(1 << 15) * 2.0,
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 0.5, 255.0, 7.5, 7.75, 8.0, 65504.0, 7e4, 2.0 ** -14, 2.0 ** -28],
+                        np.zeros(16)]).astype(np.float32)
+    x = np.resize(x, (x.size // 16) * 16)
+    want = np.empty_like(x)
+    assert L.evr_p6_pack(x.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), x.size) == 0
+    d = torch.from_numpy(x).cuda()
+    _lib.check(L.evr_p6_pack_device(_lib.ptr(d), _lib.ptr(d), x.size, _lib.stream_ptr()), 'evr_p6_pack_device')
+    got = d.cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.uint8), want.view(np.uint8))

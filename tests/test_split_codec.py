@@ -126,3 +126,68 @@ def test_fastdiv_constants_divide_exactly():
         n = n[n < (1 << 31)]
         q = (((n * np.uint64(mul.value)) >> np.uint64(32)) + n) >> np.uint64(sh.value)
         np.testing.assert_array_equal(q, n // np.uint64(d), err_msg=str(d))
+
+
+# ---- P6: the f16 + MX-fp6 mode's format (EVR_ARITH=mx6) ------------------------------------------------------------------
+_E2M3 = np.array([m * 0.125 if m < 8 else (8 + (m & 7)) * 2.0 ** ((m >> 3) - 4) for m in range(32)], np.float64)   # the 32 magnitudes
+
+
+def _e2m3_codes(v):
+    """Round to nearest (ties to the even code), saturating at 7.5 -- an independent numpy statement of the OCP e2m3 rounding."""
+    a = np.abs(v.astype(np.float64))
+    i = np.clip(np.searchsorted(_E2M3, a, side='left'), 1, 31)
+    lo, hi = _E2M3[i - 1], _E2M3[i]
+    pick_hi = (a - lo > hi - a) | ((a - lo == hi - a) & ((i & 1) == 0))
+    code = np.where(pick_hi, i, i - 1)
+    code = np.where(a >= 7.5, 31, np.where(a == 0, 0, code))
+    return (code | (np.signbit(v).astype(np.int64) << 5)).astype(np.uint8)
+
+
+def _ref_pack_p6(x, e=0, weights=False):
+    c = np.clip(np.ldexp(x.astype(np.float32).reshape(-1, 16), e), -65504.0, 65504.0).astype(np.float32)
+    hi = c.astype(np.float16)
+    lo = ((c - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float32)
+    mx = np.abs(c).max(axis=1)
+    eb = (mx.view(np.uint32) >> 23).astype(np.int64)
+    eb = np.where(eb > 3, eb - 2, 1)
+    s = np.ldexp(np.float64(1.0), eb - 127)[:, None]
+    cv, cl = _e2m3_codes(c / s), _e2m3_codes(lo / s)
+    codes = np.empty((c.shape[0], 32), np.uint8)
+    codes[:, 0::2] = cl if weights else cv
+    codes[:, 1::2] = cv if weights else cl
+    bits = np.zeros((c.shape[0], 24), np.uint8)
+    for j in range(32):
+        v16 = codes[:, j].astype(np.uint16) << ((6 * j) & 7)
+        bits[:, (6 * j) >> 3] |= (v16 & 0xff).astype(np.uint8)
+        if ((6 * j) & 7) > 2:
+            bits[:, ((6 * j) >> 3) + 1] |= (v16 >> 8).astype(np.uint8)
+    tail = np.zeros((c.shape[0], 8), np.uint8)
+    tail[:, 0] = np.maximum(eb - 11, 1) if weights else eb
+    return np.concatenate([hi.view(np.uint8).reshape(-1, 32), bits, tail], axis=1).reshape(-1)
+
+
+def test_p6_codec_matches_numpy_and_keeps_the_split_precision():
+    """hi = f16(v) | 32 e2m3 codes [v/S, (v - hi) 2^11 / S] with the group's scale S = 2^(E - 2) | the E8M0 byte: bit for bit against
+    numpy, then the precision the arithmetic relies on -- decoded activations within 2^-16 of the group's largest value."""
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.standard_normal(8192) * 10.0 ** rng.integers(-9, 4, 8192),
+                        rng.standard_normal(4096) * 3.0,                                  # groups of similar magnitudes
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, 1e-30, 0.5, 255.0, 7.5, 7.75, 8.0, 65504.0, 65519.0, 7e4, 2.0 ** -14, 2.0 ** -15],
+                        np.zeros(16)]).astype(np.float32)
+    got = _call('evr_p6_pack', x)
+    np.testing.assert_array_equal(got.view(np.uint8), _ref_pack_p6(x))
+    y = np.empty_like(x)
+    assert L.evr_p6_unpack(got.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), x.size) == 0
+    xs = np.clip(x, -65504.0, 65504.0).reshape(-1, 16); ys = y.reshape(-1, 16)
+    gmax = np.abs(xs).max(axis=1, keepdims=True)
+    ok = gmax[:, 0] >= 2.0 ** -10                          # (below that the f16 half is subnormal: absolute 2^-25)
+    assert (np.abs(ys[ok] - xs[ok]) / gmax[ok]).max() <= 2.0 ** -16
+    assert np.abs(ys[~ok] - xs[~ok]).max() <= 2.0 ** -24
+    # weights: values times 2^e (largest in [2^13, 2^14)), code pairs swapped, scale byte lowered by 11
+    for scale in (1e-3, 0.05, 1.0, 300.0):
+        w = (rng.uniform(-1, 1, 4096) * scale).astype(np.float32)
+        got = np.empty_like(w); e = ctypes.c_int(0)
+        assert L.evr_p6_pack_weights(w.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p), w.size, ctypes.byref(e)) == 0
+        assert 2.0 ** 13 <= float(np.abs(w).max()) * 2.0 ** e.value < 2.0 ** 14
+        np.testing.assert_array_equal(got.view(np.uint8), _ref_pack_p6(w, e.value, weights=True))
