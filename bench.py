@@ -24,14 +24,16 @@ quoted on):
     color    ColorNet over the E2VID+ layout, 970x624 (BS-ERGB's 970x625 cropped to even sides: the reference's ColorNet
              raises on odd sides), 50k events/window, 1 sequence = 5 recurrent streams; no metrics (the reference skips them)
     e2vidplus / etnet / spade   the other methods of the reference's registry (E2VID+ = SSL-E2VID layout, ET-Net, SPADE-E2VID), 346x260
-Arithmetic (csrc/conv.h): default split f16 + MX-fp8 ("mx"); EVR_ARITH=h3 three f16 products, fp32-grade; EVR_FP32=1
-exact fp32 MFMA.
+Arithmetic (csrc/conv.h): default split f16 + MX-fp6 ("mx6") where the layout's packed tensors all come from matrix-core epilogues
+(E2VID), split f16 + MX-fp8 ("mx") for the other layouts and under EVR_ARITH=mx; EVR_ARITH=h3 three f16 products, fp32-grade;
+EVR_FP32=1 exact fp32 MFMA.  `config.arithmetic_mode` / `dtype` report what the model actually ran (evr_model_arith).
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Besides `roofline` (dominant kernel) and
 `cpu_baseline` it carries, all measured OUTSIDE the timed region of the same run:
   roofline_voxelizer  HIP-event time of the tensorizer launches (in the step and standalone at S and 512 windows)
   score_parity        the first frames of sequence 0 replayed on the GPU and through the CPU oracle: per-frame image
                       error, mean MSE/SSIM/LPIPS of both, relative error, agreement to 3 significant figures
+  fp8_cross_terms     the same steps in a sub-process with EVR_ARITH=mx (f16 + MX-fp8: last round's arithmetic), with its own parity
   fp32_equiv          the same steps in a sub-process with EVR_ARITH=h3 (three f16 products: fp32-grade), with its own parity
   fp32_exact          ... with EVR_FP32=1 (exact fp32 MFMA arithmetic), with its own parity
   sensor_640x480      the same workload on 640x480 streams (north_star's second sensor size), with its own parity
@@ -66,11 +68,15 @@ OKEYS = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks',
          'use_upsample_conv', 'recurrent_block_type', 'final_activation']
 
 
-def arith_name():
+def arith_name(net=None):
+    """The arithmetic the network's convolutions run: EVR_ARITH (default mx6) narrowed by the library to what the layout supports."""
+    a = getattr(net, 'arith', None) or getattr(getattr(net, 'model', None), 'arith', None)
+    if a:
+        return a
     if os.environ.get('EVR_FP32') or os.environ.get('EVR_ARITH') == 'fp32':
         return 'fp32'
     e = os.environ.get('EVR_ARITH')
-    return 'h3' if e == 'h3' else ('mx6' if e == 'mx6' else 'mx')
+    return e if e in ('h3', 'mx', 'mx6') else 'mx6'
 
 
 DTYPE = {'mx': 'f16+mxfp8', 'mx6': 'f16+mxfp6', 'h3': 'f16x3', 'fp32': 'f32'}
@@ -324,13 +330,15 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic():
+def measured_traffic(an='mx6'):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes -- only if they were
-    taken on THIS source (profiles/pmc_traffic.json stores the sha of the kernel sources); otherwise null."""
+    taken on THIS source (profiles/pmc_traffic.json stores the sha of the kernel sources) in THIS arithmetic; otherwise null."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if not os.path.exists(path):
         return None, "no PMC pass committed"
     d = json.load(open(path))
+    if d.get('arith', 'mx') != an:
+        return None, f"PMC passes in profiles/ were taken in the '{d.get('arith', 'mx')}' arithmetic, this run is '{an}'"
     if d.get('source_sha') != source_sha():
         return None, (f"PMC passes in profiles/ were taken on kernel sources {d.get('source_sha')}, this build is "
                       f"{source_sha()}: re-run tools/profile_round.sh (last value: {d.get('convlstm_bytes_per_launch')})")
@@ -404,7 +412,7 @@ def run_color(args, wl, device):
     prof = [dict(p, name='full.' + p['name']) for p in net.model.profile_read()] + [dict(p, name='half.' + p['name']) for p in net.half.profile_read()]
     net.model.profile(None); net.half.profile(None)
     flops = net.model.flops_per_step() + net.half.flops_per_step()
-    an = arith_name()
+    an = arith_name(net)
     peak = PEAK_F32_MFMA_TFLOPS if an == 'fp32' else PEAK_BF16_MFMA_TFLOPS
     dom = dominant_group(prof)
     out = {"metric": "reconstructed frames/sec + Mevents/sec voxelized, ColorNet (E2VID+ layout) %dx%d B=5" % (W_, H_),
@@ -607,7 +615,7 @@ def main():
                             metrics=('mse', 'ssim', 'lpips'), device=str(device), lpips=lp, overlap=not args.no_overlap)
     hp = mk(n_seq)
     scores = torch.zeros((K + Wm, n_seq, 3), dtype=torch.float64, device=device)
-    an = arith_name()
+    an = arith_name(wl.net)
     # layers bracketed inside the timed region: the recurrent gate convolutions for E2VID (the dominant kernel the roofline block
     # quotes, as in earlier rounds); every launch for the other configurations, whose dominant layer is found from the table
     pf = args.profile_filter if args.profile_filter is not None else ('rec' if wl.name == 'e2vid' else '')
@@ -735,7 +743,7 @@ def main():
             gbs = nbytes / (rl_ms * 1e-3) / 1e9
             hbm_block = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "bytes_per_launch": round(nbytes / max(rl_launches, 1)), "note": "ConvGRU gate convolutions: 4 (zr) / 5 (out) passes over 16-channel tensors"}
-        traffic, traffic_note = measured_traffic() if (an == 'mx' and wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
+        traffic, traffic_note = measured_traffic(an) if (wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
         sel = set(p['name'] for p in lstm)
         out = {
             "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID', 'etnet': 'ET-Net', 'spade': 'SPADE-E2VID', 'e2vidplus': 'E2VID+'}[wl.name], W_, H_),
@@ -881,6 +889,7 @@ def main():
             b["cpu_frames_per_s"] = (d.get('cpu_baseline') or {}).get('value')
             return b
 
+        out["fp8_cross_terms"] = brief(sub_run([], {'EVR_ARITH': 'mx'}, K, Wm))      # the round-2 arithmetic (f16 + MX-fp8), same steps
         out["fp32_equiv"] = brief(sub_run([], {'EVR_ARITH': 'h3'}, K, Wm))
         out["fp32_exact"] = brief(sub_run([], {'EVR_FP32': '1'}, K, Wm))
         big = sub_run(['--sensor', '640x480'], {}, K, Wm)

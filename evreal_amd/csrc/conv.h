@@ -102,8 +102,6 @@ struct ConvArgs {
     float* prev_rec;          // optional [n,1,hout,wout]: the un-cropped prediction (E2VIDRecurrent.prev_recs, model.py:143)
     unsigned* sat;            // optional device counter: output runs beyond the packed format's exact range (packed.h sat_note)
     int band_lds_pad;         // conv_bandk_kernel: extra dynamic LDS bytes per block (caps the blocks per CU; host-side only)
-    int pred_prescaled;       // modes 3 / 4 with a fused prediction and no other consumer: pred_w already carries acc_scale (ReLU commutes
-                              //   with a positive scale), the epilogue skips its 16 multiplies per block
     int no_band5;             // keep a 5x5 stride-1 convolution on the implicit GEMM (LPIPS conv2: on the evaluation stream the band form's
                               //   three 51-KB blocks per CU crowd the reconstruction stream's work-groups out: 6.0k vs 6.8k frames/s)
 };
@@ -377,19 +375,19 @@ inline int pack_p6_weights(std::vector<float>& w) {
     return e;
 }
 // arithmetic mode of the 32-channel-chunk convolutions (ConvArgs::x3):
-//   2  split f16 + MX-fp8 corrections on PACKED tensors (default);
-//   4  split f16 + MX-fp6 corrections on P6 tensors (EVR_ARITH=mx6; layouts whose packed tensors are all written as whole
-//      groups by matrix-core epilogues -- model.cpp decides, the others run mode 2);
+//   4  split f16 + MX-fp6 corrections on P6 tensors (default, "mx6") -- for layouts whose packed tensors are all written as whole
+//      groups by matrix-core epilogues; evr_model_create narrows it to mode 2 for the others, LPIPS always runs mode 2;
+//   2  split f16 + MX-fp8 corrections on PACKED tensors (EVR_ARITH=mx: everywhere);
 //   3  three f16 products on H2 tensors, fp32-grade (EVR_ARITH=h3);
 //   0  exact fp32 MFMA on PLAIN tensors (EVR_FP32=1 or EVR_ARITH=fp32)
 inline int arith_mode() {
     if (getenv("EVR_FP32")) return 0;
     const char* e = getenv("EVR_ARITH");
-    if (!e || !*e || !strcmp(e, "mx")) return 2;
-    if (!strcmp(e, "mx6")) return 4;
+    if (!e || !*e || !strcmp(e, "mx6")) return 4;
+    if (!strcmp(e, "mx")) return 2;
     if (!strcmp(e, "h3")) return 3;
     if (!strcmp(e, "fp32")) return 0;
-    return 2;
+    return 4;
 }
 inline bool use_split_mode() { return arith_mode() != 0; }
 // value of the `packed` flags for tensors of a mode: 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2, 3 P6

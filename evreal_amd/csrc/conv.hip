@@ -283,13 +283,11 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
     const int m = ec.m;
     const bool mvalid = ec.mvalid;
     if constexpr ((ARITH == 3 || ARITH == 4) && FAST) {      // (FAST = a split kernel) products were accumulated at 2^(e_w + H2_ACT_EXP) / 2^e_w
-        if (!a.pred_prescaled) {      // (block-uniform)
-            const float sc = a.acc_scale;
+        const float sc = a.acc_scale;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nb][i] *= sc;
-        }
+            for (int i = 0; i < 16; ++i) acc[nb][i] *= sc;
     }
     if constexpr (LSTM) {
         static_assert(!LSTM || NB == 4, "the ConvLSTM epilogue needs the four gates in one wave tile");

@@ -90,7 +90,6 @@ struct evr_model {
     std::vector<float> head_w, head_b, pred_w;
     float pred_b = 0.f;
     float* d_head_w = nullptr; float* d_head_b = nullptr; float* d_pred_w = nullptr;
-    float* d_pred_w_scaled = nullptr;   // pred_w times the fused decoder's acc_scale (modes 3 / 4, ConvArgs::pred_prescaled)
     unsigned* d_head_wfrag = nullptr;   // head weights in MFMA-fragment order (split modes, k5 x 5 bins x 32 channels)
     int head_wfrag_e = 0;               //   and their exponent (head_pack_wfrag)
     // shape-dependent
@@ -151,7 +150,7 @@ struct evr_model {
                    if (d_head_wfrag) (void)hipFree(d_head_wfrag); if (d_sat) (void)hipFree(d_sat);
                    for (auto& pr : et_ln) { (void)hipFree(pr.first); (void)hipFree(pr.second); }
                    for (float* q : sp_seg_dw) (void)hipFree(q); for (float* q : sp_seg_db) (void)hipFree(q); if (d_sp_pred_w) (void)hipFree(d_sp_pred_w);
-                   if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); if (d_pred_w_scaled) (void)hipFree(d_pred_w_scaled); }
+                   if (d_head_w) (void)hipFree(d_head_w); if (d_head_b) (void)hipFree(d_head_b); if (d_pred_w) (void)hipFree(d_pred_w); }
     void release_shape() {
         for (auto& pr : allocs) (void)hipFree(pr.first);
         allocs.clear();
@@ -907,16 +906,6 @@ void try_fuse_pred(evr_model* m, int ci, const float* skip, bool skip_packed, fl
         a.crop_h = m->H; a.crop_w = m->W; a.crop_y0 = m->iy0; a.crop_x0 = m->ix0;
         a.prev_rec = m->prev_rec;
         if (!(m->desc.reserved[0] & 1)) a.out = nullptr;
-    }
-    // modes 3 / 4 accumulate at 2^e: relu(acc s) . w = relu(acc) . (s w) -- with the skip term arriving as one float per pixel nothing
-    // else in this epilogue needs the true scale, so the weights carry it (EVR_PRED_PRESCALE=0: the 16 multiplies per block instead)
-    static const bool prescale = getenv("EVR_PRED_PRESCALE") ? atoi(getenv("EVR_PRED_PRESCALE")) != 0 : true;
-    if (prescale && (c.x3 == 3 || c.x3 == 4) && by_dot && c.epi == EPI_BIAS_RELU && !(m->desc.reserved[0] & 1)) {
-        std::vector<float> ws(m->pred_w);
-        for (float& v : ws) v *= c.args[0].acc_scale;
-        if (!m->d_pred_w_scaled && hipMalloc((void**)&m->d_pred_w_scaled, ws.size() * sizeof(float)) != hipSuccess) return;
-        if (hipMemcpy(m->d_pred_w_scaled, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return;
-        for (int p = 0; p < 2; ++p) { c.args[p].pred_w = m->d_pred_w_scaled; c.args[p].pred_prescaled = 1; }
     }
     m->pred_fused_conv = ci;
 }
@@ -1735,6 +1724,10 @@ extern "C" int evr_model_set_gate(evr_model* m, const char* layer, evr_event_t e
 }
 
 extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->flops : 0.0; }
+
+// arithmetic mode of the model's 32-channel-chunk convolutions (conv.h arith_mode): 0 fp32, 2 f16 + MX-fp8, 3 three f16 products,
+// 4 f16 + MX-fp6 -- what EVR_ARITH asked for, narrowed to what the layout supports (evr_model_create)
+extern "C" int evr_model_arith(const evr_model* m) { return m ? m->arith : -1; }
 
 // Range guard of the packed activation formats (packed.h sat_note): how many output runs (4 or 16 channels of one pixel)
 // of the matrix-core producers left the format's exact range since the counters were last cleared, and in which layer most.

@@ -164,16 +164,20 @@ class _HipModel:
         """Once per sequence (eval loops): report activations beyond the split format's range instead of degrading silently."""
         n, layer = self.saturation(clear=True)
         if n:
-            import os
-            mode = os.environ.get('EVR_ARITH', 'mx') if not os.environ.get('EVR_FP32') else 'fp32'
+            mode = self.arith
+            how = {'h3': " (clamped at +-4094)", 'mx6': " (beyond +-65504: clamped)"}.get(mode, " (f16 only, 2^-12 relative)")
             print(f"WARNING: {n} activation runs{(' of ' + what) if what else ''} left the exact range of the '{mode}' packed "
-                  f"format (most in layer '{layer}'): those values kept reduced precision"
-                  + (" (clamped at +-4094)" if mode == 'h3' else " (f16 only, 2^-12 relative)")
-                  + "; rerun with EVR_ARITH=h3 or EVR_FP32=1 for data of this magnitude")
+                  f"format (most in layer '{layer}'): those values kept reduced precision" + how
+                  + "; rerun with EVR_FP32=1 for data of this magnitude")
         return n
 
     def flops_per_step(self):
         return float(self.lib.evr_model_flops_per_step(self.handle))
+
+    @property
+    def arith(self):
+        """'mx6' | 'mx' | 'h3' | 'fp32': the arithmetic this model's convolutions run (EVR_ARITH narrowed to what the layout supports)."""
+        return {0: 'fp32', 2: 'mx', 3: 'h3', 4: 'mx6'}.get(int(self.lib.evr_model_arith(self.handle)), '?')
 
 
 class E2VIDRecurrent(_HipModel):

@@ -48,10 +48,13 @@ def test_score_parity_three_significant_figures():
 
 
 def test_traffic_is_null_when_profiles_are_stale(monkeypatch):
-    v, note = bench.measured_traffic()
     import json
     d = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    v, note = bench.measured_traffic(d.get('arith', 'mx'))
     if d.get('source_sha') == bench.source_sha():
         assert v == d['convlstm_bytes_per_launch']
     else:
         assert v is None and 're-run' in note
+    other = 'mx' if d.get('arith', 'mx') != 'mx' else 'mx6'
+    v, note = bench.measured_traffic(other)          # passes taken in another arithmetic never count
+    assert v is None and 'arithmetic' in note

@@ -39,7 +39,7 @@ def _fire(tag, cls_name):
     # states live on the padded grid; the golden stores a ::3 subsample of the reference's padded state
     hp, wp = ((H + 15) // 16 * 16, (W + 15) // 16 * 16) if cls_name == 'FireNet_legacy' else (H, W)
     # (EVR_FIRENET_PAD32=1 in the default split mode: the states themselves are stored PACKED, ~2^-16 relative per product term)
-    split_mx = os.environ.get('EVR_FIRENET_PAD32', '0') not in ('', '0') and os.environ.get('EVR_ARITH', 'mx') == 'mx' and not os.environ.get('EVR_FP32')
+    split_mx = os.environ.get('EVR_FIRENET_PAD32', '0') not in ('', '0') and os.environ.get('EVR_ARITH', 'mx6') in ('mx', 'mx6') and not os.environ.get('EVR_FP32')
     for i in range(2):
         h = m.read_tensor(f'h{i}').cpu().numpy().reshape(1, 16, hp, wp)
         np.testing.assert_allclose(h[:, :, ::3, ::3], z[f'state{i}_sub'], rtol=1e-4, atol=2e-4 if split_mx else 1e-5)
@@ -328,8 +328,9 @@ def test_etnet_golden(norm, tag):
 
 
 def test_large_activations_are_reported_not_silent():
-    """The packed activation formats have a finite exact range (csrc/packed.h sat_note): PACKED's fp8 pieces saturate from
-    |x| ~ 256 on (the value then keeps only its f16 half, 2^-12 relative), H2 (EVR_ARITH=h3) clamps at +-4094.  Inputs 30x the
+    """The packed activation formats have a finite exact range (csrc/packed.h sat_note): PACKED's fp8 pieces (EVR_ARITH=mx) saturate
+    from |x| ~ 256 on (the value then keeps only its f16 half, 2^-12 relative), H2 (EVR_ARITH=h3) clamps at +-4094, P6 (the default for
+    this layout) scales every 16-channel group by its own maximum and only clamps beyond the half-precision range.  Inputs 30x the
     usual magnitude stay inside and pass the gate with a zero counter; at 300x and beyond every frame EITHER still passes
     1e-4 OR evr_model_saturation reports the excursion (so the degradation is never silent); results stay finite."""
     from evreal_amd import model, weights
@@ -365,7 +366,7 @@ def test_large_activations_are_reported_not_silent():
             assert worst < 1e-4 or runs > 0, (scale, runs, layer, worst)       # never a silent degradation
             if runs:
                 assert layer != ''
-            if os.environ.get('EVR_ARITH', 'mx') == 'mx' and scale < 1e4:
-                assert worst < loose, (scale, worst)   # PACKED beyond its range: the f16 half alone still carries 2^-12
+            if os.environ.get('EVR_ARITH', 'mx6') in ('mx', 'mx6') and scale < 1e4:
+                assert worst < loose, (scale, worst)   # PACKED beyond its range: the f16 half alone still carries 2^-12 (P6 scales per group)
             if scale >= 1e4:
                 assert runs > 0, scale                 # inputs beyond the half-precision range itself (+-65504) are clamped: reported

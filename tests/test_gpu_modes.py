@@ -61,18 +61,19 @@ def test_parity_in_fp32_equivalent_mode_on_the_band_kernels():
     _run({'EVR_ARITH': 'h3', 'EVR_TEST_IMG_ATOL': '1e-5', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
 
 
-def test_parity_in_f16_fp6_mode():
-    # EVR_ARITH=mx6: the E2VID-type layouts (ConvLSTM, transposed decoders, 5-bin k5 head) run f16 + MX-fp6 on P6 tensors; every
-    # other layout of these files falls back to the default mode inside the same process (model.cpp evr_model_create)
-    _run({'EVR_ARITH': 'mx6'})
+def test_parity_in_f16_fp8_mode():
+    # The default arithmetic is f16 + MX-fp6 on P6 tensors for the E2VID-type layouts (ConvLSTM, transposed decoders, 5-bin k5 head)
+    # and f16 + MX-fp8 on PACKED tensors for every other layout (model.cpp evr_model_create): the tests above ran that mix.
+    # EVR_ARITH=mx puts the E2VID-type layouts on the fp8 form too.
+    _run({'EVR_ARITH': 'mx'})
 
 
-def test_parity_in_f16_fp6_mode_on_the_band_kernels():
-    _run({'EVR_ARITH': 'mx6', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1'})
+def test_parity_in_f16_fp8_mode_on_the_band_kernels():
+    _run({'EVR_ARITH': 'mx', 'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '3'})
 
 
-def test_parity_in_f16_fp6_mode_on_the_implicit_gemm():
-    _run({'EVR_ARITH': 'mx6', 'EVR_NO_BAND': '1'})
+def test_parity_in_f16_fp8_mode_on_the_implicit_gemm():
+    _run({'EVR_ARITH': 'mx', 'EVR_NO_BAND': '1'})
 
 
 def _run_firenet(env_extra):

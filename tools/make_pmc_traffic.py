@@ -33,6 +33,7 @@ if __name__ == '__main__':
     out = {"_comment": "HBM-side traffic of the dominant kernel (ConvLSTM gate convolutions) from rocprofv3 PMC passes; "
                        "see profiles/README.md", "kernel": ks, "profile": name, "launches": [nf, nw],
            "fetch_size_kb_per_launch_raw": f_kb, "fetch_correction": 2.0, "write_size_kb_per_launch": w_kb,
-           "convlstm_bytes_per_launch": int((2.0 * f_kb + w_kb) * 1024), "source_sha": bench.source_sha()}
+           "convlstm_bytes_per_launch": int((2.0 * f_kb + w_kb) * 1024), "source_sha": bench.source_sha(),
+           "arith": "mx6" if any('m6::' in k for k in ks) else ("h3" if any('h3::' in k for k in ks) else "mx")}
     json.dump(out, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))
