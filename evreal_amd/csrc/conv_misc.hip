@@ -505,7 +505,53 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const float* __rest
     st4_any(out + (((int64_t)img * 2 * h + oy) * 2 * w + ox) * c, c4 * 4, o4, out_packed);
 }
 
+// The same on P6 tensors: one thread per (output pixel, 16-channel group) -- a P6 group is written whole (its scale is the
+// group's maximum) and decodes whole with one conversion instruction (packed.h load16_p6 / store16_p6).
+__global__ __launch_bounds__(256) void upsample2x_sum_p6_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                                 float* __restrict__ out, int n, int h, int w, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int gn = c / 16;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)n * 2 * h * 2 * w * gn;
+    if (i >= total) return;
+    const int g = (int)(i % gn);
+    int64_t p = i / gn;
+    const int ox = (int)(p % (2 * w)); p /= 2 * w;
+    const int oy = (int)(p % (2 * h));
+    const int img = (int)(p / (2 * h));
+    float sy = 0.5f * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = 0.5f * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    float v[4][16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = (k & 2) ? y1 : y0, xx = (k & 1) ? x1 : x0;
+        const int64_t o = (((int64_t)img * h + yy) * w + xx) * c + g * 16;
+        load16_p6(x + o, v[k]);
+        if (skip) {
+            float u[16];
+            load16_p6(skip + o, u);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[k][j] += u[j];
+        }
+    }
+    float o16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o16[j] = hy * (hx * v[0][j] + lx * v[1][j]) + ly * (hx * v[2][j] + lx * v[3][j]);
+    store16_p6(out + (((int64_t)img * 2 * h + oy) * 2 * w + ox) * c, 0u, g * 16, o16);
+#endif
+}
+
 int launch_upsample2x_sum(const float* x, const float* skip, float* out, int n, int h, int w, int c, int x_packed, int skip_packed, int out_packed, hipStream_t stream) {
+    if (out_packed == 3) {
+        EVR_REQUIRE(c % 16 == 0 && x_packed == 3 && (!skip || skip_packed == 3), "upsample: a P6 output takes P6 inputs (%d / %d), channels %d a multiple of 16", x_packed, skip_packed, c);
+        const int64_t total = (int64_t)n * 4 * h * w * (c / 16);
+        hipLaunchKernelGGL(upsample2x_sum_p6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, skip, out, n, h, w, c);
+        EVR_LAUNCH_CHECK();
+        return EVR_OK;
+    }
     EVR_REQUIRE(c % 4 == 0, "upsample: channels %d not a multiple of 4", c);
     EVR_REQUIRE(!(x_packed || skip_packed || out_packed) || c % 16 == 0, "upsample: PACKED tensors need channels %d to be a multiple of 16", c);
     const int64_t total = (int64_t)n * 4 * h * w * (c / 4);

@@ -1067,6 +1067,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
             Step s; s.kind = ST_UPSAMPLE; s.out = up.p; s.h = h; s.w = w; s.c = cin; s.a_packed = P; s.b_packed = P; s.out_packed = P;
             for (int p = 0; p < 2; ++p) { s.a[p] = x[p]; s.b[p] = sk[p].p; }
             m->steps.push_back(s);
+            name2(m, dn + ".up", up, up);
             h *= 2; w *= 2;
             if ((rc = alloc(m, &o, n, h, w, cout, stream, P))) return rc;
             ConvIO a{};
@@ -1495,15 +1496,15 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
         for (int k = 0; k < t.ndim; ++k) t.shape[k] = tensors[i].shape[k];
         m->sd[tensors[i].name] = t;
     }
-    // EVR_ARITH=mx6 (f16 + MX-fp6, P6 tensors): P6 groups carry their own scale and are written WHOLE, by matrix-core epilogues.
-    // That covers the layouts whose packed tensors all come from such epilogues -- UNetRecurrent with ConvLSTM blocks, transposed-conv
-    // decoders, BatchNorm or no norm, and the 5-bin k5 32-channel head of the shipped E2VID checkpoints (the BASELINE configuration);
-    // layouts with VALU producers of packed tensors (bilinear upsampling, the dynamic decoder, InstanceNorm, ConvGRU's 4-channel
-    // epilogue, SPADE, ET-Net, FireNet) keep the f16 + MX-fp8 mode.
+    // mx6 (f16 + MX-fp6, P6 tensors; the default): P6 groups carry their own scale and are written WHOLE -- by matrix-core epilogues
+    // and by the bilinear upsampling kernel's group form.  That covers UNetRecurrent with ConvLSTM blocks, transposed-conv or
+    // upsample-conv decoders, BatchNorm or no norm, and the 5-bin k5 32-channel head: the E2VID / E2VID+ / SSL-E2VID checkpoints'
+    // layouts (BASELINE configurations 2 and 5).  Layouts with 4-channel producers of packed tensors (the dynamic decoder,
+    // InstanceNorm, ConvGRU's epilogue, SPADE, ET-Net, FireNet) keep the f16 + MX-fp8 mode.
     m->arith = arith_mode();
     if (m->arith == 4) {
         const evr_model_desc& d = *desc;
-        const bool ok = d.arch == EVR_ARCH_UNET_RECURRENT && d.recurrent_block == EVR_REC_CONVLSTM && !d.use_upsample_conv && !(d.reserved[1] & 1) &&
+        const bool ok = d.arch == EVR_ARCH_UNET_RECURRENT && d.recurrent_block == EVR_REC_CONVLSTM && !(d.reserved[1] & 1) &&
                         d.norm != EVR_NORM_IN && d.base_num_channels == 32 && d.kernel_size == 5 && d.num_bins == 5 && use_group_store();
         if (!ok) m->arith = 2;
     }

@@ -115,6 +115,23 @@ __device__ __forceinline__ f4 load4_p6(const float* p, unsigned row_off, int c4)
     v[3] = fmaf(e2m3_dec((unsigned)(bits >> 42) & 63u), sc, (float)h1[1]);
     return v;
 }
+// one whole P6 group (g = its 64 B) -> 16 values: a single v_cvt_scalef32_pk32_f32_fp6 decodes all the codes
+__device__ __forceinline__ void load16_p6(const float* g, float (&v)[16]) {
+    // (the 16 dwords are read as float4s and taken apart by name: indexing a 4-wide integer vector with the unrolled loop variable
+    // made hipcc use element 0 for every k here -- tools/up_diag.py found channels 2-7 / 10-15 carrying the halves of channels 0-1 / 8-9)
+    const float4* q = (const float4*)g;
+    const float4 qa = q[0], qb = q[1], qc = q[2], qd = q[3];
+    const unsigned a[4] = {__float_as_uint(qa.x), __float_as_uint(qa.y), __float_as_uint(qa.z), __float_as_uint(qa.w)};
+    const unsigned b[4] = {__float_as_uint(qb.x), __float_as_uint(qb.y), __float_as_uint(qb.z), __float_as_uint(qb.w)};
+    const v6u_t pk = {__float_as_uint(qc.x), __float_as_uint(qc.y), __float_as_uint(qc.z), __float_as_uint(qc.w), __float_as_uint(qd.x), __float_as_uint(qd.y)};
+    const f32x32v_t un = __builtin_amdgcn_cvt_scalef32_pk32_f32_fp6(pk, __uint_as_float((__float_as_uint(qd.z) & 0xffu) << 23));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const h2_t h0 = __builtin_bit_cast(h2_t, a[k]), h1 = __builtin_bit_cast(h2_t, b[k]);
+        v[2 * k] = fmaf(un[4 * k + 1], P6_LO_INV, (float)h0[0]); v[2 * k + 1] = fmaf(un[4 * k + 3], P6_LO_INV, (float)h0[1]);
+        v[8 + 2 * k] = fmaf(un[16 + 4 * k + 1], P6_LO_INV, (float)h1[0]); v[8 + 2 * k + 1] = fmaf(un[16 + 4 * k + 3], P6_LO_INV, (float)h1[1]);
+    }
+}
 // 16 consecutive channels -> one P6 group
 __device__ __forceinline__ void store16_p6(float* p, unsigned row_off, int cg, const float (&w)[16]) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));

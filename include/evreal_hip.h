@@ -183,7 +183,7 @@ int evr_model_set_gate(evr_model* model, const char* layer, evr_event_t ev);
 double evr_model_flops_per_step(const evr_model* m);
 /* arithmetic of the model's 32-channel-chunk convolutions: 0 exact fp32, 2 f16 + MX-fp8 ("mx"), 3 three f16 products ("h3"),
  * 4 f16 + MX-fp6 ("mx6") -- the mode EVR_ARITH selects, narrowed to what the layout supports ("mx6" needs a layout whose packed
- * tensors are all written by matrix-core epilogues; others run "mx") */
+ * tensors are all written as whole 16-channel groups: ConvLSTM UNets with transposed or upsample-conv decoders; others run "mx") */
 int evr_model_arith(const evr_model* m);
 /* Range guard of the packed activation formats the split arithmetic modes store between layers: number of output runs
  * (4 or 16 channels of one pixel) that left the format's exact range since the last clear, and the layer with most of them
