@@ -401,7 +401,7 @@ inline int use_group_store() { const char* e = getenv("EVR_GROUP_STORE"); return
 // `a` is the host copy (grid sizing, validation); `d_args` the same plan resident in device memory (the
 // kernel reads it with scalar loads; it is uploaded once per shape, not per launch).
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img = nullptr);
-// (conv.hip is compiled once per split arithmetic: mode 2 + the fp32 kernels, and mode 3; launch_conv_igemm dispatches on a.x3)
+// (conv.hip is compiled once per split arithmetic: mode 2 + the fp32 kernels, mode 3, mode 4; launch_conv_igemm dispatches on a.x3)
 int launch_conv_igemm_mx(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 int launch_conv_igemm_h3(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 int launch_conv_igemm_m6(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
@@ -455,7 +455,7 @@ struct CtxArgs {
 int launch_ctx_down(const CtxArgs& a, hipStream_t stream);
 // HyperE2VID per-pixel dynamic filtering (hyper_dynamic.py:50-57,83-88): atoms = coeff[6,12] x bases[12,25];
 // out[pix][c*6+m] = sum_l atoms[m][l] * x[pix + offset(l)][c] over the 5x5 neighbourhood (zero padded).
-// (out_fmt: 0 PLAIN, 1 PACKED, 2 H2 -- the format of `out`, written directly)
+// (out_fmt: 0 PLAIN, 1 PACKED, 2 H2 -- the format of `out`, written directly; P6 has no 4-channel writer)
 int launch_dynamic_filter(const float* x, const float* coeff, const float* bases, float* out, int n, int h, int w,
                           int c, hipStream_t stream, int out_fmt = 0);
 

@@ -9,7 +9,7 @@
 //   GEMM view   M = n*hm*wm output pixels, N = output channels, K = taps x input channels
 //   data        activations NHWC fp32 (a K chunk of 16/32 channels of one pixel = one 64/128-B line);
 //               weights pre-laid as [N][K] (K contiguous) at model creation, BatchNorm folded
-//   MFMA        two arithmetic modes on the same tiles (template X3):
+//   MFMA        the arithmetic modes on the same tiles (template X3 = fp32 or split; EVR_ARITH picks the split):
 //               fp32   v_mfma_f32_32x32x2_f32, an exact fp32 fma chain (157 TF peak) -- FireNet (16-channel chunks)
 //                      and the reference mode (EVR_FP32=1);
 //               split  (conv.h) x = hi + lo8 2^-12, w = hi + wlo8 2^-(e+12) with f16 'hi' halves (RNE) and fp8 e4m3
@@ -21,6 +21,10 @@
 //                      (tools/split_scheme_sim.py; gate 1e-4; three bf16 products 1.7e-5, plain bf16 9e-3).
 //                      Weights are pre-split on the host, activations by the PRODUCING kernel's epilogue (PACKED
 //                      format): the main loop feeds 16-B LDS slots straight to the MFMAs
+//               split6 (EVR_ARITH = 4, conv.h P6) the same with the cross terms in e2m3 (fp6) and one E8M0 scale per 16-channel
+//                      group: both operands fp6 -> the MX MFMA takes 8 passes instead of 16, 2 x 32 + 32 = 96 matrix cycles
+//                      per 32 k; the default for the layouts whose packed tensors are written as whole groups
+//               h3     (EVR_ARITH = 3, conv.h H2) three f16 products per term: fp32-grade, 192 matrix cycles per 32 k
 //   tile        block = WM waves stacked along M; a wave owns 32 pixels x (NB*32) channels, i.e. NB
 //               accumulators of 16 VGPRs; for ConvLSTM NB = 4 and the weight rows are permuted so
 //               the four 32-column blocks are the in/remember/out/cell gates of the SAME 32 hidden
@@ -44,8 +48,9 @@
 #include <cstdlib>
 
 // This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
-// exact-fp32 kernels -- and EVR_ARITH = 3 -- three f16 products on H2 tensors (conv.h).  Kernels live in their own inner
-// namespace so the two objects do not collide; conv_misc.hip dispatches on ConvArgs::x3.
+// exact-fp32 kernels -- EVR_ARITH = 3 -- three f16 products on H2 tensors -- and EVR_ARITH = 4 -- f16 + MX-fp6 on P6 tensors, the
+// default where the layout allows (conv.h).  Kernels live in their own inner namespace so the objects do not collide;
+// conv_misc.hip dispatches on ConvArgs::x3.
 #ifndef EVR_ARITH
 #define EVR_ARITH 2
 #endif

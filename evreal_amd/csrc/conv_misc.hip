@@ -1,6 +1,6 @@
 // The convolution family's kernels that do not depend on the split arithmetic: the head convolutions (direct VALU and
 // matrix-core forms), the standalone prediction layer, HyperE2VID's context / dynamic-filter kernels, bilinear upsample,
-// skip-sum, format conversion -- and the dispatcher over conv.hip's two compilations (ConvArgs::x3).
+// skip-sum, format conversion -- and the dispatcher over conv.hip's three compilations (ConvArgs::x3).
 #include "conv.h"
 #include "packed.h"
 #include <cstdlib>
@@ -12,8 +12,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// conv.hip is compiled twice (build.py): -DEVR_ARITH=2 carries the f16 + MX-fp8 split kernels and the exact-fp32 ones,
-// -DEVR_ARITH=3 the three-f16-product kernels on H2 tensors.
+// conv.hip is compiled three times (build.py): -DEVR_ARITH=2 carries the f16 + MX-fp8 split kernels and the exact-fp32 ones,
+// -DEVR_ARITH=3 the three-f16-product kernels on H2 tensors, -DEVR_ARITH=4 the f16 + MX-fp6 kernels on P6 tensors.
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
     if (a.x3 == 3) return launch_conv_igemm_h3(a, d_args, kc, wm, nb, stream, img);
     if (a.x3 == 4) return launch_conv_igemm_m6(a, d_args, kc, wm, nb, stream, img);

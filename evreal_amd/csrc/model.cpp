@@ -915,7 +915,7 @@ int plan_unet(evr_model* m, hipStream_t stream) {
     const int E = d.num_encoders, base = d.base_num_channels, n = m->n_seq;
     const bool lstm = d.recurrent_block == EVR_REC_CONVLSTM;
     int rc;
-    const int P = m->packed ? m->fmt : 0;   // every tensor that feeds a matrix-core convolution is PACKED (1) / H2 (2) in the split modes
+    const int P = m->packed ? m->fmt : 0;   // every tensor that feeds a matrix-core convolution is PACKED (1) / H2 (2) / P6 (3) in the split modes
     DevTensor head;
     if ((rc = alloc(m, &head, n, m->hp, m->wp, base, stream, P))) return rc;
     name2(m, "head", head, head);

@@ -1,4 +1,5 @@
-// Device helpers for the PACKED activation format (conv.h): per 16 channels 16 f16 'hi' | 16 fp8 'lo8' | 16 fp8 'x8'.
+// Device helpers for the packed activation formats (conv.h).  PACKED: per 16 channels 16 f16 'hi' | 16 fp8 'lo8' | 16 fp8 'x8';
+// H2 and P6 further down.
 #pragma once
 #include <hip/hip_runtime.h>
 
