@@ -96,6 +96,30 @@ def test_lpips_vs_oracle(shape):
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
 
 
+def test_lpips_with_user_supplied_weights():
+    """When the real AlexNet-v0.1 LPIPS weights are available (EVREAL_LPIPS_WEIGHTS = a torch.save'd pyiqa / lpips state_dict, the
+    file evreal_amd.eval picks up), the HIP path and the oracle are compared on THEM -- trained filters instead of the synthetic
+    statistics.  Offline the weights cannot be obtained: the test then skips and says so."""
+    import os
+    from evreal_amd.eval_metrics import LPIPS_WEIGHTS_ENV
+    path = os.environ.get(LPIPS_WEIGHTS_ENV, os.path.join('pretrained', 'lpips_alex.pth'))
+    if not os.path.exists(path):
+        pytest.skip(f'no LPIPS weights at ${LPIPS_WEIGHTS_ENV} / pretrained/lpips_alex.pth (pyiqa downloads them; there is no network here)')
+    from evreal_amd.lpips import LPIPS
+    from oracle import lpips as ol
+    sd = torch.load(path, map_location='cpu', weights_only=False)
+    sd = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, 'detach') else v, dtype=np.float32) for k, v in sd.items()}
+    H, W = 260, 346
+    rng = np.random.default_rng(17)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ref = np.stack([0.5 + 0.4 * np.sin(xx / (7.0 + i)) * np.cos(yy / (9.0 + i)) for i in range(3)]).astype(np.float32)
+    img = np.clip(ref + 0.1 * rng.standard_normal(ref.shape), 0, 1).astype(np.float32)
+    m = LPIPS(sd)
+    got = m(torch.from_numpy(img).cuda(), torch.from_numpy(ref).cuda()).cpu().numpy()
+    want = ol.lpips(sd, img, ref)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
+
+
 def test_metrics_kernel_against_the_published_definition():
     """evr_metrics vs the Wang et al. known answers (tests/golden/metrics_published.npz, float64, explicit window loops)."""
     import json
