@@ -141,3 +141,30 @@ def test_full_size_properties(vox):
     psum = ps.astype(np.float64).reshape(nw, n).sum(1)
     np.testing.assert_allclose(sums, psum, atol=2e-2)
     assert np.abs(a).max() <= 64
+
+
+def test_clustered_events(vox):
+    """Windows whose events sit in a few sensor rows (one range with 20k records = 80 ticket chunks, ranges around the
+    one-chunk limit, cancelling +1/-1 pairs that return a cell to +0 before it is touched again, a full-sensor window
+    behind them) stay bit-exact, statistics included."""
+    from oracle import voxel as ov
+    rng = np.random.default_rng(21)
+    W, H, B = 346, 260, 5
+    xs, ys, ts, ps, offs = [], [], [], [], [0]
+    for i, (n, y_lo, y_hi) in enumerate([(20000, 100, 104), (700, 8, 12), (520, 0, 4), (3000, 250, 260), (9000, 0, 260)]):
+        x = rng.integers(0, W, n); y = rng.integers(y_lo, y_hi, n)
+        t = np.sort(rng.uniform(0, 2e-2, n)); t = (t - t[0]).astype(np.float32)
+        p = rng.integers(0, 2, n) * 2.0 - 1.0
+        if i == 2:                                # pairs on one pixel and identical timestamps: +v then -v
+            x[1::2] = x[0::2]; y[1::2] = y[0::2]; t[1::2] = t[0::2]; p[1::2] = -p[0::2]
+        xs.append(x.astype(np.float32)); ys.append(y.astype(np.float32)); ts.append(t); ps.append(p.astype(np.float32))
+        offs.append(offs[-1] + n)
+    x, y, t, p = map(np.concatenate, (xs, ys, ts, ps))
+    got, st = run(vox, x, y, t, p, offs, B, H, W, stats=True)
+    want = ov.voxelize_windows(x, y, t, p, offs, B, (H, W))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for w in range(len(offs) - 1):
+        w64 = want[w].astype(np.float64)
+        assert int(st[w, 2]) == int((want[w] != 0).sum())
+        np.testing.assert_allclose(st[w, 0], w64.sum(), rtol=0, atol=1e-6 * max(1.0, np.abs(w64).sum()))
+        np.testing.assert_allclose(st[w, 1], (w64 ** 2).sum(), rtol=1e-6, atol=1e-12)
