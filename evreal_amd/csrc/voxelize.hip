@@ -357,20 +357,45 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     float f1 = 0.f, f2 = 0.f; int fz = 0;
     const int Rc = nrows * W;
     float* o = out + (int64_t)w * B * HW + (int64_t)y0 * W;
-    for (int b = 0; b < B; ++b) {
-        for (int j = tid * 4; j < Rc; j += K2T * 4) {
-            const float4 v = *(const float4*)&acc[b * Rp + j];
-            if (vec_out && j + 4 <= Rc) {
-                *(float4*)&o[(int64_t)b * HW + j] = v;
-            } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                for (int q = 0; q < 4; ++q)
-                    if (j + q < Rc) o[(int64_t)b * HW + j + q] = vv[q];
+    if (vec_out && !(Rc & 3)) {      // (the last range of a window may have fewer rows: Rc % 4 != 0 takes the general loop)
+        // 16-B groups of all bins flattened (group j of bin b), four per thread and pass: the LDS reads of a pass are in
+        // flight together and its stores leave back to back, instead of one read -> wait -> store round per group
+        const int Rq = Rc >> 2, total = B * Rq;
+        int b = 0, j = tid;
+        for (int i0 = tid; i0 < total; i0 += 4 * K2T) {
+            float4 v[4]; int64_t go[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ok[u] = i0 + u * K2T < total;
+                while (j >= Rq) { j -= Rq; ++b; }
+                go[u] = (int64_t)b * HW + 4 * j;
+                v[u] = ok[u] ? *(const float4*)&acc[b * Rp + 4 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                j += K2T;
             }
-            // cells beyond the range end stay zero in LDS, so they do not disturb the statistics
-            f1 += (v.x + v.y) + (v.z + v.w);
-            f2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            fz += (v.x != 0.f) + (v.y != 0.f) + (v.z != 0.f) + (v.w != 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) *(float4*)&o[go[u]] = v[u];
+                f1 += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                f2 += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+                fz += (v[u].x != 0.f) + (v[u].y != 0.f) + (v[u].z != 0.f) + (v[u].w != 0.f);
+            }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            for (int j = tid * 4; j < Rc; j += K2T * 4) {
+                const float4 v = *(const float4*)&acc[b * Rp + j];
+                if (vec_out && j + 4 <= Rc) {
+                    *(float4*)&o[(int64_t)b * HW + j] = v;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int q = 0; q < 4; ++q)
+                        if (j + q < Rc) o[(int64_t)b * HW + j + q] = vv[q];
+                }
+                // cells beyond the range end stay zero in LDS, so they do not disturb the statistics
+                f1 += (v.x + v.y) + (v.z + v.w);
+                f2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                fz += (v.x != 0.f) + (v.y != 0.f) + (v.z != 0.f) + (v.w != 0.f);
+            }
         }
     }
     if (partials) {
