@@ -374,7 +374,13 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (ok[u]) *(float4*)&o[go[u]] = v[u];
+                if (ok[u]) {
+                    // non-temporal: the grid is consumed much later (and is larger than the caches); streamed past the L2, it
+                    // no longer evicts the records and segment tables the range work-groups are about to read
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    __builtin_nontemporal_store(t, (f4*)&o[go[u]]);
+                }
                 f1 += (v[u].x + v[u].y) + (v[u].z + v[u].w);
                 f2 += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
                 fz += (v[u].x != 0.f) + (v[u].y != 0.f) + (v[u].z != 0.f) + (v[u].w != 0.f);
