@@ -45,7 +45,7 @@ constexpr int K1W = K1T / 64;       // its waves
 constexpr int SEG = 2048;           // events per segment: 4 per thread, event (wave k, slot j, lane l) = k*256 + j*64 + l
 constexpr int K2T = 256;            // threads of a range workgroup
 constexpr int K2W = K2T / 64;
-constexpr int NTAG = 1024;          // ticket slots of a range workgroup (hashed by pixel)
+constexpr int NTAG = 512;         // ticket slots of a range workgroup (hashed by pixel)
 constexpr int MAXSEG = 64;          // segment tables folded per pass of the range kernel
 constexpr int ACC_KB_DEFAULT = 34;  // LDS for the B x rows x W cells of a range (5 rows of 346: four workgroups per CU)
 constexpr int MAX_G = 4096;
