@@ -6,29 +6,33 @@
 // The reference adds, per (bin, pixel) cell, the fp32 weights of the events that hit it IN EVENT
 // ORDER.  Float atomics would break that order, so every cell is accumulated in LDS by a workgroup
 // that sees the cell's events in time order.  The pixel plane is cut into G RANGES of `rows`
-// consecutive sensor rows (B x rows x W cells = one workgroup's LDS, 41.5 KB at 346x260, B = 5).
+// consecutive sensor rows (B x rows x W cells = one workgroup's LDS: 4 rows = 27.7 KB at 346x260, B = 5).
 //
 //   K1 vox_split   several 512-thread workgroups per window, each taking SEGMENTS of 2048 consecutive
 //                  events: one load round trip fetches coordinates, timestamps and polarities (12
 //                  independent loads per lane), then every event is finished ONCE -- t_norm with the
 //                  reference's exact fp32 operation order, its range and its cell offset -- and the
 //                  segment is stably partitioned by range (ballot ranks inside a wave, per-wave LDS
-//                  histograms, one prefix) into 16-B records {t_norm, p, offset}.  A per-segment table
-//                  of G+1 offsets says where each range's records sit.
-//   K2 vox_range   one 256-thread workgroup per (window, range); three fit a CU.  It reads its
+//                  histograms, one prefix) into records -- 8 B {t_norm, offset | polarity byte << 24} in the
+//                  raw form, 16 B {t_norm, p, offset} in the fp32 form.  A per-segment table of G+1
+//                  offsets says where each range's records sit.
+//   K2 vox_range   one 256-thread workgroup per (window, range); five fit a CU.  It reads its
 //                  slice of every segment table (one round trip), then its records (a second one,
 //                  ~N/G of them, contiguous per segment, in time order), and accumulates them one
 //                  record per thread: threads that hit the same pixel are serialised
 //                  lowest-thread-first through an LDS atomic-min ticket, so every cell sees its adds
 //                  in event order.  Only the (at most two) bins with a non-zero weight are touched --
 //                  adding the reference's +-0 products never changes a cell (cells start at +0).  The
-//                  finished range streams out with 16-B stores: every output cell is written exactly
+//                  finished range streams out with 16-B NON-TEMPORAL stores (the grid is consumed much
+//                  later and is larger than the caches: streamed past the L2 it no longer evicts the
+//                  records its neighbours are about to read): every output cell is written exactly
 //                  once, zero fill included, and nothing is ever read back from HBM.  Per-range
 //                  {sum, sum of squares, nnz} feed eval.py:402-405.
 //   K3 vox_stats   fixed-order reduction of the per-range partials -> stats[w][3] (deterministic).
 //
 // HBM-side traffic per window: the events once (13 N raw / 16 N fp32) + 4 B H W (output) -- the
-// algorithmic bytes of SURVEY 8d -- plus 2 x 16 N of records that normally stay in L2 / Infinity Cache.
+// algorithmic bytes of SURVEY 8d -- plus 2 x 8 N (raw) / 2 x 16 N (fp32 form) of records that normally stay in the
+// L2 / Infinity Cache.
 //
 // fp32 arithmetic is one IEEE rounding per op (this file is built with -ffp-contract=off; HIP's
 // default correctly-rounded fp32 divide is kept), matching torch's CPU kernels.
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(K1T) void vox_split_kernel(
 
         // ---- one round trip: everything the segment's events need (clamped indices: every load is unconditional) ----
         int rel[4]; bool ok[4];
-        int xi[4], yi[4]; float tn[4], pv[4];
+        int xi[4], yi[4]; float tn[4], pv[4]; unsigned pbyte[4] = {0u, 0u, 0u, 0u};
         if (RAW) {
             uint32_t wd[4]; double td[4]; uint8_t pb[4];
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(K1T) void vox_split_kernel(
                 const float tf = (float)(td[j] - t0d);                   // dataset.py:56 (f64 subtract, cast)
                 if (lin) tn[j] = lin_tnorm(rel[j], n, B);
                 else { float q = (tf - 0.0f) / dt; tn[j] = q * bm1; }    // ts[0] is exactly 0 after the shift
-                pv[j] = (float)((double)pb[j] * 2.0 - 1.0);              // dataset.py:227
+                pv[j] = 0.f; pbyte[j] = pb[j];                          // p = 2 pol - 1 (dataset.py:227) is formed by the range kernel
             }
         } else {
             float fx[4], fy[4], ft[4];
@@ -222,12 +226,15 @@ __global__ __launch_bounds__(K1T) void vox_split_kernel(
         for (int b = tid; b <= G; b += K1T) trow[b] = bbase[b];
 
         // ---- scatter the records ----
+        // raw form: 8-B records {t_norm, offset | polarity byte << 24} (offset < 2^15); fp32 form: 16-B {t_norm, p, offset, -}
         float4* srec = rec + rb + (int64_t)sg * SEG;
+        float2* srec2 = (float2*)rec + rb + (int64_t)sg * SEG;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (bkt[j] >= 0) {
                 const int pos = bbase[bkt[j]] + hist[k * G + bkt[j]] + rank[j];
-                srec[pos] = make_float4(tn[j], pv[j], __uint_as_float(off[j]), 0.f);
+                if (RAW) srec2[pos] = make_float2(tn[j], __uint_as_float(off[j] | (pbyte[j] << 24)));
+                else srec[pos] = make_float4(tn[j], pv[j], __uint_as_float(off[j]), 0.f);
             }
         }
         __syncthreads();                       // before the next segment re-zeroes hist
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(K1T) void vox_split_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ K2
+template <bool RAW>
 __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end, const int64_t* __restrict__ rec_base,
     const float4* __restrict__ rec, const int* __restrict__ table, float* __restrict__ out,
@@ -312,8 +320,16 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
                 int s = 0;                                  // segment of record i: seg_pre[s] <= i < seg_pre[s+1]
                 for (int step = MAXSEG / 2; step > 0; step >>= 1)
                     if (s + step < ns && seg_pre[s + step] <= i) s += step;
-                const float4 r = rec[rb + (int64_t)(sg0 + s) * SEG + seg_at[s] + (i - seg_pre[s])];
-                tn = r.x; p = r.y; pl = __float_as_uint(r.z);
+                const int64_t ri = rb + (int64_t)(sg0 + s) * SEG + seg_at[s] + (i - seg_pre[s]);
+                if (RAW) {
+                    const float2 r = ((const float2*)rec)[ri];
+                    const unsigned wd = __float_as_uint(r.y);
+                    tn = r.x; pl = wd & 0xFFFFFFu;
+                    p = (float)((double)(wd >> 24) * 2.0 - 1.0);             // dataset.py:227
+                } else {
+                    const float4 r = rec[ri];
+                    tn = r.x; p = r.y; pl = __float_as_uint(r.z);
+                }
             }
             const unsigned h = pl & (NTAG - 1);
             for (;; ++round) {
@@ -508,7 +524,7 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     const unsigned bit = RAW ? 2u : 1u;
     if (dev < 0 || dev >= 64 || !(attr_done[dev].load(std::memory_order_relaxed) & bit)) {
         EVR_HIP(hipFuncSetAttribute((const void*)vox_split_kernel<RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EVR_HIP(hipFuncSetAttribute((const void*)vox_range_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EVR_HIP(hipFuncSetAttribute((const void*)vox_range_kernel<RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev >= 0 && dev < 64) attr_done[dev].fetch_or(bit, std::memory_order_relaxed);
     }
     // split workgroups per window: enough for the average window in one pass, at most 32 (longer windows loop)
@@ -528,7 +544,7 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     const int xcd_map = n_windows >= 8;
     const int64_t blocks = xcd_map ? (int64_t)((n_windows + 7) / 8) * 8 * pl.G : (int64_t)n_windows * pl.G;
     EVR_REQUIRE(blocks < (1LL << 31), "evr_voxelize: %d windows x %d ranges exceed the grid", n_windows, pl.G);
-    hipLaunchKernelGGL(vox_range_kernel, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
+    hipLaunchKernelGGL(vox_range_kernel<RAW>, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
                        rec, table, out, partials, hdr, n_windows, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map);
     EVR_LAUNCH_CHECK();
     if (stats) {

@@ -92,6 +92,21 @@ def test_raw_form_matches_dataset_path(vox):
         assert np.array_equal(got[w].view(np.uint32), want.view(np.uint32)), w
 
 
+def test_raw_form_keeps_any_polarity_byte(vox):
+    """The raw form's 8-B records carry the polarity BYTE (p = 2 pol - 1 is formed by the range kernel, dataset.py:227):
+    files whose polarity column holds something other than 0 / 1 give what the reference's arithmetic gives."""
+    from oracle import voxel as ov
+    from evreal_amd import synth
+    t, x, y, p = synth.poisson_events(9, 20000, 1.0e6, 346, 260)
+    p = np.random.default_rng(1).choice(np.array([0, 1, 2, 7, 255], np.uint8), len(p))
+    xy = np.stack([x, y], axis=1)
+    offs = np.array([0, 20000], dtype=np.int64)
+    got = vox.voxelize_raw(dev(xy), dev(t), dev(p), dev(offs), 5, (260, 346)).cpu().numpy()
+    xs, ys, ts, ps = synth.window_events_f32(t, xy, p, 0, 20000)
+    want = ov.events_to_voxel(xs, ys, ts, ps, 5, (260, 346))
+    assert np.array_equal(got[0].view(np.uint32), want.view(np.uint32))
+
+
 def test_out_of_range_events_are_dropped_and_counted(vox):
     x = np.array([1, 400, 3, -2], np.float32); y = np.array([1, 2, 300, 5], np.float32)
     t = np.array([0, 1e-3, 2e-3, 3e-3], np.float32); p = np.ones(4, np.float32)
