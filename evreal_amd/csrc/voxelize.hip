@@ -247,7 +247,8 @@ template <bool RAW>
 __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end, const int64_t* __restrict__ rec_base,
     const float4* __restrict__ rec, const int* __restrict__ table, float* __restrict__ out,
-    double* __restrict__ partials, VoxHeader* hdr, int n_windows, int G, int rows, int Rp, int B, int H, int W, int vec_out, int xcd_map) {
+    double* __restrict__ partials, VoxHeader* hdr, int n_windows, int G, int rows, int Rp, int B, int H, int W, int vec_out, int xcd_map,
+    unsigned rq_magic) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.x == 0 && threadIdx.x == 0) {       // K1 has finished (kernel boundary): publish its count, re-arm the counter
         hdr->dropped_last = hdr->dropped_acc;
@@ -373,35 +374,42 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     float f1 = 0.f, f2 = 0.f; int fz = 0;
     const int Rc = nrows * W;
     float* o = out + (int64_t)w * B * HW + (int64_t)y0 * W;
-    if (vec_out && !(Rc & 3)) {      // (the last range of a window may have fewer rows: Rc % 4 != 0 takes the general loop)
-        // 16-B groups of all bins flattened (group j of bin b), four per thread and pass: the LDS reads of a pass are in
-        // flight together and its stores leave back to back, instead of one read -> wait -> store round per group
-        const int Rq = Rc >> 2, total = B * Rq;
-        int b = 0, j = tid;
-        for (int i0 = tid; i0 < total; i0 += 4 * K2T) {
-            float4 v[4]; int64_t go[4]; bool ok[4];
+    int nzw = 0;                       // non-zero cells counted per wave (uniform), fast path
+    if (vec_out && rq_magic && nrows == rows) {      // (a last range with fewer rows takes the general loop)
+        // 16-B groups of all bins flattened (index i = group j of bin b = i / Rq by multiply-high), four per thread and
+        // pass: the LDS reads of a pass are in flight together and its stores leave back to back.  The kernel issues VALU
+        // instructions for 70 % of its cycles (profiles/r03_voxelizer_pmc.md), so the statistics ride on packed fp32
+        // adds / FMAs and a ballot count instead of 20 scalar-per-lane operations per group.
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const unsigned Rq = (unsigned)Rc >> 2, total = (unsigned)B * Rq;
+        f2v s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
+        for (unsigned base = 0; base < total; base += 4 * K2T) {
+            f4v v[4]; unsigned go[4]; bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ok[u] = i0 + u * K2T < total;
-                while (j >= Rq) { j -= Rq; ++b; }
-                go[u] = (int64_t)b * HW + 4 * j;
-                v[u] = ok[u] ? *(const float4*)&acc[b * Rp + 4 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                j += K2T;
+                const unsigned i = base + u * K2T + tid;
+                ok[u] = i < total;
+                const unsigned ii = ok[u] ? i : 0u;
+                const unsigned bb = __umulhi(ii, rq_magic), j4 = (ii - bb * Rq) * 4u;
+                go[u] = bb * (unsigned)HW + j4;
+                v[u] = *(const f4v*)&acc[bb * (unsigned)Rp + j4];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (ok[u]) {
                     // non-temporal: the grid is consumed much later (and is larger than the caches); streamed past the L2, it
                     // no longer evicts the records and segment tables the range work-groups are about to read
-                    typedef float f4 __attribute__((ext_vector_type(4)));
-                    const f4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    __builtin_nontemporal_store(t, (f4*)&o[go[u]]);
+                    __builtin_nontemporal_store(v[u], (f4v*)&o[go[u]]);
+                    const f2v lo = {v[u].x, v[u].y}, hi = {v[u].z, v[u].w};
+                    s1p += lo; s1p += hi;
+                    s2p = __builtin_elementwise_fma(lo, lo, s2p); s2p = __builtin_elementwise_fma(hi, hi, s2p);
                 }
-                f1 += (v[u].x + v[u].y) + (v[u].z + v[u].w);
-                f2 += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
-                fz += (v[u].x != 0.f) + (v[u].y != 0.f) + (v[u].z != 0.f) + (v[u].w != 0.f);
+                nzw += __popcll(__ballot(ok[u] && v[u].x != 0.f)) + __popcll(__ballot(ok[u] && v[u].y != 0.f)) +
+                       __popcll(__ballot(ok[u] && v[u].z != 0.f)) + __popcll(__ballot(ok[u] && v[u].w != 0.f));
             }
         }
+        f1 = s1p.x + s1p.y; f2 = s2p.x + s2p.y;
     } else {
         for (int b = 0; b < B; ++b) {
             for (int j = tid * 4; j < Rc; j += K2T * 4) {
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
         }
     }
     if (partials) {
-        double s1 = evr_wave_sum((double)f1), s2 = evr_wave_sum((double)f2), nz = evr_wave_sum((double)fz);
+        double s1 = evr_wave_sum((double)f1), s2 = evr_wave_sum((double)f2), nz = evr_wave_sum((double)fz) + (double)nzw;
         if (lane == 0) { red[k * 3 + 0] = s1; red[k * 3 + 1] = s2; red[k * 3 + 2] = nz; }
         __syncthreads();
         if (tid < 3) {
@@ -541,11 +549,14 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     EVR_LAUNCH_CHECK();
     const int64_t HW = (int64_t)H * W;
     const int vec_out = (HW % 4 == 0) && (((int64_t)pl.rows * W) % 4 == 0 || pl.G == 1) && (((uintptr_t)out & 15) == 0);
+    // flush index -> (bin, group) by multiply-high: groups per bin of a full range; exact for every index < B * Rq <= 2^15
+    const unsigned rq_full = (unsigned)(((int64_t)pl.rows * W) >> 2);
+    const unsigned rq_magic = (vec_out && rq_full >= 2 && (int64_t)B * HW < (1LL << 31)) ? (unsigned)((0x100000000ULL + rq_full - 1) / rq_full) : 0u;
     const int xcd_map = n_windows >= 8;
     const int64_t blocks = xcd_map ? (int64_t)((n_windows + 7) / 8) * 8 * pl.G : (int64_t)n_windows * pl.G;
     EVR_REQUIRE(blocks < (1LL << 31), "evr_voxelize: %d windows x %d ranges exceed the grid", n_windows, pl.G);
     hipLaunchKernelGGL(vox_range_kernel<RAW>, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
-                       rec, table, out, partials, hdr, n_windows, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map);
+                       rec, table, out, partials, hdr, n_windows, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic);
     EVR_LAUNCH_CHECK();
     if (stats) {
         hipLaunchKernelGGL(vox_stats_kernel, dim3(n_windows), dim3(256), 0, stream, partials, stats, pl.G);
