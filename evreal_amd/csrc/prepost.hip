@@ -7,6 +7,7 @@
 // Both are HBM/L2-bound elementwise passes around small reductions; fp32 with one rounding per
 // operation (built with -ffp-contract=off) so the elementwise arithmetic matches numpy/torch.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -203,15 +204,25 @@ __device__ __forceinline__ void pct_rank(int n, float q100, int& prev, int& next
 // virtual index -- are independent, so they run side by side (4 x n work-groups: a 64-frame batch fills the chip; the
 // single-work-group form walked them one after the other on 64 of 256 CUs).
 __global__ __launch_bounds__(PCT_THREADS) void pct_select_kernel(const float* __restrict__ img, int n, float q_lo, float q_hi,
-                                                                  float* __restrict__ vals) {
+                                                                  float* __restrict__ vals, int pair) {
     __shared__ PctShared sh;
-    const int sel = blockIdx.x;
     const float* v = img + (int64_t)blockIdx.y * n;
     if (threadIdx.x < 4) sh.level_valid[threadIdx.x] = 0;
     __syncthreads();
     int prev, next; float gamma;
-    pct_rank(n, (sel & 2) ? q_hi : q_lo, prev, next, gamma);
     const unsigned keys[PCT_MAXR] = {0u};
+    if (pair) {
+        // one work-group per (percentile, image): ranks prev and prev + 1 share their counting passes through the memoised
+        // histograms (they differ in the last radix level at most), so the second select is four histogram scans
+        const int which = blockIdx.x;
+        pct_rank(n, which ? q_hi : q_lo, prev, next, gamma);
+        const float a = key2f(radix_select<false>(keys, 0, v, n, prev, sh));
+        const float b = (next == prev) ? a : key2f(radix_select<false>(keys, 0, v, n, next, sh));
+        if (threadIdx.x == 0) { vals[(int64_t)blockIdx.y * 4 + 2 * which] = a; vals[(int64_t)blockIdx.y * 4 + 2 * which + 1] = b; }
+        return;
+    }
+    const int sel = blockIdx.x;
+    pct_rank(n, (sel & 2) ? q_hi : q_lo, prev, next, gamma);
     const float x = key2f(radix_select<false>(keys, 0, v, n, (sel & 1) ? next : prev, sh));
     if (threadIdx.x == 0) vals[(int64_t)blockIdx.y * 4 + sel] = x;
 }
@@ -294,7 +305,8 @@ extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q
         hipLaunchKernelGGL(pct_exp_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, img, total);
         EVR_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(pct_select_kernel, dim3(4, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace);
+    static const int pair = [] { const char* e = getenv("EVR_PCT_PAIR"); return e ? atoi(e) : 0; }();     // A/B switch
+    hipLaunchKernelGGL(pct_select_kernel, dim3(pair ? 2 : 4, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace, pair);
     EVR_LAUNCH_CHECK();
     int gx = (px + 256 * 8 - 1) / (256 * 8);
     if (gx < 1) gx = 1;
