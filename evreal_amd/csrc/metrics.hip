@@ -23,7 +23,6 @@ namespace {
 constexpr int R = 5;              // Gaussian radius: int(3.5*1.5+0.5)
 constexpr int TH = 16, TW = 64;   // output tile
 constexpr int IH = TH + 2 * R, IW = TW + 2 * R;
-constexpr int VW = (IW + 2 + 3) & ~3;   // row length of the vertical-pass maps: a multiple of 4 floats, 16 floats readable from every run start
 
 struct Gauss { double w[R + 1]; };   // w[0] centre, w[j] = weight at distance j
 
@@ -40,7 +39,7 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restri
                                                             int H, int W, int clip, unsigned which, Gauss g,
                                                             double* __restrict__ partials, int tiles_x, int tiles_y) {
     __shared__ float sx[IH][IW + 1], sy[IH][IW + 1];
-    __shared__ __attribute__((aligned(16))) float v[5][TH][VW];     // after the vertical pass: ux, uy, uxx, uyy, uxy (rows 16-B aligned)
+    __shared__ float v[5][TH][IW + 1];     // after the vertical pass: ux, uy, uxx, uyy, uxy
     __shared__ double red[2][4];
     const int f = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
     const float* X = ref + (int64_t)f * H * W;   // skimage argument order: (ref, img) -> im1 = ref
@@ -68,74 +67,51 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restri
         }
     }
     if (which & 2u) {
-        // Both passes keep the scipy operation order per output value; what changed (round 3) is who computes what: a thread
-        // owns FOUR adjacent outputs along the filter axis and slides over one register window of 4 + 2R inputs, so an
-        // output costs 3.5 (pass 1: 28 reads per 4 outputs, two inputs) / 1 (pass 2: 16-B reads) LDS instructions instead of 22 / 55.
         // pass 1: along axis 0 (rows), for every column of the haloed tile
-        for (int i = tid; i < (TH / 4) * IW; i += 256) {
-            const int c = i % IW, r0 = 4 * (i / IW);
-            float wx[4 + 2 * R], wy[4 + 2 * R];
-#pragma unroll
-            for (int m = 0; m < 4 + 2 * R; ++m) { wx[m] = sx[r0 + m][c]; wy[m] = sy[r0 + m][c]; }
-            // map by map: the window's 14 values are formed (fp32) and widened ONCE, then shared by the four outputs -- the
-            // kernel is bound by the fp64 pipe, and 55 of an output's 110 fp64-pipe operations were these conversions
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                double wd[4 + 2 * R];
-#pragma unroll
-                for (int m = 0; m < 4 + 2 * R; ++m) {
-                    const float x = wx[m], y = wy[m];
-                    const float e = k == 0 ? x : k == 1 ? y : k == 2 ? x * x : k == 3 ? y * y : x * y;
-                    wd[m] = (double)e;
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    double a = wd[rr + R] * g.w[0];
-#pragma unroll
-                    for (int j = R; j >= 1; --j) a += (wd[rr + R - j] + wd[rr + R + j]) * g.w[j];   // scipy: jj = -size1 .. -1
-                    v[k][r0 + rr][c] = (float)a;
-                }
+        for (int i = tid; i < TH * IW; i += 256) {
+            const int r = i / IW, c = i % IW;
+            double a[5];
+            {
+                const float x = sx[r + R][c], y = sy[r + R][c];
+                const float xx = x * x, yy = y * y, xy = x * y;
+                a[0] = x * g.w[0]; a[1] = y * g.w[0]; a[2] = xx * g.w[0]; a[3] = yy * g.w[0]; a[4] = xy * g.w[0];
             }
+            for (int j = R; j >= 1; --j) {   // scipy: jj = -size1 .. -1
+                const float xa = sx[r + R - j][c], xb = sx[r + R + j][c];
+                const float ya = sy[r + R - j][c], yb = sy[r + R + j][c];
+                const float xxa = xa * xa, xxb = xb * xb, yya = ya * ya, yyb = yb * yb, xya = xa * ya, xyb = xb * yb;
+                a[0] += ((double)xa + (double)xb) * g.w[j];
+                a[1] += ((double)ya + (double)yb) * g.w[j];
+                a[2] += ((double)xxa + (double)xxb) * g.w[j];
+                a[3] += ((double)yya + (double)yyb) * g.w[j];
+                a[4] += ((double)xya + (double)xyb) * g.w[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k][r][c] = (float)a[k];
         }
         __syncthreads();
-        // pass 2: along axis 1 (columns) + SSIM map; thread = (row, run of four columns): TH x TW / 4 = 256 runs
-        static_assert(TH * TW / 4 == 256 && TW % 4 == 0 && TW + 2 * R + 2 <= VW, "one run of four outputs per thread");
+        // pass 2: along axis 1 (columns) + SSIM map
         const float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
-        {
-            const int r = tid / (TW / 4), c0 = 4 * (tid % (TW / 4));
-            const int gy = y0 + r;
-            float u[4][5];
+        for (int i = tid; i < TH * TW; i += 256) {
+            const int r = i / TW, c = i % TW;
+            const int gy = y0 + r, gx = x0 + c;
+            if (gy < R || gy >= H - R || gx < R || gx >= W - R) continue;   // crop(S, 5)
+            float u[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                double win[16];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f4v t = *(const f4v*)&v[k][r][c0 + 4 * m];
-                    win[4 * m] = (double)t[0]; win[4 * m + 1] = (double)t[1]; win[4 * m + 2] = (double)t[2]; win[4 * m + 3] = (double)t[3];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double a = win[q + R] * g.w[0];
-#pragma unroll
-                    for (int j = R; j >= 1; --j) a += (win[q + R - j] + win[q + R + j]) * g.w[j];
-                    u[q][k] = (float)a;
-                }
+                double a = (double)v[k][r][c + R] * g.w[0];
+                for (int j = R; j >= 1; --j) a += ((double)v[k][r][c + R - j] + (double)v[k][r][c + R + j]) * g.w[j];
+                u[k] = (float)a;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gx = x0 + c0 + q;
-                if (gy < R || gy >= H - R || gx < R || gx >= W - R) continue;   // crop(S, 5)
-                const float ux = u[q][0], uy = u[q][1], uxx = u[q][2], uyy = u[q][3], uxy = u[q][4];
-                const float vx = uxx - ux * ux, vy = uyy - uy * uy, vxy = uxy - ux * uy;
-                const float A1 = (2.f * ux) * uy + C1;
-                const float A2 = 2.f * vxy + C2;
-                const float B1 = (ux * ux + uy * uy) + C1;
-                const float B2 = (vx + vy) + C2;
-                const float D = B1 * B2;
-                const float S = (A1 * A2) / D;
-                ss += (double)S;
-            }
+            const float ux = u[0], uy = u[1], uxx = u[2], uyy = u[3], uxy = u[4];
+            const float vx = uxx - ux * ux, vy = uyy - uy * uy, vxy = uxy - ux * uy;
+            const float A1 = (2.f * ux) * uy + C1;
+            const float A2 = 2.f * vxy + C2;
+            const float B1 = (ux * ux + uy * uy) + C1;
+            const float B2 = (vx + vy) + C2;
+            const float D = B1 * B2;
+            const float S = (A1 * A2) / D;
+            ss += (double)S;
         }
     }
     se = evr_wave_sum(se); ss = evr_wave_sum(ss);
