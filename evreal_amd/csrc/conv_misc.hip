@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
 //   B (pixels)   the normalised, zero-padded input tile [B][8+5][32+4] sits in LDS as u32 = hi | lo << 16 (split once
 //            per element); a lane gathers 8 elements per slab and two v_perm build the hi and lo operands.
 //   C^T      lane = pixel, registers = channels -> bias, ReLU, PACKED 8-B stores.
-__global__ __launch_bounds__(256) void head_mfma_kernel(const HeadArgs a) {
+__global__ __launch_bounds__(256, 2) void head_mfma_kernel(const HeadArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 32, LR = TH + 5, LC = TW + 4, PLANE = LR * LC;
     extern __shared__ unsigned htile[];   // [B][LR][LC]
@@ -310,7 +310,12 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
     if (a.wfrag && a.k == 5 && a.cout == 32 && a.B == 5) {
         const HeadArgs& a2 = a;
         const int ntiles = a.n * ((a.hp + 7) / 8) * ((a.wp + 31) / 32);
-        const dim3 g((unsigned)(ntiles < 768 ? ntiles : 768));        // persistent: 3 blocks per CU walk the tiles
+        // persistent: the 80 weight registers (236 VGPRs in all) leave room for TWO work-groups per CU, so the grid is 512.  Measured on
+        // one box (tools/head_blocks_ab.sh, two rounds): 768 work-groups (the third per CU starts when a first one ends) 421 us, 512 or
+        // 1024: 382-384 us; a 168-register build that does fit three spills the weight fragments (730 us); both row passes of a wave
+        // unrolled together 390 us.  EVR_HEAD_BLOCKS overrides the grid.
+        static const int head_blocks = [] { const char* e = getenv("EVR_HEAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+        const dim3 g((unsigned)(ntiles < head_blocks ? ntiles : head_blocks));
         hipLaunchKernelGGL(head_mfma_kernel, g, dim3(256), (size_t)a.B * 13 * 36 * sizeof(unsigned), stream, a2);
         EVR_LAUNCH_CHECK();
         return EVR_OK;
