@@ -41,15 +41,16 @@ class HotPath:
             self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
             self.k = 0
             # The evaluation of frame t starts only when frame t+1 has passed the layer EVR_EVAL_GATE names (the library records an
-            # event there; default res1.conv2 -- after the three ConvLSTM layers and both residual blocks; 'none': at once, as in rounds 1-2): the
-            # evaluation kernels then share the chip with the decoders of the next frame (and its head / first encoder) instead of its
-            # ConvLSTM layers (2.2 ms -> 1.5 ms for enc0.rec in the step; +1 % end to end with the gate after res0.conv2, another +1 %
-            # after res1.conv2 once the evaluation half had shrunk: tools/gate_sweep.sh, profiles/r03_gate_sweep.txt).  The scores
-            # of frame t land one step later; flush() ends a run.  Models without that layer (FireNet) are not gated.
+            # event there; 'none': at once, as in rounds 1-2): the evaluation kernels then share the chip with the residual blocks /
+            # decoders of the next frame instead of its head and ConvLSTM layers (2.2 ms -> 1.5 ms for enc0.rec in the step; +1 % end
+            # to end).  Default: after res0.conv2; from 48 sequences per step on after res1.conv2 -- there the evaluation half fits
+            # beside the three decoders (+1 % at 64 sequences), while a small batch is a latency chain and loses 5-6 % to the later
+            # start (tools/gate_sweep.sh, tools/gate_ab_workloads.sh; profiles/r03_gate_sweep.txt).  The scores of frame t land one
+            # step later; flush() ends a run.  Models without that layer (FireNet) are not gated.
             import ctypes, os
             self._gate = None
             self._pending = None
-            g = os.environ.get('EVR_EVAL_GATE', 'res1.conv2')
+            g = os.environ.get('EVR_EVAL_GATE') or ('res1.conv2' if n_seq >= 48 else 'res0.conv2')
             if g and g != 'none' and hasattr(model, 'set_gate'):
                 h = ctypes.c_void_p()
                 _lib.check(_lib.load().evr_event_create(ctypes.byref(h)), 'evr_event_create')

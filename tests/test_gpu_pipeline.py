@@ -49,7 +49,7 @@ def _run(overlap, n_seq=3, n_steps=5, read_every_frame=True):
 
 def test_gated_evaluation_stream_gives_the_same_scores():
     """Default two-stream flow: the evaluation of frame t is enqueued one step later, behind an event the library records inside
-    frame t+1 (after res1.conv2); scores land in the rows they were given, identical to the single-stream run."""
+    frame t+1 (after res0.conv2 at this batch size); scores land in the rows they were given, identical to the single-stream run."""
     _, sc1, _ = _run(False, n_steps=7)
     _, sc2, _ = _run(True, n_steps=7, read_every_frame=False)
     np.testing.assert_array_equal(sc1, sc2)
