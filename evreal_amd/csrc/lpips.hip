@@ -476,9 +476,12 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
         a.epi = EPI_BIAS_RELU; a.x3 = L.x3;
-        {   // experiment switch: EVR_LPIPS_BAND5=<KB of LDS padding> puts conv2 on the band kernel with that padding; unset: implicit GEMM
+        {   // conv2 (5x5) on the band kernel with 8 KB of LDS padding (two blocks per CU instead of three); EVR_LPIPS_BAND5=<KB> sets the
+            // padding, EVR_LPIPS_BAND5=-1 keeps the implicit GEMM (the default until the evaluation stream moved behind the residual
+            // blocks: beside the ConvLSTM layers its LDS footprint cost more than the kernel gained; now +0.7 .. 1.0 %, profiles/r03_env_ab.txt)
             const char* e = getenv("EVR_LPIPS_BAND5");
-            a.no_band5 = e ? 0 : 1; a.band_lds_pad = e ? atoi(e) * 1024 : 0;
+            const int kb = e ? atoi(e) : 8;
+            a.no_band5 = kb < 0 ? 1 : 0; a.band_lds_pad = kb < 0 ? 0 : kb * 1024;
         }
         a.acc_scale = (L.x3 == 3) ? std::ldexp(1.0f, -(L.mx_e + H2_ACT_EXP)) : 1.0f;
         a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED (H2 in mode 3) in the split modes

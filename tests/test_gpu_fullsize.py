@@ -48,30 +48,33 @@ def _d(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _run(m, o, H, W, num_encoders, frames, n_seq, n_events, seed0, normalize=True, check_states=False):
+def _run(m, o, H, W, num_encoders, frames, n_seq, n_events, seed0, normalize=True, check_states=False, oracle_seqs=None):
+    """oracle_seqs: the sequences replayed through the CPU oracle (default: all; the GPU always advances all n_seq together)."""
     from evreal_amd.voxel import Voxelizer
     from oracle import prepost as op, voxel as ov
     crop = op.CropParams(W, H, num_encoders)
     vz = Voxelizer()
     st = torch.zeros((n_seq, 3), dtype=torch.float64, device='cuda')
     m.reset_states(); o.reset_states()
+    sel = list(range(n_seq)) if oracle_seqs is None else list(oracle_seqs)
     worst = 0.0
     for f in range(frames):
         ev, cat, offs = _windows([seed0 + 1000 * f + s for s in range(n_seq)], n_events, W, H)
         g = vz.voxelize(_d(cat[0]), _d(cat[1]), _d(cat[2]), _d(cat[3]), _d(offs), 5, (H, W), stats=st)
         img = m(g, stats=st if normalize else None)['image'].cpu().numpy()
-        v = np.stack([ov.events_to_voxel(*e, 5, (H, W)) for e in ev])
+        v = np.stack([ov.events_to_voxel(*ev[s], 5, (H, W)) for s in sel])
         if normalize:
-            v = np.stack([op.normalize_event_tensor(v[s:s + 1])[0] for s in range(n_seq)])
+            v = np.stack([op.normalize_event_tensor(v[s:s + 1])[0] for s in range(len(sel))])
         with torch.no_grad():
             want = crop.crop(o(torch.from_numpy(crop.pad(v))).numpy())
-        err = float(np.abs(img - want).max())
+        err = float(np.abs(img[sel] - want).max())
         worst = max(worst, err)
         assert err < IMG_ATOL, (f, err)
     if check_states:
         for i in range(num_encoders):
-            h = m.read_tensor(f'h{i}').cpu().numpy().reshape(o.states[i][0].shape)
-            c = m.read_tensor(f'c{i}').cpu().numpy().reshape(o.states[i][1].shape)
+            shp = (n_seq,) + tuple(o.states[i][0].shape[1:])
+            h = m.read_tensor(f'h{i}').cpu().numpy().reshape(shp)[sel]
+            c = m.read_tensor(f'c{i}').cpu().numpy().reshape(shp)[sel]
             np.testing.assert_allclose(h, o.states[i][0].numpy(), rtol=2e-4, atol=5e-5, err_msg=f'h{i}')
             np.testing.assert_allclose(c, o.states[i][1].numpy(), rtol=2e-4, atol=5e-5, err_msg=f'c{i}')
     return worst
@@ -82,7 +85,9 @@ def test_drift_100_frames_346x260_8_sequences():
     from evreal_amd import weights
     torch.set_num_threads(min(32, torch.get_num_threads()))
     m, o = _pair(dict(weights.E2VID_KWARGS), seed=21)
-    worst = _run(m, o, 260, 346, 3, frames=100, n_seq=8, n_events=15000, seed0=40000, check_states=True)
+    # (the mode variants of tests/test_gpu_modes.py replay sequences 0 and 7 through the oracle: EVR_TEST_DRIFT_ORACLE_SEQS=0,7)
+    sel = [int(x) for x in os.environ.get('EVR_TEST_DRIFT_ORACLE_SEQS', '').split(',') if x] or None
+    worst = _run(m, o, 260, 346, 3, frames=100, n_seq=8, n_events=15000, seed0=40000, check_states=True, oracle_seqs=sel)
     print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
 
 

@@ -99,8 +99,9 @@ def test_fp32_grade_arithmetic_on_trained_weights():
 
 def test_drift_100_frames_in_fp32_equivalent_mode():
     """100 frames x 8 sequences at 346x260 in the three-f16-product mode, gate 1e-5 per pixel (measured 2.4e-7: the level
-    of the exact-fp32 mode's own summation-order difference from the CPU oracle)."""
-    env = dict(os.environ, EVR_ARITH='h3', EVR_TEST_IMG_ATOL='1e-5', EVR_WIDE_MIN='1')
+    of the exact-fp32 mode's own summation-order difference from the CPU oracle).  The GPU advances all 8 sequences; sequences 0 and 7
+    are replayed through the CPU oracle (the default-mode run in test_gpu_fullsize.py replays all 8)."""
+    env = dict(os.environ, EVR_ARITH='h3', EVR_TEST_IMG_ATOL='1e-5', EVR_WIDE_MIN='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
@@ -108,8 +109,8 @@ def test_drift_100_frames_in_fp32_equivalent_mode():
 
 def test_drift_100_frames_with_wide_band_kernel():
     """The 100-frame, 8-sequence, 346x260 drift gate again with the ConvLSTM gates on the kernel the 64-sequence bench
-    times (8 sequences alone stay below its 1024-block threshold)."""
-    env = dict(os.environ, EVR_WIDE_MIN='1')
+    times (8 sequences alone stay below its 1024-block threshold).  Sequences 0 and 7 against the oracle, as above."""
+    env = dict(os.environ, EVR_WIDE_MIN='1', EVR_WIDE='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')      # (EVR_WIDE=1: twin AND 256 x 256 forms)
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
