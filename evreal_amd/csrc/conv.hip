@@ -1806,11 +1806,7 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
         // other's MFMAs).  The 8-wave and overlapped-tile / 3-slot-ring configurations of earlier rounds measured slower
         // (profiles/r02_tile_variants.txt) and are gone: with the zero row their 80 KiB no longer leave two blocks per CU.
         // 256-pixel block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
-        // EVR_WIDE: 0 never, 1 by channel count (below), 2 / 3 one form for every ConvLSTM layer.  Default 1 in the fp8 and three-f16
-        // builds, 3 in the fp6 build: since the evaluation stream is gated behind the residual blocks (pipeline.HotPath) the ConvLSTM
-        // launches run alone, where the 256 x 256 form is the faster one for every K (1196-1220 against 1242-1272 us, PMC passes);
-        // A/B in the step, two rounds on one box: 7289 / 7278 -> 7397 / 7350 frames/s (profiles/r03_env_ab.txt)
-        static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : (EVR_ARITH == 4 ? 3 : 1);
+        static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
         static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 1024;   // >= 4 rounds of 256 blocks; tests lower it
         const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
                              (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= wide_min;

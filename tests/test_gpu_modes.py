@@ -110,7 +110,7 @@ def test_drift_100_frames_in_fp32_equivalent_mode():
 def test_drift_100_frames_with_wide_band_kernel():
     """The 100-frame, 8-sequence, 346x260 drift gate again with the ConvLSTM gates on the kernel the 64-sequence bench
     times (8 sequences alone stay below its 1024-block threshold).  Sequences 0 and 7 against the oracle, as above."""
-    env = dict(os.environ, EVR_WIDE_MIN='1', EVR_WIDE='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')      # (EVR_WIDE=1: twin AND 256 x 256 forms)
+    env = dict(os.environ, EVR_WIDE_MIN='1', EVR_WIDE='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')      # (EVR_WIDE=1, the default: twin AND 256 x 256 forms)
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
