@@ -18,6 +18,14 @@ from .prepost import Metrics, post_process_normalization
 from .voxel import Voxelizer
 
 
+def default_eval_gate(n_seq, environ=None):
+    """Layer of frame t+1 behind which the evaluation of frame t may start: EVR_EVAL_GATE if set ('none' = ungated), else after the
+    first residual block, from 48 sequences per step on after the second one (measured: profiles/r03_gate_ab_workloads.txt)."""
+    import os
+    g = (os.environ if environ is None else environ).get('EVR_EVAL_GATE')
+    return g or ('res1.conv2' if n_seq >= 48 else 'res0.conv2')
+
+
 class HotPath:
     def __init__(self, model, num_bins, sensor_size, n_seq, event_tensor_normalization=True,
                  post_process_norm='robust', metrics=('mse', 'ssim'), device='cuda:0', lpips=None, overlap=False):
@@ -50,7 +58,7 @@ class HotPath:
             import ctypes, os
             self._gate = None
             self._pending = None
-            g = os.environ.get('EVR_EVAL_GATE') or ('res1.conv2' if n_seq >= 48 else 'res0.conv2')
+            g = default_eval_gate(n_seq)
             if g and g != 'none' and hasattr(model, 'set_gate'):
                 h = ctypes.c_void_p()
                 _lib.check(_lib.load().evr_event_create(ctypes.byref(h)), 'evr_event_create')

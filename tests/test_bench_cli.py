@@ -58,3 +58,16 @@ def test_traffic_is_null_when_profiles_are_stale(monkeypatch):
     other = 'mx' if d.get('arith', 'mx') != 'mx' else 'mx6'
     v, note = bench.measured_traffic(other)          # passes taken in another arithmetic never count
     assert v is None and 'arithmetic' in note
+
+
+def test_evaluation_gate_default_follows_the_batch_size():
+    """pipeline.HotPath's gate rule (host logic): after the first residual block, from 48 sequences per step on after the second;
+    EVR_EVAL_GATE overrides, 'none' disables."""
+    from evreal_amd.pipeline import default_eval_gate
+    assert default_eval_gate(1, {}) == 'res0.conv2'
+    assert default_eval_gate(47, {}) == 'res0.conv2'
+    assert default_eval_gate(48, {}) == 'res1.conv2'
+    assert default_eval_gate(64, {}) == 'res1.conv2'
+    assert default_eval_gate(64, {'EVR_EVAL_GATE': 'dec0'}) == 'dec0'
+    assert default_eval_gate(8, {'EVR_EVAL_GATE': 'none'}) == 'none'
+    assert default_eval_gate(8, {'EVR_EVAL_GATE': ''}) == 'res0.conv2'
