@@ -77,7 +77,7 @@ def arith_name(net=None):
     if os.environ.get('EVR_FP32') or os.environ.get('EVR_ARITH') == 'fp32':
         return 'fp32'
     e = os.environ.get('EVR_ARITH')
-    return e if e in ('h3', 'mx', 'mx6') else 'mx6'
+    return e if e in ('h3', 'mx', 'mx6') else 'h3'
 
 
 DTYPE = {'mx': 'f16+mxfp8', 'mx6': 'f16+mxfp6', 'h3': 'f16x3', 'fp32': 'f32'}
@@ -188,12 +188,47 @@ class Workload:
             self.make_oracle = lambda: omod.UNetRecurrentOracle(t(self.sd), **{k: kw[k] for k in OKEYS})
             self.norm_in, self.post, self.enc = False, 'none', kw['num_encoders']   # config/method/E2VID+.json
             self.title = "E2VID+ / SSL-E2VID layout (no norm, bilinear-upsample + k5 conv decoders; synthetic weights)"
+        elif name == 'ckpt':
+            self._from_checkpoint()
         else:
             raise SystemExit(f"bench.py: unknown --config {name}")
         if sensor is not None:
             self.W, self.H = sensor
-        if self.net is not None:
+        if self.net is not None and self.sd is not None:
             self.net.load_state_dict(self.sd)
+
+
+    def _from_checkpoint(self):
+        """EVREAL_MODEL_CKPT=<path> EVREAL_MODEL_METHOD=<E2VID|E2VID+|SSL-E2VID|FireNet|FireNet+|HyperE2VID> (`--config ckpt`): a user's
+        trained checkpoint through the drop-in loader (evreal_amd.eval.get_model_from_checkpoint_path = eval.py:124-158) with the
+        method's shipped settings (config/method/*.json of the reference), scored against a CPU oracle built from the same state_dict."""
+        from evreal_amd import eval as ev, configs
+        from oracle import model as omod
+        path, method = os.environ.get('EVREAL_MODEL_CKPT'), os.environ.get('EVREAL_MODEL_METHOD', 'E2VID')
+        if not path or not os.path.exists(path):
+            raise SystemExit("bench.py --config ckpt: EVREAL_MODEL_CKPT must name a checkpoint file")
+        mc = configs.method_configs().get(method)
+        if mc is None or method in ('SPADE-E2VID', 'ET-Net'):
+            raise SystemExit(f"bench.py --config ckpt: EVREAL_MODEL_METHOD={method!r} (one of E2VID, E2VID+, SSL-E2VID, FireNet, FireNet+, HyperE2VID)")
+        self.W, self.H, self.n_seq, self.k = 346, 260, 64, 15000
+        self.net = ev.get_model_from_checkpoint_path(mc['model_name'], path)
+        self.sd = None
+        sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in self.net._sd.items()}      # the float tensors the library packed
+        kw = dict(getattr(self.net, 'kwargs', {}))
+        okw = {k: kw[k] for k in OKEYS if k in kw}
+        if kw.get('use_dynamic_decoder'):
+            okw['use_dynamic_decoder'] = True
+        okw['final_activation'] = kw.get('final_activation') or 'none'
+        if mc['model_name'] == 'FireNet':
+            self.make_oracle = lambda: omod.FireNetLegacyOracle(sd_t)
+        elif mc['model_name'] == 'FireNet+':
+            self.make_oracle = lambda: omod.FireNetOracle(sd_t)
+        else:
+            self.make_oracle = lambda: omod.UNetRecurrentOracle(sd_t, **okw)
+        self.norm_in, self.post = bool(mc.get('event_tensor_normalization', False)), mc.get('post_process_norm', 'none')
+        self.enc = self.net.num_encoders
+        self.tag = "file:" + hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+        self.title = f"{method} from the user's checkpoint ({self.tag})"
 
 
 def build_inputs(rank, n_seq, n_steps, device, W_, H_, k):
@@ -215,7 +250,7 @@ def build_inputs(rank, n_seq, n_steps, device, W_, H_, k):
 
 
 # ------------------------------------------------------------------------------------------------ CPU leg
-def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_frames=0):
+def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_frames=0, seq=0, threads=None):
     """Oracle ("port") timed on the host cores, batch 1 like the reference: C voxelizer (1 thread) + numpy
     normalization + torch-CPU forward + numpy percentile + MSE + scipy SSIM + torch-CPU LPIPS.  BOUNDED: the torch
     thread count is the faster of {8, 32} (capped by the core count; all 256 threads of the GPU box's host run this
@@ -235,7 +270,7 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
 
     def frame(w, keep=None):
         t0 = time.perf_counter()
-        xs, ys, tf, ps = synth.window_events_f32(ts[w, 0], xy[w, 0], pol[w, 0], 0, k)
+        xs, ys, tf, ps = synth.window_events_f32(ts[w, seq], xy[w, seq], pol[w, seq], 0, k)
         lib.oracle_voxelize(f(xs), f(ys), f(tf), f(ps), f(offs), 1, BINS, H_, W_, f(out))
         t1 = time.perf_counter()
         v = op.normalize_event_tensor(out) if wl.norm_in else out
@@ -246,7 +281,7 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
         if wl.post != 'none':
             img = op.post_process_normalization(img, wl.post)
         t4 = time.perf_counter()
-        a, b = omet.clip01(img), omet.clip01(refs[0])
+        a, b = omet.clip01(img), omet.clip01(refs[seq])
         sc = [omet.mse(a, b), omet.ssim(a, b)]
         if lpips_sd is not None:
             with torch.no_grad():
@@ -258,7 +293,7 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
 
     t_start = time.perf_counter()
     best, best_t = None, None
-    for nt in sorted({min(8, os.cpu_count()), min(32, os.cpu_count())}):
+    for nt in ([threads] if threads else sorted({min(8, os.cpu_count()), min(32, os.cpu_count())})):
         torch.set_num_threads(nt)
         frame(0)                                   # warm-up at this thread count
         dt = sum(frame(1 % xy.shape[0]))
@@ -274,7 +309,7 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
         done += 1
     total = sum(times.values())
     res = {"value": round(done / total, 3), "unit": "frames/s", "cores": best, "kind": "port",
-           "sample": f"{done} frames of one {W_}x{H_} sequence, batch 1, {wl.name} forward on {best} torch threads of the "
+           "sample": f"{done} frames of one {W_}x{H_} sequence (#{seq}), batch 1, {wl.name} forward on {best} torch threads of the "
                      f"{os.cpu_count()}-core host (C voxelizer and numpy/scipy stages 1 thread), torch {torch.__version__}",
            "ms_per_frame": {kk: round(1e3 * v / max(done, 1), 3) for kk, v in times.items()},
            "mevents_per_s_voxelizer": round(k * done / max(times['voxel'], 1e-9) / 1e6, 2)}
@@ -285,13 +320,13 @@ def sig3(x):
     return float(f"{x:.3g}")
 
 
-def score_parity(gpu_frames, cpu_frames, names, gate=1e-4):
-    """gpu_frames / cpu_frames: [(image [H,W], [scores...])] for the same windows of sequence 0."""
+def score_parity(gpu_frames, cpu_frames, names, gate=1e-4, sequences=(0,)):
+    """gpu_frames / cpu_frames: [(image [H,W], [scores...])] for the same windows of the sequences named in `sequences`."""
     n = min(len(gpu_frames), len(cpu_frames))
     if n == 0:
         return None
     img_err = [float(np.abs(gpu_frames[i][0] - cpu_frames[i][0]).max()) for i in range(n)]
-    out = {"frames": n, "sequence": 0, "image_max_abs_err": max(img_err), "image_max_abs_err_per_frame_max5": sorted(img_err)[-5:],
+    out = {"frames": n, "sequences": list(sequences), "image_max_abs_err": max(img_err), "image_max_abs_err_per_frame_max5": sorted(img_err)[-5:],
            "image_gate": gate, "image_gate_ok": bool(max(img_err) < gate),
            "oracle": "oracle/ (torch-CPU fp32 restatement pinned against the reference classes; MSE/SSIM/LPIPS arithmetic "
                      "restated from scikit-image / pyiqa: parity unpinned, see DESIGN.md section 3)"}
@@ -377,6 +412,135 @@ def dominant_group(prof, fp32_layers=False):
     name, g = max(groups.items(), key=lambda kv: kv[1]['ms'])
     total = sum(v['ms'] for v in groups.values())
     return name, g, total
+
+
+# ------------------------------------------------------------------------------------------------ the driver's line
+REQUIRED_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+LINE_LIMIT = 4096
+
+
+def _r(x, n=4):
+    """Round floats for the compact line (significant digits, so 8.9e-7 survives)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{n}g}")
+    except (TypeError, ValueError):
+        return None
+
+
+def _brief_scalars(b):
+    """value / roofline fraction / image error of a side block (a `brief()` dict of main(), or an error record)."""
+    if not isinstance(b, dict):
+        return None
+    if 'error' in b:
+        return {"error": str(b['error'])[:60]}
+    rl, sp = b.get('roofline') or {}, b.get('score_parity') or {}
+    o = {"value": _r(b.get('value'), 5), "dtype": b.get('dtype'), "frac": _r(rl.get('frac')), "bound": rl.get('bound'),
+         "err": _r(sp.get('image_max_abs_err'), 2), "ok": bool(sp.get('image_gate_ok')) and bool(sp.get('all_3sf', True))}
+    if b.get('cpu_frames_per_s') is not None:
+        o["cpu"] = _r(b.get('cpu_frames_per_s'), 3)
+    return o
+
+
+def compact_line(out, full_path=None):
+    """The ONE line the driver parses: every key of the contract with `roofline` and `cpu_baseline`, scalars only for the side
+    blocks, always below LINE_LIMIT bytes (tests/test_bench_cli.py).  The full object is written to `full_path`."""
+    cfg, rl = out.get('config') or {}, out.get('roofline') or {}
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+            'data', 'mevents_per_s', 'model_tflops', 'rccl_ranks')
+    o = {k: out.get(k) for k in keep}
+    sc = cfg.get('scores') or {}
+    o["config"] = {"workload": str(cfg.get('workload', ''))[:330], "name": cfg.get('name'), "sequences_per_gpu": cfg.get('sequences_per_gpu'),
+                   "events_per_window": cfg.get('events_per_window'), "sensor": cfg.get('sensor'), "bins": cfg.get('bins'),
+                   "gflop_per_frame": cfg.get('gflop_per_frame'), "arithmetic_mode": cfg.get('arithmetic_mode'),
+                   "weights": cfg.get('weights'), "lpips_weights": cfg.get('lpips_weights'), "unique_steps": cfg.get('unique_steps'),
+                   "range_guard_runs": (cfg.get('range_guard') or {}).get('runs_beyond_exact_range'),
+                   "scores": {k: _r(sc.get(k), 7) for k in ('mse', 'ssim', 'lpips')} | {"count": sc.get('count')}}
+    ss = rl.get('single_stream') or {}
+    o["roofline"] = {"bound": rl.get('bound'), "achieved": rl.get('achieved'), "peak": rl.get('peak'), "unit": rl.get('unit'),
+                     "frac": rl.get('frac'), "traffic": rl.get('traffic'), "kernel": str(rl.get('kernel', ''))[:110],
+                     "avg_launch_us": rl.get('avg_launch_us'), "launches": rl.get('launches'),
+                     "gflop_per_launch": rl.get('gflop_per_launch'), "mfma_issue_frac": rl.get('mfma_issue_frac'),
+                     "alone_us": ss.get('avg_launch_us'), "share": rl.get('share_of_bracketed_time')}
+    if out.get('roofline_mfma'):
+        o["roofline"]["mfma_frac"] = (out['roofline_mfma'] or {}).get('frac')
+    rv = out.get('roofline_voxelizer')
+    if rv:
+        o["roofline_voxelizer"] = {"bound": "hbm", "achieved": rv.get('achieved'), "peak": rv.get('peak'), "unit": rv.get('unit'),
+                                   "frac": rv.get('frac'), "in_step_frac": (rv.get('in_step') or {}).get('frac'),
+                                   "bytes_per_window": rv.get('bytes_per_window')}
+    cb = out.get('cpu_baseline')
+    o["cpu_baseline"] = None if not cb else {"value": cb.get('value'), "unit": cb.get('unit'), "cores": cb.get('cores'), "kind": cb.get('kind'),
+                                             "sample": str(cb.get('sample', ''))[:170]}
+    sp = out.get('score_parity')
+    if sp:
+        o["score_parity"] = {"frames": sp.get('frames'), "sequences": sp.get('sequences'), "image_max_abs_err": _r(sp.get('image_max_abs_err'), 3),
+                             "image_gate": sp.get('image_gate'), "image_gate_ok": sp.get('image_gate_ok'), "all_3sf": sp.get('all_3sf')}
+        for nm in ('mse', 'ssim', 'lpips'):
+            if isinstance(sp.get(nm), dict):
+                o["score_parity"][nm + "_rel_err"] = _r(sp[nm].get('rel_err'), 2)
+    st = out.get('steady_state')
+    if st:
+        o["steady_state"] = {"value": st.get('value'), "seconds": st.get('seconds')}
+    if out.get('per_rank'):
+        o["per_rank"] = out['per_rank']
+    for k in ('fast', 'fp8_cross_terms', 'fp32_exact', 'sensor_640x480', 'user_checkpoint'):
+        if k in out:
+            o[k] = _brief_scalars(out[k])
+    if isinstance(out.get('sensor_640x480'), dict) and isinstance(o.get('sensor_640x480'), dict):
+        o['sensor_640x480']['vox_frac'] = (out['sensor_640x480'].get('roofline_voxelizer') or {}).get('frac')
+    if 'large_batch' in out:
+        o["large_batch_128"] = ((out['large_batch'] or {}).get('n_seq_128') or {}).get('value')
+    if 'small_batch' in out:
+        o["small_batch"] = {k.replace('n_seq_', ''): _r(v.get('value'), 4) for k, v in out['small_batch'].items() if isinstance(v, dict)}
+    if 'configs' in out:
+        short = {'3 (': 'firenet_3', '4 (': 'hyper_4', '5 (': 'color_5', 'extra (E2VID+': 'e2vidplus', 'extra (ET-Net': 'etnet', 'extra (SPADE': 'spade'}
+        o["configs"] = {}
+        for k, v in out['configs'].items():
+            for pre, nm in short.items():
+                if k.startswith(pre) and isinstance(v, dict):
+                    o["configs"][nm] = _brief_scalars(v)
+    ec = out.get('eval_cli')
+    if isinstance(ec, dict):
+        if 'error' in ec:
+            o["eval_cli"] = {"error": str(ec['error'])[:60]}
+        else:
+            g = lambda a: (ec.get(a) or {})
+            o["eval_cli"] = {"off": g('save_images_off').get('value'), "on": g('save_images_on').get('value'),
+                             "loop_off": (g('save_images_off').get('frame_loop') or {}).get('value'),
+                             "loop_on": (g('save_images_on').get('frame_loop') or {}).get('value')}
+    o["full"] = full_path
+    # never above the limit: drop the optional blocks, least important first
+    for k in ('small_batch', 'eval_cli', 'large_batch_128', 'fp8_cross_terms', 'configs', 'sensor_640x480', 'fp32_exact', 'steady_state',
+              'user_checkpoint', 'fast', 'score_parity', 'roofline_voxelizer'):
+        if len(json.dumps(o)) < LINE_LIMIT:
+            break
+        o.pop(k, None)
+    return o
+
+
+def aggregate(sc, elapsed, n_seq, K, dist=None, device='cpu'):
+    """What the ranks exchange at the end of a run: ONE all-reduce(SUM) of [sum_seq mean*count per metric ..., count] -- exactly
+    MetricTracker.update (eval.py:259-266) -- plus the max over ranks of the timed region and every rank's own time.
+    sc: [K, n_seq, 3] scores of this rank.  -> (totals [1, 4], elapsed = max over ranks, per_rank block or None)."""
+    from evreal_amd.dist import reduce_metric_sums
+    seq_mean = np.asarray(sc, dtype=np.float64).mean(axis=0)                          # per sequence
+    sums = np.array([[seq_mean[:, 0].sum() * K, seq_mean[:, 1].sum() * K, seq_mean[:, 2].sum() * K, n_seq * K]], dtype=np.float64)
+    per_rank = None
+    if dist is not None and dist.is_initialized():
+        world = dist.get_world_size()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        each = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(each, tmax)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        times = [float(t.item()) for t in each]
+        fps = [n_seq * K / t for t in times]
+        per_rank = {"frames_per_s_min": round(min(fps), 1), "frames_per_s_max": round(max(fps), 1), "ranks": world}
+        elapsed = float(tmax.item())
+    tot = reduce_metric_sums(torch.from_numpy(sums).to(device), dist)
+    return tot, elapsed, per_rank
 
 
 # ------------------------------------------------------------------------------------------------ colour workload
@@ -542,9 +706,9 @@ def run_eval_cli(args, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='e2vid', choices=['e2vid', 'firenet', 'hyper', 'color', 'etnet', 'spade', 'e2vidplus', 'eval_cli'])
+    ap.add_argument('--config', default='e2vid', choices=['e2vid', 'firenet', 'hyper', 'color', 'etnet', 'spade', 'e2vidplus', 'eval_cli', 'ckpt'])
     ap.add_argument('--n-seq', type=int, default=0, help='independent sequences advanced together per GPU (0: the config default)')
     ap.add_argument('--sensor', default='', help='sensor WxH of the synthetic streams (default: the config; e2vid also 640x480)')
     ap.add_argument('--cpu-frames', type=int, default=200, help='frames of the CPU baseline (0 disables)')
@@ -552,7 +716,10 @@ def main():
     ap.add_argument('--profile-filter', default=None, help='layers bracketed with HIP events (roofline block)')
     ap.add_argument('--no-overlap', action='store_true', help='evaluation kernels on the reconstruction stream (no second HIP stream)')
     ap.add_argument('--vox-ahead', type=int, default=8, help='steps voxelized per tensorizer launch (windows do not depend on the recurrence)')
-    ap.add_argument('--sub', action='store_true', help='side run: headline + roofline + a short oracle comparison (no sub-runs)')
+    ap.add_argument('--sub', action='store_true', help='side run: headline + roofline + a short oracle comparison (no sub-runs); prints the FULL object')
+    ap.add_argument('--unique-steps', type=int, default=40, help='distinct windows per sequence resident in HBM; later steps reuse them in order '
+                    '(windows do not depend on the recurrence, the recurrent state keeps evolving: every step does all of its work)')
+    ap.add_argument('--side-steps', type=int, default=20, help='timed steps of every side block (sub-processes)')
     args = ap.parse_args()
     if not args.parity_frames:
         args.parity_frames = 4 if args.sub else 12
@@ -572,9 +739,22 @@ def main():
     device = torch.device('cuda', local_rank)
 
     def emit(out):
+        """--sub: the full object (the parent picks what it needs).  Otherwise: the full object goes to gpurun_out/bench_full.json and the
+        LAST stdout line is compact_line(out), < 4 KB (the driver keeps ~8 KB of stdout: round 3's 24.7-KB line did not parse)."""
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL prints a version banner through C stdio: keep the JSON the LAST stdout line
-        print(json.dumps(out), flush=True)
+        if args.sub:
+            print(json.dumps(out), flush=True)
+            return
+        path = None
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            path = os.path.join('gpurun_out', 'bench_full.json' if out.get('n_gpus', 1) == 1 else f"bench_full_n{out.get('n_gpus')}.json")
+            with open(os.path.join(ROOT, path), 'w') as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            path = None
+        print(json.dumps(compact_line(out, path)), flush=True)
 
     if args.config == 'eval_cli':
         emit(run_eval_cli(args, device))
@@ -602,7 +782,10 @@ def main():
     net = wl.net
     W_, H_, K_EVENTS = wl.W, wl.H, wl.k
     n_seq, K, Wm = args.n_seq or wl.n_seq, args.steps, args.warmup
-    xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, K + Wm, device, W_, H_, K_EVENTS)
+    # U distinct windows per sequence are resident; step s uses window s % U (a multiple of the tensorizer's look-ahead)
+    AHEAD = max(1, args.vox_ahead)
+    U = min(K + Wm, max(AHEAD, args.unique_steps // AHEAD * AHEAD))
+    xy, ts, pol, offs, refs, host_inputs = build_inputs(rank, n_seq, U, device, W_, H_, K_EVENTS)
     lpips_path = os.environ.get('EVREAL_LPIPS_WEIGHTS')
     if lpips_path:      # a real pyiqa/lpips AlexNet-v0.1 state_dict supplied by the user
         lpips_sd = {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in
@@ -629,21 +812,24 @@ def main():
 
     # The tensorizer runs AHEAD steps at a time (one launch over AHEAD x n_seq windows, pipeline.HotPath.prefetch_raw): windows
     # do not depend on the recurrence.  Every launch is inside the timed region.  --vox-ahead 1: one launch per step.
-    AHEAD = max(1, args.vox_ahead)
-    offs_flat = torch.arange((K + Wm) * n_seq + 1, dtype=torch.int64, device=device) * K_EVENTS
+    offs_flat = torch.arange(U * n_seq + 1, dtype=torch.int64, device=device) * K_EVENTS
 
     def run_steps(h, s_begin, s_end, ref, out_rows, ns=None):
         ns = ns or n_seq
         if AHEAD == 1 or ns != n_seq:
             for s in range(s_begin, s_end):
-                h.step_raw(xy, ts, pol, offs[s][:ns + 1] if ns != n_seq else offs[s], ref, out_rows(s))
+                u = s % U
+                h.step_raw(xy, ts, pol, offs[u][:ns + 1] if ns != n_seq else offs[u], ref, out_rows(s))
             h.flush()
             return
-        for s0 in range(s_begin, s_end, AHEAD):
-            a = min(AHEAD, s_end - s0)
-            h.prefetch_raw(xy, ts, pol, offs_flat[s0 * n_seq:(s0 + a) * n_seq + 1], a)
+        s0 = s_begin
+        while s0 < s_end:
+            u0 = s0 % U
+            a = min(AHEAD, s_end - s0, U - u0)
+            h.prefetch_raw(xy, ts, pol, offs_flat[u0 * n_seq:(u0 + a) * n_seq + 1], a)
             for s in range(s0, s0 + a):
                 h.step_ahead(ref, out_rows(s))
+            s0 += a
         h.flush()
 
     run_steps(hp, 0, Wm, refs, lambda s: scores[s])
@@ -682,26 +868,19 @@ def main():
         hp.overlap = True
 
     steady = None
-    if side or args.sub:
+    if side or args.sub or world > 1:
         cycles = max(1, int(np.ceil(2.2 / max(elapsed, 1e-3))))
-        torch.cuda.synchronize()
+        barrier()
         t1 = time.perf_counter()
         for _ in range(cycles):
             run_steps(hp, Wm, Wm + K, refs, lambda s: scratch)
-        torch.cuda.synchronize()
+        barrier()
         dt = time.perf_counter() - t1
         steady = {"seconds": round(dt, 3), "steps": cycles * K, "value": round(n_seq * cycles * K / dt, 2),
                   "ms_per_step": round(1e3 * dt / (cycles * K), 4)}
 
     # metric aggregation exactly as MetricTracker.update (eval.py:259-266): sum(mean*count), count
-    seq_mean = sc.mean(axis=0)                           # per sequence
-    sums = np.array([[seq_mean[:, 0].sum() * K, seq_mean[:, 1].sum() * K, seq_mean[:, 2].sum() * K, n_seq * K]],
-                    dtype=np.float64)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tot = reduce_metric_sums(torch.from_numpy(sums).to(device), dist)
-    elapsed = float(tmax.item())
+    tot, elapsed, per_rank = aggregate(sc, elapsed, n_seq, K, dist, device)
 
     out = None
     if rank == 0:
@@ -762,7 +941,8 @@ def main():
                        "name": wl.name, "sequences_per_gpu": n_seq, "events_per_window": K_EVENTS, "sensor": [W_, H_], "bins": BINS,
                        "gflop_per_frame": round(flops_step / n_seq / 1e9, 3),
                        "lpips_gflop_per_frame": round(lp.flops() / n_seq / 1e9, 3), "sharding": "sequences across GPUs",
-                       "lpips_weights": lpips_tag, "arithmetic_mode": an,
+                       "lpips_weights": lpips_tag, "arithmetic_mode": an, "weights": getattr(wl, 'tag', 'synthetic(seeded)' if wl.name != 'firenet' else 'shipped FireNet checkpoint'),
+                       "unique_steps": U,
                        "range_guard": {"runs_beyond_exact_range": sat_runs, "layer": sat_layer},
                        "scores": {"mse": tot[0, 0] / tot[0, 3], "ssim": tot[0, 1] / tot[0, 3], "lpips": tot[0, 2] / tot[0, 3],
                                   "count": int(tot[0, 3])}},
@@ -783,6 +963,7 @@ def main():
                          "avg_launch_us": round(1e3 * rl_ms / max(rl_launches, 1), 2), "launches": rl_launches,
                          "layers": layer_table(prof)},
             "steady_state": steady,
+            "per_rank": per_rank,
         }
         if hbm_block is not None:      # report the binding roof; the matrix-core view stays under roofline_mfma
             hbm_block.update({k: out["roofline"][k] for k in ("kernel", "share_of_bracketed_time", "avg_launch_us", "launches", "layers", "traffic", "arithmetic")})
@@ -796,13 +977,15 @@ def main():
               "kernels": "every launch of one evr_voxelize_raw call (statistics for the event-tensor normalization included)"}
         if vox_ms_in_step:
             # (average over the timed region's launches; with look-ahead a launch covers up to AHEAD steps -- the last one fewer)
-            n_launch = -(-K // AHEAD)
+            n_launch, s0_ = 0, Wm
+            while s0_ < Wm + K:      # (the same grouping as run_steps: a launch ends at the look-ahead, the region's end or the window wrap)
+                s0_ += min(AHEAD, Wm + K - s0_, U - s0_ % U); n_launch += 1
             win_per_launch = n_seq * K / n_launch
             g = win_per_launch * bytes_win / (vox_ms_in_step * 1e-3) / 1e9
             rv["in_step"] = {"windows": round(win_per_launch, 1), "steps_per_launch": AHEAD, "us": round(1e3 * vox_ms_in_step, 2), "achieved": round(g, 1),
                              "frac": round(g / PEAK_HBM_GBS, 4), "us_per_step": round(1e3 * vox_ms_in_step * n_launch / K, 2),
                              "note": "inside the timed region, sharing the chip with the evaluation stream"}
-        n_win_avail = (K + Wm) * n_seq
+        n_win_avail = U * n_seq
         for nw in sorted({n_seq, min(512, n_win_avail)}):
             o_ = torch.arange(nw + 1, dtype=torch.int64, device=device) * K_EVENTS
             buf = torch.empty((nw, BINS, H_, W_), dtype=torch.float32, device=device)
@@ -824,48 +1007,53 @@ def main():
                     continue
                 h2 = mk(ns)
                 sc2 = torch.zeros((ns, 3), dtype=torch.float64, device=device)
-                ofs = [offs[s][:ns + 1].contiguous() for s in range(K + Wm)]
+                ofs = [offs[u][:ns + 1].contiguous() for u in range(U)]
                 for s in range(Wm):
-                    h2.step_raw(xy, ts, pol, ofs[s], refs[:ns], sc2)
+                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2)
                 h2.flush()
                 torch.cuda.synchronize()
-                reps = 4
+                Ks = 80
                 t1 = time.perf_counter()
-                for _ in range(reps):
-                    for s in range(Wm, Wm + K):
-                        h2.step_raw(xy, ts, pol, ofs[s], refs[:ns], sc2)
+                for s in range(Wm, Wm + Ks):
+                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2)
                 h2.flush()
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
-                sb[f"n_seq_{ns}"] = {"value": round(ns * K * reps / dt, 1), "ms_per_step": round(1e3 * dt / (K * reps), 4)}
+                sb[f"n_seq_{ns}"] = {"value": round(ns * Ks / dt, 1), "ms_per_step": round(1e3 * dt / Ks, 4)}
                 del h2
             sb["note"] = ("the headline advances %d sequences per GPU in lock-step; evreal_amd.eval --batch-sequences S does "
                           "the same for the sequences of a dataset" % n_seq)
             out["small_batch"] = sb
 
-        if side or args.sub:
-            # ---- score parity: first frames of sequence 0, GPU replay (THIS dispatch: same n_seq, same kernels) vs the CPU oracle
-            F = min(args.parity_frames, K + Wm)
-            saved, hp.overlap = hp.overlap, False
-            net.reset_states()
-            gpu_frames = []
-            for s in range(F):
-                img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
-                torch.cuda.synchronize()
-                gpu_frames.append((img[0, 0].cpu().numpy().copy(), [float(v) for v in scratch[0].cpu().numpy()]))
-            hp.overlap = saved
-            cb, cpu_frames = (None, [])
-            if args.cpu_frames > 0:
-                cb, cpu_frames = cpu_baseline(wl, host_inputs, args.cpu_frames if side else F, budget_s=25.0 if side else 0.0,
-                                              lpips_sd=lpips_sd, keep_frames=F)
-            out["cpu_baseline"] = cb
-            out["score_parity"] = score_parity(gpu_frames, cpu_frames, ['mse', 'ssim', 'lpips'], gate=1e-5 if an in ('h3', 'fp32') else 1e-4)
-        else:
-            out["cpu_baseline"] = None
-
+    # the ranks part here: what follows is rank 0's own checking (CPU oracle) and the side blocks, outside every timed region
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+    if rank == 0:
+        # ---- score parity: the first frames of two sequences, GPU replay (THIS dispatch: same n_seq, same kernels) vs the CPU oracle;
+        # ---- cpu_baseline: the oracle timed on sequence 0 (bounded: ~25 s on the default run, ~10 s beside other ranks, parity frames only in sub-runs)
+        F = min(args.parity_frames, U)
+        seqs = sorted({0, (37 * n_seq) // 64}) if not args.sub else [0]
+        saved, hp.overlap = hp.overlap, False
+        net.reset_states()
+        gpu_frames = {q: [] for q in seqs}
+        for s in range(F):
+            img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
+            torch.cuda.synchronize()
+            sc_h = scratch.cpu().numpy()
+            for q in seqs:
+                gpu_frames[q].append((img[q, 0].cpu().numpy().copy(), [float(v) for v in sc_h[q]]))
+        hp.overlap = saved
+        cb, cpu_frames = None, {q: [] for q in seqs}
+        if args.cpu_frames > 0:
+            budget = 0.0 if args.sub else (25.0 if world == 1 else 10.0)
+            cb, cpu_frames[0] = cpu_baseline(wl, host_inputs, F if args.sub else args.cpu_frames, budget_s=budget, lpips_sd=lpips_sd, keep_frames=F)
+            for q in seqs[1:]:
+                _, cpu_frames[q] = cpu_baseline(wl, host_inputs, F, budget_s=0.0, lpips_sd=lpips_sd, keep_frames=F, seq=q, threads=cb['cores'])
+        out["cpu_baseline"] = cb
+        out["score_parity"] = score_parity([f for q in seqs for f in gpu_frames[q]], [f for q in seqs for f in cpu_frames[q]],
+                                           ['mse', 'ssim', 'lpips'], gate=1e-5 if an in ('h3', 'fp32') else 1e-4, sequences=seqs)
 
     if rank == 0 and side:
         # release this process's device memory before the sub-runs allocate theirs
@@ -875,6 +1063,7 @@ def main():
         pick = lambda d, keys: {k: d.get(k) for k in keys}
         rl_keys = ('bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us', 'kernel', 'share_of_bracketed_time', 'mfma_issue_frac')
         par_keys = ('frames', 'image_max_abs_err', 'image_gate', 'image_gate_ok', 'all_3sf')
+        Ks = max(4, args.side_steps)
 
         def brief(d, extra=()):
             if 'error' in d:
@@ -890,26 +1079,29 @@ def main():
             b["cpu_frames_per_s"] = (d.get('cpu_baseline') or {}).get('value')
             return b
 
-        out["fp8_cross_terms"] = brief(sub_run([], {'EVR_ARITH': 'mx'}, K, Wm))      # the round-2 arithmetic (f16 + MX-fp8), same steps
-        out["fp32_equiv"] = brief(sub_run([], {'EVR_ARITH': 'h3'}, K, Wm))
-        out["fp32_exact"] = brief(sub_run([], {'EVR_FP32': '1'}, K, Wm))
+        # the opt-in fast arithmetic (f16 + MX-fp6 cross terms: rounds 2-3's headline) and its fp8 predecessor, same steps, own parity (gate 1e-4)
+        out["fast"] = brief(sub_run([], {'EVR_ARITH': 'mx6'}, Ks, Wm))
+        out["fp8_cross_terms"] = brief(sub_run([], {'EVR_ARITH': 'mx'}, Ks, Wm))
+        out["fp32_exact"] = brief(sub_run([], {'EVR_FP32': '1'}, Ks, Wm))
         # (per-GPU sequence count is a free parameter of the workload: 64 is what rounds 1-3 quote and profile; more sequences fill the
         # 128-pixel-tile layers' last round better)
-        out["large_batch"] = {"n_seq_128": brief(sub_run(['--n-seq', '128'], {}, K, Wm))}
-        big = sub_run(['--sensor', '640x480'], {}, K, Wm)
+        out["large_batch"] = {"n_seq_128": brief(sub_run(['--n-seq', '128'], {}, Ks, Wm))}
+        big = sub_run(['--sensor', '640x480'], {}, Ks, Wm)
         out["sensor_640x480"] = brief(big) | ({"roofline_voxelizer": pick(big.get('roofline_voxelizer') or {}, ('achieved', 'frac'))} if 'error' not in big else {})
         out["configs"] = {
             "1 (E2VID, CPU PyTorch path)": "cpu_baseline above: the oracle port on the host cores, same windows, same metrics",
             "2 (E2VID 346x260, MSE+SSIM+LPIPS)": "the headline line",
-            "3 (FireNet 240x180, k_events)": brief(sub_run(['--config', 'firenet'], {}, K, Wm)),
-            "4 (HyperE2VID 346x260, 4 sequences)": brief(sub_run(['--config', 'hyper'], {}, K, Wm)),
-            "5 (ColorNet E2VID+ 970x624, 50k events/window)": brief(sub_run(['--config', 'color'], {}, max(K // 2, 4), Wm, timeout=600)),
+            "3 (FireNet 240x180, k_events)": brief(sub_run(['--config', 'firenet'], {}, Ks, Wm)),
+            "4 (HyperE2VID 346x260, 4 sequences)": brief(sub_run(['--config', 'hyper'], {}, Ks, Wm)),
+            "5 (ColorNet E2VID+ 970x624, 50k events/window)": brief(sub_run(['--config', 'color'], {}, max(Ks // 2, 4), Wm, timeout=600)),
             # the rest of the reference's method registry (eval.py:124-158), same step, not BASELINE configurations
-            "extra (E2VID+ / SSL-E2VID layout 346x260, 64 sequences)": brief(sub_run(['--config', 'e2vidplus'], {}, K, Wm)),
-            "extra (ET-Net 346x260, 8 sequences)": brief(sub_run(['--config', 'etnet'], {}, K, Wm, timeout=600)),
-            "extra (SPADE-E2VID 346x260, 8 sequences)": brief(sub_run(['--config', 'spade'], {}, K, Wm, timeout=600)),
+            "extra (E2VID+ / SSL-E2VID layout 346x260, 64 sequences)": brief(sub_run(['--config', 'e2vidplus'], {}, Ks, Wm)),
+            "extra (ET-Net 346x260, 8 sequences)": brief(sub_run(['--config', 'etnet'], {}, Ks, Wm, timeout=600)),
+            "extra (SPADE-E2VID 346x260, 8 sequences)": brief(sub_run(['--config', 'spade'], {}, Ks, Wm, timeout=600)),
         }
-        out["eval_cli"] = sub_run(['--config', 'eval_cli'], {}, K, Wm, timeout=600)
+        if os.environ.get('EVREAL_MODEL_CKPT'):      # a user's trained checkpoint through the drop-in loader, with its own parity
+            out["user_checkpoint"] = brief(sub_run(['--config', 'ckpt'], {}, Ks, Wm, timeout=600))
+        out["eval_cli"] = sub_run(['--config', 'eval_cli'], {}, Ks, Wm, timeout=600)
     if rank == 0:
         emit(out)
 

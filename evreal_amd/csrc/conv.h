@@ -375,19 +375,20 @@ inline int pack_p6_weights(std::vector<float>& w) {
     return e;
 }
 // arithmetic mode of the 32-channel-chunk convolutions (ConvArgs::x3):
-//   4  split f16 + MX-fp6 corrections on P6 tensors (default, "mx6") -- for layouts whose packed tensors are all written as whole
-//      groups by matrix-core epilogues; evr_model_create narrows it to mode 2 for the others, LPIPS always runs mode 2;
+//   3  three f16 products on H2 tensors, fp32-grade ("h3"; the DEFAULT since round 4: the reference computes in fp32, and this is the
+//      fastest arithmetic here whose image error stays at the level of an fp32 summation-order change, <= 1e-6);
+//   4  split f16 + MX-fp6 corrections on P6 tensors (EVR_ARITH=mx6, the opt-in fast mode: 1.4e-5 on the image) -- for layouts whose packed
+//      tensors are all written as whole groups by matrix-core epilogues; evr_model_create narrows it to mode 2 for the others, LPIPS then runs mode 2;
 //   2  split f16 + MX-fp8 corrections on PACKED tensors (EVR_ARITH=mx: everywhere);
-//   3  three f16 products on H2 tensors, fp32-grade (EVR_ARITH=h3);
 //   0  exact fp32 MFMA on PLAIN tensors (EVR_FP32=1 or EVR_ARITH=fp32)
 inline int arith_mode() {
     if (getenv("EVR_FP32")) return 0;
     const char* e = getenv("EVR_ARITH");
-    if (!e || !*e || !strcmp(e, "mx6")) return 4;
+    if (!e || !*e || !strcmp(e, "h3")) return 3;
+    if (!strcmp(e, "mx6")) return 4;
     if (!strcmp(e, "mx")) return 2;
-    if (!strcmp(e, "h3")) return 3;
     if (!strcmp(e, "fp32")) return 0;
-    return 4;
+    return 3;
 }
 inline bool use_split_mode() { return arith_mode() != 0; }
 // value of the `packed` flags for tensors of a mode: 0 PLAIN, 1 PACKED (f16 | fp8 | fp8), 2 H2, 3 P6

@@ -1728,7 +1728,18 @@ extern "C" double evr_model_flops_per_step(const evr_model* m) { return m ? m->f
 
 // arithmetic mode of the model's 32-channel-chunk convolutions (conv.h arith_mode): 0 fp32, 2 f16 + MX-fp8, 3 three f16 products,
 // 4 f16 + MX-fp6 -- what EVR_ARITH asked for, narrowed to what the layout supports (evr_model_create)
-extern "C" int evr_model_arith(const evr_model* m) { return m ? m->arith : -1; }
+// (FireNet's unpadded 16-channel layers run three f16 products on H2 tensors whatever the global mode -- finish_conv: when every
+// convolution of the model agrees on a mode, THAT is the one reported)
+extern "C" int evr_model_arith(const evr_model* m) {
+    if (!m) return -1;
+    int x3 = 0;
+    for (const auto& c : m->convs) {
+        if (!c.x3) continue;                      // (a VALU / fp32 side layer, e.g. a 1x1 prediction conv, does not decide the mode)
+        if (x3 && c.x3 != x3) return m->arith;
+        x3 = c.x3;
+    }
+    return x3 ? x3 : (m->convs.empty() ? m->arith : 0);
+}
 
 // Range guard of the packed activation formats (packed.h sat_note): how many output runs (4 or 16 channels of one pixel)
 // of the matrix-core producers left the format's exact range since the counters were last cleared, and in which layer most.
