@@ -438,9 +438,11 @@ def _brief_scalars(b):
         return {"error": str(b['error'])[:60]}
     rl, sp = b.get('roofline') or {}, b.get('score_parity') or {}
     o = {"value": _r(b.get('value'), 5), "dtype": b.get('dtype'), "frac": _r(rl.get('frac')), "bound": rl.get('bound'),
-         "err": _r(sp.get('image_max_abs_err'), 2), "ok": bool(sp.get('image_gate_ok')) and bool(sp.get('all_3sf', True))}
+         "err": _r(sp.get('image_max_abs_err'), 2), "ok": bool(sp.get('image_gate_ok')) and sp.get('all_3sf') is not False}
     if b.get('cpu_frames_per_s') is not None:
         o["cpu"] = _r(b.get('cpu_frames_per_s'), 3)
+    if b.get('roofline_dynamic_filter'):
+        o["dynfilter_hbm_frac"] = _r(b['roofline_dynamic_filter'].get('frac'))
     return o
 
 
@@ -559,7 +561,7 @@ def run_color(args, wl, device):
     grid = torch.empty((n_seq, BINS, H_, W_), dtype=torch.float32, device=device)
 
     def step(s):
-        vz.voxelize_raw(xy, ts, pol, offs[s], BINS, (H_, W_), out=grid)
+        vz.voxelize_raw(xy, ts, pol, offs[s], BINS, (H_, W_), out=grid, n_window_events=n_seq * k)
         return net(grid)
 
     for s in range(Wm):
@@ -819,14 +821,14 @@ def main():
         if AHEAD == 1 or ns != n_seq:
             for s in range(s_begin, s_end):
                 u = s % U
-                h.step_raw(xy, ts, pol, offs[u][:ns + 1] if ns != n_seq else offs[u], ref, out_rows(s))
+                h.step_raw(xy, ts, pol, offs[u][:ns + 1] if ns != n_seq else offs[u], ref, out_rows(s), n_window_events=ns * K_EVENTS)
             h.flush()
             return
         s0 = s_begin
         while s0 < s_end:
             u0 = s0 % U
             a = min(AHEAD, s_end - s0, U - u0)
-            h.prefetch_raw(xy, ts, pol, offs_flat[u0 * n_seq:(u0 + a) * n_seq + 1], a)
+            h.prefetch_raw(xy, ts, pol, offs_flat[u0 * n_seq:(u0 + a) * n_seq + 1], a, n_window_events=a * n_seq * K_EVENTS)
             for s in range(s0, s0 + a):
                 h.step_ahead(ref, out_rows(s))
             s0 += a
@@ -926,7 +928,7 @@ def main():
         traffic, traffic_note = measured_traffic(an) if (wl.name == 'e2vid' and n_seq == 64 and (W_, H_) == (346, 260)) else (None, "not the profiled configuration")
         sel = set(p['name'] for p in lstm)
         out = {
-            "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID', 'etnet': 'ET-Net', 'spade': 'SPADE-E2VID', 'e2vidplus': 'E2VID+'}[wl.name], W_, H_),
+            "metric": "reconstructed frames/sec + Mevents/sec voxelized, %s %dx%d B=5" % ({'e2vid': 'E2VID', 'firenet': 'FireNet', 'hyper': 'HyperE2VID', 'etnet': 'ET-Net', 'spade': 'SPADE-E2VID', 'e2vidplus': 'E2VID+'}.get(wl.name, os.environ.get('EVREAL_MODEL_METHOD', 'E2VID')), W_, H_),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": 'f32' if fp32_net else DTYPE[an], "data": "synthetic",
@@ -965,6 +967,15 @@ def main():
             "steady_state": steady,
             "per_rank": per_rank,
         }
+        df = [p_ for p_ in prof if p_['name'] == 'dynamic_filter' and p_['launches']]
+        if df:      # HyperE2VID's per-pixel dynamic filtering (hyper_dynamic.py:50-57,83-88) is a VALU kernel bound by its tensors: x [n,h,w,256] and
+            # coeff [n,h,w,72] read once, out [n,h,w,1536] written once, 4 B per channel, at the first decoder's output grid (hp/4 x wp/4)
+            hq, wq = -(-H_ // 8) * 8 // 4, -(-W_ // 8) * 8 // 4
+            nbytes = n_seq * hq * wq * (256 + 72 + 1536) * 4.0
+            us = 1e3 * df[0]['ms'] / df[0]['launches']
+            out["roofline_dynamic_filter"] = {"bound": "hbm", "achieved": round(nbytes / (us * 1e-6) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                              "frac": round(nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), "bytes_per_launch": round(nbytes),
+                                              "avg_launch_us": round(us, 2), "kernel": "dynamic_filter_kernel"}
         if hbm_block is not None:      # report the binding roof; the matrix-core view stays under roofline_mfma
             hbm_block.update({k: out["roofline"][k] for k in ("kernel", "share_of_bracketed_time", "avg_launch_us", "launches", "layers", "traffic", "arithmetic")})
             out["roofline_mfma"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "mfma_issue_frac")}
@@ -990,7 +1001,7 @@ def main():
             o_ = torch.arange(nw + 1, dtype=torch.int64, device=device) * K_EVENTS
             buf = torch.empty((nw, BINS, H_, W_), dtype=torch.float32, device=device)
             st = torch.zeros((nw, 3), dtype=torch.float64, device=device)
-            ms = time_launches(lambda: vz.voxelize_raw(xy, ts, pol, o_, BINS, (H_, W_), out=buf, stats=st), 20, device)
+            ms = time_launches(lambda: vz.voxelize_raw(xy, ts, pol, o_, BINS, (H_, W_), out=buf, stats=st, n_window_events=nw * K_EVENTS), 20, device)
             g = nw * bytes_win / (ms * 1e-3) / 1e9
             rv[f"standalone_{nw}"] = {"windows": nw, "us": round(1e3 * ms, 2), "achieved": round(g, 1), "frac": round(g / PEAK_HBM_GBS, 4),
                                       "mevents_per_s": round(nw * K_EVENTS / (ms * 1e-3) / 1e6, 1)}
@@ -1009,13 +1020,13 @@ def main():
                 sc2 = torch.zeros((ns, 3), dtype=torch.float64, device=device)
                 ofs = [offs[u][:ns + 1].contiguous() for u in range(U)]
                 for s in range(Wm):
-                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2)
+                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2, n_window_events=ns * K_EVENTS)
                 h2.flush()
                 torch.cuda.synchronize()
                 Ks = 80
                 t1 = time.perf_counter()
                 for s in range(Wm, Wm + Ks):
-                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2)
+                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2, n_window_events=ns * K_EVENTS)
                 h2.flush()
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
@@ -1039,7 +1050,7 @@ def main():
         net.reset_states()
         gpu_frames = {q: [] for q in seqs}
         for s in range(F):
-            img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scratch)
+            img, _ = hp.step_raw(xy, ts, pol, offs[s], refs, scratch, n_window_events=n_seq * K_EVENTS)
             torch.cuda.synchronize()
             sc_h = scratch.cpu().numpy()
             for q in seqs:
@@ -1069,6 +1080,8 @@ def main():
             if 'error' in d:
                 return d
             b = pick(d, ('value', 'ms_per_step', 'dtype', 'mevents_per_s', 'model_tflops', 'steady_state') + tuple(extra))
+            if d.get('roofline_dynamic_filter'):
+                b['roofline_dynamic_filter'] = d['roofline_dynamic_filter']
             b["roofline"] = pick(d.get('roofline') or {}, rl_keys)
             sp = d.get('score_parity') or {}
             b["score_parity"] = pick(sp, par_keys) | {k: sp[k] for k in ('mse', 'ssim', 'lpips', 'uint8_plane_mismatch_fraction_max', 'merge_max_abs_diff_u8') if k in sp}

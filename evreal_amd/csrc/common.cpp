@@ -19,7 +19,8 @@ const char* last_error() { return g_err; }
 }  // namespace evr
 
 extern "C" const char* evr_last_error(void) { return evr::last_error(); }
-extern "C" int evr_version(void) { return 1000; }
+// 1001 (round 4): evr_percentile_normalize requires its workspace (NULL is rejected); evr_model_arith reports the effective mode
+extern "C" int evr_version(void) { return 1001; }
 extern "C" int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_t name_len) {
     hipDeviceProp_t p;
     EVR_HIP(hipGetDeviceProperties(&p, device));

@@ -1794,6 +1794,10 @@ extern "C" int evr_model_profile_read(evr_model* m, int max_layers, char* names,
         if (i < nconv) fl = m->convs[i].flops;
         else if (i == nconv + 64) fl = 2.0 * m->n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
         else if (i == nconv + (size_t)ST_DYN) fl = m->dyn_flops;
+        else if (i == nconv + (size_t)ST_ATTN && !m->et_attn.empty()) {      // every attention launch: S = Q K^T and O = P V over 8 heads of 32
+            const AttnArgs& a0 = m->et_attn[0];
+            fl = 2.0 * 2.0 * a0.n * (double)a0.Lq * a0.Lk * 32.0 * a0.heads;
+        }
         ms[k] = m->prof_ms[i]; flops_per_launch[k] = fl; launches[k] = m->prof_n[i];
         ++k;
     }

@@ -65,6 +65,7 @@ class MemMapDataset:
             self.length = min(self.length, max_length + 1)
         self._vox = None
         self._dev = None
+        self._host_cols = None
         self._img = None
         self._255 = None
         self._table = None
@@ -224,8 +225,15 @@ class MemMapDataset:
         return self._table
 
     # -- device residency ----------------------------------------------------------------------
-    def host_events(self):
-        """The sequence's event columns as the arrays that go to HBM (int16 xy, float64 t, uint8 p), validated."""
+    def host_events(self, keep=False):
+        """The sequence's event columns as the arrays that go to HBM (int16 xy, float64 t, uint8 p), validated.  The result is
+        cached until it has been handed out once with keep=False (eval's grouping validates a sequence before the batch that
+        uploads it is formed: one pass over the files, and the host copy is released as soon as it has been concatenated)."""
+        if self._host_cols is not None:
+            cols = self._host_cols
+            if not keep:
+                self._host_cols = None
+            return cols
         fh = self.filehandle
         xy = np.ascontiguousarray(fh["xy"])
         # The reference trusts the coordinates (SURVEY 8a quirk 6): index_put_ raises beyond the sensor and WRAPS negative
@@ -234,19 +242,30 @@ class MemMapDataset:
         if xy.size and (xy.min() < 0 or xy.max() >= 32768):
             raise ValueError(f"{self.data_path}: pixel coordinates outside [0, 32767] (min {xy.min()}, max {xy.max()})")
         # ... and a coordinate beyond sensor_resolution (a wrong constructor argument / metadata.json) would give plausible
-        # but wrong voxel grids: fail here, once per sequence, the way the reference fails on the first such window
+        # but wrong voxel grids: fail here, once per sequence, the way the reference fails on the first such window -- for the
+        # events some window of this dataset object can touch only (the reference never indexes the others: events before the
+        # first / after the last window, or beyond max_length)
         H, W = self.sensor_resolution
-        if xy.size and (int(xy[:, 0].max()) >= W or int(xy[:, 1].max()) >= H):
-            raise IndexError(f"{self.data_path}: event coordinates up to x={int(xy[:, 0].max())}, y={int(xy[:, 1].max())} "
-                             f"lie outside the {W}x{H} sensor (sensor_resolution is [H, W]): index out of range in the "
-                             "voxel grid")
+        tb = self.table()
+        ok = tb['valid'] & (tb['idx1'] > tb['idx0'])
+        if xy.size and ok.any():
+            lo, hi = int(tb['idx0'][ok].min()), int(tb['idx1'][ok].max())
+            used = xy[max(lo, 0):max(hi, 0)]
+            if used.size and (int(used[:, 0].max()) >= W or int(used[:, 1].max()) >= H):
+                raise IndexError(f"{self.data_path}: event coordinates up to x={int(used[:, 0].max())}, y={int(used[:, 1].max())} "
+                                 f"lie outside the {W}x{H} sensor (sensor_resolution is [H, W]): index out of range in the "
+                                 "voxel grid")
         pol = np.ascontiguousarray(fh["p"])
         # dataset.py:227 computes p*2-1 from {0,1}; a file that stores -1/+1 (or anything else) would silently become
         # 255 -> weight 509 after a uint8 cast
-        if pol.size and not np.isin(pol, (0, 1)).all():
+        # (one max / min pass: np.isin over millions of events was a third of a short call's set-up)
+        if pol.size and ((pol.max() > 1) if pol.dtype.kind in 'ub' else (pol.max() > 1 or pol.min() < 0 or pol.dtype.kind not in 'iu')):
             raise ValueError(f"{self.data_path}: events_p.npy must hold 0/1 (or bool) polarities, found values "
                              f"{np.unique(pol)[:6].tolist()}")
-        return xy.astype(np.int16), np.array(fh["t"], dtype=np.float64), pol.astype(np.uint8)
+        cols = (xy.astype(np.int16), np.array(fh["t"], dtype=np.float64), pol.astype(np.uint8))
+        if keep:
+            self._host_cols = cols
+        return cols
 
     def upload_images(self):
         """Reference frames (uint8) into HBM once."""
@@ -337,12 +356,21 @@ class SequenceBatch:
         assert all(tuple(d.sensor_resolution) == (H, W) for d in self.dss), "batched sequences must share the sensor size"
         self.H, self.W, self.num_bins = H, W, self.dss[0].num_bins
         self.device = self.dss[0].device
-        cols = [d.host_events() for d in self.dss]
+        cols = [d.host_events() for d in self.dss]      # (validated; a cached copy from eval's grouping is handed over and dropped)
         self.base = np.concatenate([[0], np.cumsum([len(c[1]) for c in cols])]).astype(np.int64)    # slot j = events [base[j], base[j+1])
         _lib.require_gpu()
-        self.xy = torch.from_numpy(np.concatenate([c[0] for c in cols])).to(self.device)
-        self.ts = torch.from_numpy(np.concatenate([c[1] for c in cols])).to(self.device)
-        self.p = torch.from_numpy(np.concatenate([c[2] for c in cols])).to(self.device)
+        n_ev = int(self.base[-1])
+        # one resident array per column, filled slot by slot: the host never holds a concatenated second copy of the batch
+        self.xy = torch.empty((n_ev, 2), dtype=torch.int16, device=self.device)
+        self.ts = torch.empty((n_ev,), dtype=torch.float64, device=self.device)
+        self.p = torch.empty((n_ev,), dtype=torch.uint8, device=self.device)
+        for j in range(len(cols)):
+            b, e = int(self.base[j]), int(self.base[j + 1])
+            if e > b:
+                self.xy[b:e].copy_(torch.from_numpy(cols[j][0].reshape(-1, 2)))
+                self.ts[b:e].copy_(torch.from_numpy(cols[j][1]))
+                self.p[b:e].copy_(torch.from_numpy(cols[j][2]))
+            cols[j] = None
         self.vox = Voxelizer(self.device)
 
     def voxel_steps(self, items, out, stats, stream=None):

@@ -107,7 +107,35 @@ def _load_checkpoint(path):
             del sys.modules['parse_config']
 
 
+_MODEL_CACHE = OrderedDict()      # (method, checkpoint identity, arithmetic switches) -> model with packed weights resident in HBM
+
+
+def _model_cache_key(model_name, checkpoint_path):
+    st = os.stat(checkpoint_path)
+    switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('EVR_')))     # every kernel / arithmetic switch is read at create time
+    return (model_name, os.path.abspath(checkpoint_path), st.st_mtime_ns, st.st_size, torch.cuda.current_device(), switches)
+
+
 def get_model_from_checkpoint_path(model_name, checkpoint_path):
+    """eval.py:124-158.  The reference re-reads the checkpoint for every (eval config, method) pair of a run; unpickling + re-laying
+    and splitting the weights for the matrix cores (evr_model_create: 0.1 s for E2VID) is most of a short call's set-up, so a model is
+    kept per (method, file identity, EVR_* switches) for the life of the process -- EVREAL_MODEL_CACHE=0 disables it.  Recurrent
+    state is reset per sequence by the callers, as before."""
+    if os.environ.get('EVREAL_MODEL_CACHE', '1') == '0':
+        return _build_model(model_name, checkpoint_path)
+    key = _model_cache_key(model_name, checkpoint_path)
+    model = _MODEL_CACHE.get(key)
+    if model is None:
+        model = _build_model(model_name, checkpoint_path)
+        _MODEL_CACHE[key] = model
+        while len(_MODEL_CACHE) > 4:
+            _MODEL_CACHE.popitem(last=False)
+    else:
+        _MODEL_CACHE.move_to_end(key)
+    return model
+
+
+def _build_model(model_name, checkpoint_path):
     checkpoint = _load_checkpoint(checkpoint_path)
     if model_name == "SPADE-E2VID":    # eval.py:130-133
         model, state_dict = model_arch.SpadeE2vid(), checkpoint
@@ -358,18 +386,24 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
 
 def sequence_costs(seqs):
     """Longest-processing-time weights of SURVEY 8e: number of windows x padded pixels per sequence.  Needs only the
-    .npy headers and the small per-frame tables (the event columns stay memory-mapped), so every rank can afford it for
-    the whole dataset; a sequence whose reader fails weighs 1 and fails again, loudly, on the rank that owns it."""
+    .npy headers and the small per-frame tables (the event columns stay memory-mapped).  Rank 0 computes them and
+    broadcasts the vector: every rank must partition by the SAME numbers (a rank-local read failure would otherwise
+    give ranks different plans: sequences evaluated twice or not at all); a sequence whose reader fails weighs 1 and
+    fails again, loudly, on the rank that owns it."""
     d = _dist()
     if d is None or d.get_world_size() <= 1 or len(seqs) <= 1:
         return [1] * len(seqs)          # one rank takes everything: nothing to balance
-    costs = []
-    for s in seqs:
-        try:
-            costs.append(MemMapDataset(s['sequence_path'], **s['dataset_kwargs']).window_cost())
-        except Exception:
-            costs.append(1)
-    return costs
+    box = [None]
+    if d.get_rank() == 0:
+        costs = []
+        for s in seqs:
+            try:
+                costs.append(MemMapDataset(s['sequence_path'], **s['dataset_kwargs']).window_cost())
+            except Exception:
+                costs.append(1)
+        box[0] = costs
+    d.broadcast_object_list(box, src=0)
+    return list(box[0])
 
 
 def fold_dataset_metrics(dataset_metrics, metric_names, dist, device=None):
@@ -430,10 +464,20 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
                 if S > 1 and not eval_config.get('color', False):
                     res0 = tuple(open_sequence(mine[k]).sensor_resolution)
                     ok0 = bool(open_sequence(mine[k]).table()['valid'].all())
+                    try:      # (a first sequence that does not validate runs -- and raises -- alone: no later sequence is opened)
+                        open_sequence(mine[k]).host_events(keep=True)
+                    except Exception:
+                        ok0 = False
                     while ok0 and len(group) < S and k + len(group) < len(mine):
                         nxt = mine[k + len(group)]
-                        if tuple(open_sequence(nxt).sensor_resolution) != res0:
-                            break
+                        try:      # a sequence whose files do not validate (coordinates beyond the sensor, polarities other than 0/1)
+                            # must not take the healthy sequences before it down: it starts its own group and fails there,
+                            # after they have been evaluated and counted, as in the reference's one-at-a-time loop
+                            if tuple(open_sequence(nxt).sensor_resolution) != res0:
+                                break
+                            open_sequence(nxt).host_events(keep=True)
+                        except Exception:
+                            break           # (evaluated on its own next: raises there with its own message)
                         group.append(nxt)
                         if not bool(open_sequence(nxt).table()['valid'].all()):
                             break

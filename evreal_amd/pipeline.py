@@ -10,6 +10,10 @@ frame: those kernels are small and leave most of the chip idle on their own; HIP
 the image buffer is double-buffered.  Scores then land in `scores_out` asynchronously: call flush() and synchronise
 before reading them or the (post-normalised) image -- the evaluation of the newest frame is held back until the next
 frame has been enqueued, so that it can start behind an event recorded INSIDE that frame (EVR_EVAL_GATE).
+Contract of the deferred evaluation: `ref` and `scores_out` passed to step t are READ / WRITTEN during step t + 1 (or
+flush()), so the caller must not overwrite `ref` in place between the two calls (pass a fresh tensor per frame, as
+evreal_amd.eval does, or use overlap=False); a caller that only does `step(); synchronize()` sees the newest frame's
+scores one step late.
 """
 import torch
 
@@ -62,11 +66,17 @@ class HotPath:
             if g and g != 'none' and hasattr(model, 'set_gate'):
                 h = ctypes.c_void_p()
                 _lib.check(_lib.load().evr_event_create(ctypes.byref(h)), 'evr_event_create')
-                try:
-                    model.set_gate(g, h)
-                    self._gate, self._gate_layer = h, g
-                    model._gate_owner = self
-                except _lib.EvrError:
+                # (a layout without the chosen layer -- one residual block, no residual blocks -- falls back to the earlier gate
+                # positions before giving the gate up; FireNet has none of them and runs ungated)
+                for layer in dict.fromkeys([g, 'res0.conv2', 'enc2.rec']):
+                    try:
+                        model.set_gate(layer, h)
+                        self._gate, self._gate_layer = h, layer
+                        model._gate_owner = self
+                        break
+                    except _lib.EvrError:
+                        continue
+                if self._gate is None:
                     _lib.load().evr_event_destroy(h)
         self._vox_events = None
         self._ring, self._ring_stats, self._ring_pos, self._ring_len = None, None, 0, 0
@@ -128,14 +138,16 @@ class HotPath:
         kernel drops and counts).  Synchronises: call it once per sequence / batch, not per step."""
         self.vox.raise_if_dropped()
 
-    def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None):
+    def step_raw(self, xy, ts, pol, win_offsets, ref=None, scores_out=None, n_window_events=None):
         """One frame for every sequence.  xy/ts/pol: resident raw event arrays; win_offsets: int64
         [n_seq+1] device tensor delimiting this step's n_seq windows.  ref: [n_seq,H,W] reference
-        frames (already /255) or None.  Returns (img [n_seq,1,H,W], scores [n_seq,2|3] = mse, ssim[, lpips] or None)."""
+        frames (already /255) or None.  n_window_events: events inside these windows if known on the host (Voxelizer.voxelize_raw).
+        Returns (img [n_seq,1,H,W], scores [n_seq,2|3] = mse, ssim[, lpips] or None)."""
         if self._vox_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats)
+        self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W), out=self.grid, stats=self.stats,
+                              n_window_events=n_window_events)
         if self._vox_events is not None:
             e1.record()
             self._vox_events.append((e0, e1))
@@ -145,7 +157,7 @@ class HotPath:
     # Windows do not depend on the recurrence, so the tensorizer may run for several steps at once: ONE launch over
     # A x n_seq windows (its kernels reach a higher fraction of the HBM roof on 512 windows than on 64) fills a
     # ring of voxel grids that the following A steps consume.
-    def prefetch_raw(self, xy, ts, pol, win_offsets, n_steps):
+    def prefetch_raw(self, xy, ts, pol, win_offsets, n_steps, n_window_events=None):
         """win_offsets: int64 [n_steps * n_seq + 1], the windows of the next n_steps steps in step-major order."""
         if self._ring is None or self._ring.shape[0] < n_steps:
             self._ring = torch.empty((n_steps, self.n, self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
@@ -156,7 +168,7 @@ class HotPath:
             e0.record()
         self.vox.voxelize_raw(xy, ts, pol, win_offsets, self.B, (self.H, self.W),
                               out=self._ring[:n_steps].view(n_steps * self.n, self.B, self.H, self.W),
-                              stats=self._ring_stats[:n_steps].view(n_steps * self.n, 3))
+                              stats=self._ring_stats[:n_steps].view(n_steps * self.n, 3), n_window_events=n_window_events)
         if self._vox_events is not None:
             e1.record()
             self._vox_events.append((e0, e1))

@@ -166,3 +166,39 @@ def test_dataset_reader_matches_reference_tables(tmp_path):
             assert sha(frames[j]) == c['items'][i]['frame_sha'], (name, i)
         item = ds[ok[-1]]
         assert item['event_count'] == c['items'][ok[-1]]['event_count'] and item['events'].shape == (5, s['height'], s['width'])
+
+
+def test_bad_sequence_does_not_discard_the_healthy_ones_before_it(tmp_path, monkeypatch, capsys):
+    """One sequence whose files do not validate (here: polarities stored as -1/+1 -> 255 after the uint8 cast) sits in the
+    middle of a dataset evaluated with batch_sequences = 8.  The reference evaluates and counts every sequence before the
+    failing one and stops the dataset there (eval.py:360-375); so must the batched loop: the sequences before it write
+    their files and enter dataset_metrics, the ones after it do not run."""
+    from evreal_amd import eval as ev, synth
+    monkeypatch.setenv('EVREAL_BATCH_SEQUENCES', '8')
+    g = load_json('eval_loop.json')
+    w = load_npz('firenet_weights.npz')
+    ckpt = {'state_dict': {k: torch.from_numpy(w[k]) for k in w.files},
+            'config': {'model': {'num_bins': 5, 'skip_type': 'no_skip', 'recurrent_block_type': 'convgru',
+                                 'base_num_channels': 16, 'num_residual_blocks': 2,
+                                 'recurrent_blocks': {'resblock': [0]}, 'kernel_size': 3,
+                                 'final_activation': 'none', 'norm': 'none', 'BN_momentum': 0.01}}}
+    model_path = str(tmp_path / 'firenet.pth')
+    torch.save(ckpt, model_path)
+    g2 = {'cfgs': {'k3k': dict(g['cfgs']['k3k'], save_images=False)},
+          'seqs': {f's{i}': [40 + i, 30000, 1.0e6, 64, 48, 200.0, None, None] for i in range(4)}}
+    _write_tree(str(tmp_path), g2, model_path)
+    bad = tmp_path / 'data' / 'SYN' / 's2' / 'events_p.npy'
+    p = np.load(bad)
+    np.save(bad, (p.astype(np.int8) * 2 - 1))                       # -1 / +1 instead of 0 / 1
+    monkeypatch.chdir(tmp_path)
+    res = ev.evaluate(['FireNet'], ['k3k'], ['SYN'], ['mse'])
+    out = capsys.readouterr().out
+    assert 'Exception while evaluating method FireNet on SYN dataset' in out and 'events_p.npy must hold 0/1' in out
+    base = tmp_path / 'outputs' / 'k3k' / 'SYN'
+    for ok_seq in ('s0', 's1'):
+        assert (base / ok_seq / 'FireNet' / 'timestamps.txt').read_text().strip(), ok_seq
+        assert (base / ok_seq / 'FireNet' / 'mse.txt').read_text().strip(), ok_seq
+    assert not (base / 's3' / 'FireNet' / 'timestamps.txt').exists()          # the reference's dataset loop stops at the failure
+    dm = res['k3k'][0][0]
+    n01 = sum(len((base / q / 'FireNet' / 'mse.txt').read_text().strip().splitlines()) for q in ('s0', 's1'))
+    assert dm.get_count('mse') == n01 > 0
