@@ -168,6 +168,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // is a 16-B access, the address arithmetic happens once per lane, and the fused prediction layer reduces over
 // channels in registers.  epi_setup (before the main loop) starts the accumulators at the bias and requests the
 // epilogue's operands (cell state / residual / fused skip) a whole main loop before they are needed.
+// timing ablation of the epilogues' memory traffic (tools/ablate_wide.sh; results are garbage): bit 4 (16) no operand loads, bit 6 (64) no stores
+#ifdef EVR_WIDE_ABLATE
+constexpr int EPI_ABLATE = EVR_WIDE_ABLATE;
+#else
+constexpr int EPI_ABLATE = 0;
+#endif
 struct EpiCtx {
     int m; bool mvalid, direct;
     int e_img, e_my, e_mx;      // decoded GEMM row (only when the output pixel is not the row itself)
@@ -229,7 +235,7 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
     const bool res = (epi == EPI_RESIDUAL_RELU);
     constexpr int PN = LSTM ? 1 : NB;
     const float* pre_ptr = LSTM ? a.state : (gru ? nullptr : (res ? a.residual : a.post_add));
-    if (pre_ptr && !(a.debug_ablate & 16)) {   // (bit 4 of EVR_ABLATE: timing without the operand loads)
+    if (pre_ptr && !(a.debug_ablate & 16) && !(EPI_ABLATE & 16)) {   // (bit 4 of EVR_ABLATE: timing without the operand loads)
         // The loads are issued back to back and their RAW bits parked in `pre` (PACKED operands are decoded in
         // epi_finish): anything that consumes a value here, or a per-lane branch around a load, makes hipcc wait
         // for each load in turn -- 16+ serialised L2 round trips per lane.  Lanes past the end of M read row 0.
@@ -313,14 +319,14 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 hn[j] = go * tanh_t<FAST>(cn[j]);                                          // submodules.py:243
                 hall[4 * q + j] = hn[j];
             }
-            *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
+            if (!(EPI_ABLATE & 64) || cn[0] == 123.456f) *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
             if (!a.out_packed) *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
             else if (!a.group_store) store4_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
         }
         if (a.out_packed && a.group_store) {       // the wave's 32 hidden channels of this pixel = two PACKED groups, one per lane of the pair
             float w16[16];
             xchg16(hall, w16);
-            store16_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 16 * h, w16);
+            if (!(EPI_ABLATE & 64) || w16[0] == 123.456f) store16_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 16 * h, w16);
         }
         return;
     } else {
@@ -481,7 +487,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 float w16[16];
                 xchg16(outv, w16);
                 const int cg = cgb - 4 * h + 16 * h;           // the lane's group inside the column group
-                if (mvalid && cg < nvalid) { sat_check16<FMT>(a.sat, w16); store16_fmt<FMT>(a.out, opx * ct, cg, w16); }
+                if (mvalid && cg < nvalid && (!(EPI_ABLATE & 64) || w16[0] == 123.456f)) { sat_check16<FMT>(a.sat, w16); store16_fmt<FMT>(a.out, opx * ct, cg, w16); }
                 __builtin_amdgcn_sched_barrier(0);             // one block's conversion temporaries at a time
             }
             // fused 1x1 prediction conv (model/unet.py:136-138): the group's last 32-column block closes one output
@@ -1446,6 +1452,14 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
     };
     const unsigned vmask0 = neighbours(mA), vmask1 = neighbours(mB);
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
+    // timing ablation (results are garbage when non-zero), COMPILE-TIME only (-DEVR_WIDE_ABLATE=mask, tools/ablate_wide.sh: a run-time
+    // mask costs this kernel registers it does not have): bit 0 no waits / barriers in the loop, bit 1 no LDS-DMA requests in the
+    // loop, bit 2 no epilogue, bit 5 no MFMAs (bits 4 / 6: no epilogue operand loads / no epilogue stores, EPI_ABLATE above)
+#ifdef EVR_WIDE_ABLATE
+    constexpr int ablate = EVR_WIDE_ABLATE;
+#else
+    constexpr int ablate = 0;
+#endif
 
     // prologue: band 0 and the first weight tile (bare s_barrier: __syncthreads() carries a fence hipcc lowers to vmcnt(0))
     if (tid < SP) lds[NBUF * A_F4 + 2 * B_F4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1465,8 +1479,8 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
             const int d2 = (t / 3 + 1) % 3;
             int cb = c + (t / 3 + 1) / 3;
             if (cb >= nchunks) cb = nchunks - 1;
-            issue_w(t2, cw, pa ^ ((t + 1) & 1));       // first, so that the counted wait below can leave the band in flight
-            if (!SINGLE && t % 3 == 0) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
+            if (!(ablate & 2)) issue_w(t2, cw, pa ^ ((t + 1) & 1));       // first, so that the counted wait below can leave the band in flight
+            if (!SINGLE && t % 3 == 0 && !(ablate & 2)) issue_band(cb, d2, pa ^ ((t / 3 + 1) & 1));
             __builtin_amdgcn_sched_barrier(0);
             const int ab = SINGLE ? 0 : (pa ^ ((t / 3) & 1));
             const float4* lb = &lds[NBUF * A_F4 + (pa ^ (t & 1)) * B_F4 + (wni * 32 * NB + r) * SP];
@@ -1487,18 +1501,22 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
                 if constexpr (PHASES == 1) { if ((t / 3 == 0 && (nb >> 1) == 1) || (t % 3 == 0 && (nb & 1) == 1)) continue; }
                 if constexpr (PHASES == 2) { if (t % 3 == 0 && (nb >> 1) == 1) continue; }
                 const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+                if (ablate & 32) { acc0[nb][0] += __uint_as_float(wb.h0[0] ^ xa0.h0[0]); acc1[nb][0] += __uint_as_float(wb.h1[1] ^ xa1.f0[0]); }
+                else {
                 acc0[nb] = mma_split(acc0[nb], wb, xa0, mx_sb, mx_sa);
                 acc1[nb] = mma_split(acc1[nb], wb, xa1, mx_sb, mx_sa);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             }
             // the tile requested first in THIS step is needed next; only the band pieces requested after it may stay in
             // flight (loads complete in order).  lgkmcnt(0): this wave's fragment reads have left LDS before anyone
             // overwrites the buffers
+            if (ablate & 1) continue;
             if constexpr (SINGLE) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (t % 3 == 2 && !(t == 8 && c == nchunks - 1)) {   // everyone has left the band: fetch the next one into the same buffer
-                    issue_band(cb, d2, 0);
+                    if (!(ablate & 2)) issue_band(cb, d2, 0);
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 }
             } else {
@@ -1507,12 +1525,74 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
             }
         }
     }
+    if (ablate & 4) { if (acc0[0][0] + acc1[1][0] + acc0[2][3] + acc1[3][5] == 123.456f) img_out[tid] = acc0[1][1] + acc1[0][2] + acc0[3][0] + acc1[2][0]; return; }
     if constexpr (LSTM) {      // the cell update needs the four gate blocks together
+        // (both pixel blocks' cell states are requested before the first block's gate arithmetic: the second request's latency
+        // hides under it instead of following it)
+        f32x16 late2[PN];
         epi_prefetch<NB, true, false>(a, n0w, h, late, ec0);
+        epi_prefetch<NB, true, false>(a, n0w, h, late2, ec1);
         epi_finish<NB, true, false, true>(a, ec0, n0w, h, acc0, late, img_out);
-        epi_prefetch<NB, true, false>(a, n0w, h, late, ec1);
-        epi_finish<NB, true, false, true>(a, ec1, n0w, h, acc1, late, img_out);
+        epi_finish<NB, true, false, true>(a, ec1, n0w, h, acc1, late2, img_out);
     } else {
+        if constexpr (GROUPED) {
+            // The last decoder with the prediction layer fused and every 32-column block = one sub-pixel phase (E2VID: dec2): a block
+            // closes one output pixel per lane pair, so the epilogue is a reduction of the accumulators and nothing has to be parked.
+            // All eight (pixel block, phase) skip terms are requested FIRST and consumed after the eight dot products: the general
+            // path below ran eight load -> sigmoid -> store chains one after the other (timing ablation, round 4: 331 of this
+            // layer's 657 us were its epilogue; 657 -> 428 us with this form).  Same operation order per value as epi_finish:
+            // results are bit-identical.
+            if (a.pred_w && a.tp.grp_cols == 32 && a.out == nullptr && a.post_add == nullptr && a.n_valid >= 32 &&
+                (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU)) {
+                const bool relu = a.epi != EPI_BIAS;
+                const float sc = (ARITH == 3 || ARITH == 4) ? a.acc_scale : 1.0f;
+                unsigned opx[2][NB]; int oy[2][NB], ox[2][NB]; float skipv[2][NB];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        int cgb;
+                        const EpiCtx& ec = pb ? ec1 : ec0;
+                        out_addr<true>(a, ec, n0w, h, nb, opx[pb][nb], cgb, oy[pb][nb], ox[pb][nb]);
+                        skipv[pb][nb] = (a.pred_skip_dot && ec.mvalid) ? a.pred_skip_dot[opx[pb][nb]] : 0.f;
+                    }
+                f4 pwq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pwq[q] = *(const f4*)(a.pred_w + 4 * h + 8 * q);
+                float part[2][NB];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        float pp = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            float v = (pb ? acc1[nb][i] : acc0[nb][i]) * sc;
+                            v = relu ? fmaxf(v, 0.f) : v;
+                            pp = fmaf(v, pwq[i >> 2][i & 3], pp);
+                        }
+                        part[pb][nb] = pp;
+                    }
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const EpiCtx& ec = pb ? ec1 : ec0;
+                        float pp = part[pb][nb];
+                        pp += __shfl_xor(pp, 32, 64);
+                        if (h == 0 && ec.mvalid) {
+                            const int y = oy[pb][nb] - a.crop_y0, x = ox[pb][nb] - a.crop_x0;
+                            float sres = pp + a.pred_b;
+                            if (a.pred_skip_dot) sres += skipv[pb][nb];
+                            if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
+                            if (a.prev_rec) a.prev_rec[opx[pb][nb]] = sres;
+                            if ((unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w)
+                                img_out[(unsigned)((ec.e_img * a.crop_h + y) * a.crop_w + x)] = sres;
+                        }
+                    }
+                return;
+            }
+        }
         // plain epilogues: one 32-column block at a time, and the second pixel block's 64 accumulators wait in LDS (idle
         // now: the last step ended with vmcnt(0) + barrier) -- 128 live accumulators plus the epilogue's operand /
         // conversion registers do not fit in 256, and hipcc's own spill goes to scratch memory

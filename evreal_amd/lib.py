@@ -101,10 +101,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EvrError(f"{LIB_PATH} not found: build it with `python -m evreal_amd.build` "
+    path = os.environ.get('EVR_LIB') or LIB_PATH      # (EVR_LIB: another BUILD of this library -- timing-ablation variants, tools/ablate_wide.sh)
+    if not os.path.exists(path):
+        raise EvrError(f"{path} not found: build it with `python -m evreal_amd.build` "
                        "(there is no CPU fallback)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the ABI and the header drifted apart
         fn.restype, fn.argtypes = res, args
