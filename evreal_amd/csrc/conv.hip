@@ -319,7 +319,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                 hn[j] = go * tanh_t<FAST>(cn[j]);                                          // submodules.py:243
                 hall[4 * q + j] = hn[j];
             }
-            if (!(EPI_ABLATE & 64) || cn[0] == 123.456f) *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;                  // the cell state stays fp32 (never a GEMM operand)
+            if (!(EPI_ABLATE & (64 | 256)) || cn[0] == 123.456f) *(f4*)(a.state + ec.lstm_o + 8 * q) = cn;      // (bit 8: the cell-state store alone -- a clean ablation: c feeds no matrix operand)                  // the cell state stays fp32 (never a GEMM operand)
             if (!a.out_packed) *(f4*)(a.out + ec.lstm_o + 8 * q) = hn;
             else if (!a.group_store) store4_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
         }
@@ -1596,31 +1596,55 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
         // plain epilogues: one 32-column block at a time, and the second pixel block's 64 accumulators wait in LDS (idle
         // now: the last step ended with vmcnt(0) + barrier) -- 128 live accumulators plus the epilogue's operand /
         // conversion registers do not fit in 256, and hipcc's own spill goes to scratch memory
+        // (round 4: the operands of a pixel block's FOUR column blocks are requested together -- two exposed load latencies per tile
+        // instead of eight: the timing ablation put 100 of dec1's 590 us on these loads.  Not in the fp6 build: its group conversion
+        // needs the registers, hipcc spilled 5 of them.)
         float4* park = &lds[wv * 1024];        // 16 KB per wave
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 park[(nb * 4 + q) * 64 + lane] = make_float4(acc1[nb][4 * q], acc1[nb][4 * q + 1], acc1[nb][4 * q + 2], acc1[nb][4 * q + 3]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f32x16 one[1], op[1];
-            one[0] = acc0[nb];
-            epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec0);
-            epi_finish<1, false, GROUPED, true>(a, ec0, n0w + 32 * nb, h, one, op, img_out);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            f32x16 one[1], op[1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = park[(nb * 4 + q) * 64 + lane];
-                one[0][4 * q] = v.x; one[0][4 * q + 1] = v.y; one[0][4 * q + 2] = v.z; one[0][4 * q + 3] = v.w;
+        if constexpr (FMT != 3) {
+            {
+                f32x16 op4[NB];
+                epi_prefetch<NB, false, GROUPED>(a, n0w, h, op4, ec0);
+                epi_finish<NB, false, GROUPED, true>(a, ec0, n0w, h, acc0, op4, img_out);
             }
-            epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec1);
-            epi_finish<1, false, GROUPED, true>(a, ec1, n0w + 32 * nb, h, one, op, img_out);
             __builtin_amdgcn_sched_barrier(0);
+            {
+                f32x16 op4[NB];
+                epi_prefetch<NB, false, GROUPED>(a, n0w, h, op4, ec1);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = park[(nb * 4 + q) * 64 + lane];
+                        acc0[nb][4 * q] = v.x; acc0[nb][4 * q + 1] = v.y; acc0[nb][4 * q + 2] = v.z; acc0[nb][4 * q + 3] = v.w;
+                    }
+                epi_finish<NB, false, GROUPED, true>(a, ec1, n0w, h, acc0, op4, img_out);
+            }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x16 one[1], op[1];
+                one[0] = acc0[nb];
+                epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec0);
+                epi_finish<1, false, GROUPED, true>(a, ec0, n0w + 32 * nb, h, one, op, img_out);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x16 one[1], op[1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = park[(nb * 4 + q) * 64 + lane];
+                    one[0][4 * q] = v.x; one[0][4 * q + 1] = v.y; one[0][4 * q + 2] = v.z; one[0][4 * q + 3] = v.w;
+                }
+                epi_prefetch<1, false, GROUPED>(a, n0w + 32 * nb, h, op, ec1);
+                epi_finish<1, false, GROUPED, true>(a, ec1, n0w + 32 * nb, h, one, op, img_out);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #endif

@@ -47,10 +47,15 @@ class HotPath:
         self.img = torch.empty((n_seq, 1, self.H, self.W), dtype=torch.float32, device=self.dev)
         self.overlap = bool(overlap)
         if self.overlap:
-            self.imgs = [self.img, torch.empty_like(self.img)]
+            # EVR_IMG_BUFFERS image buffers in rotation (default 3): frame t + 2 must not wait for the evaluation of frame t, which starts
+            # late inside frame t + 1 (the gate below) and ends after it -- with two buffers the reconstruction stream stalled at
+            # every frame start until that evaluation had released its buffer
+            import os as _os
+            nbuf = max(2, int(_os.environ.get('EVR_IMG_BUFFERS', '3') or 3))
+            self.imgs = [self.img] + [torch.empty_like(self.img) for _ in range(nbuf - 1)]
             self.side = self._side_stream()
-            self.ev_model = [torch.cuda.Event(), torch.cuda.Event()]     # image k is complete (main stream)
-            self.ev_done = [None, None]                                  # evaluation of image k has finished (side stream)
+            self.ev_model = [torch.cuda.Event() for _ in range(nbuf)]    # image k is complete (main stream)
+            self.ev_done = [None] * nbuf                                 # evaluation of image k has finished (side stream)
             self.k = 0
             # The evaluation of frame t starts only when frame t+1 has passed the layer EVR_EVAL_GATE names (the library records an
             # event there; 'none': at once, as in rounds 1-2): the evaluation kernels then share the chip with the residual blocks /
@@ -208,11 +213,11 @@ class HotPath:
             self._pending = None
 
     def _rest_overlapped(self, ref, scores_out, grid, stats):
-        k = self.k; self.k ^= 1
+        k = self.k; self.k = (k + 1) % len(self.imgs)
         main = torch.cuda.current_stream(self.dev)
         img = self.imgs[k]
         if self.ev_done[k] is not None:
-            main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (two frames ago)
+            main.wait_event(self.ev_done[k])           # the side stream is done with this buffer (len(imgs) frames ago)
         if self._gate is not None and getattr(self.model, '_gate_owner', None) is not self:
             self.model.set_gate(self._gate_layer, self._gate)      # (another HotPath over the same model took the gate)
             self.model._gate_owner = self
