@@ -45,6 +45,7 @@
 //               tile fastest: an A tile is reused from L2 across its N tiles and neighbouring M tiles
 #include "conv.h"
 #include "packed.h"
+#include <atomic>
 #include <cstdlib>
 
 // This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
@@ -1190,7 +1191,7 @@ static bool bandk_eligible(const ConvArgs& a, int kc, int kw) {
 // ReLU / residual / ConvGRU update / fused prediction: the shared epi_finish), which therefore runs under that DMA.
 // The exact-fp32 MFMA these layers used before runs at 1/16 of the f16 rate; the padded-to-32-channels route (EVR_FIRENET_PAD32)
 // doubles every tensor's bytes in a network that is HBM-bound (28 tensor passes of 64 B per pixel per frame).
-template <int NB>
+template <int NB, int NBUF>
 __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -1198,8 +1199,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
     constexpr int A_ROWS = TM + 16, A_PIECES = A_ROWS / 16, A_F4 = A_ROWS * SP;      // a DMA piece = 16 rows
     constexpr int W_ROWS = 32 * NB, W_F4 = W_ROWS * SP, W_PIECES = W_ROWS / 16;      // one (tap, source) weight tile
     constexpr int MAX_TC = 18;                           // 9 taps x 2 sources
-    __shared__ __attribute__((aligned(16))) float4 lds[2 * A_F4 + MAX_TC * W_F4 + SP];   // [band 0 | band 1 | weights | a zero row]
-    constexpr int WOFF = 2 * A_F4, ZOFF = 2 * A_F4 + MAX_TC * W_F4;
+    // Round 4: a RING of NBUF band buffers, requests DIST bands ahead of the one being multiplied (across tile boundaries).  These
+    // layers are bound by HBM latency, not bandwidth: with two buffers a block had one 9-KB band in flight, 2 blocks x 256 CUs x 9 KB
+    // = 4.7 MB on the whole chip -- at ~2 us per round trip that is the 2.2 TB/s the kernel measured (0.27 of the roof).
+    // NBUF = 4 (two-source layers: the ConvGRU gates; 74 KB, two blocks per CU) or 2 (one-source layers: the residual convolutions,
+    // whose 9 weight tiles leave room for FOUR blocks per CU at 37 KB -- they are bound by per-tile latency, not by bytes: 4.2 us per
+    // 128-pixel tile and block for 0.4 us of MFMAs); the LDS is sized per launch (launch_c16).
+    constexpr int DIST = NBUF - 1;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [band ring | weights (9 or 18 tiles) | a zero row]
+    (void)MAX_TC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1218,6 +1226,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
     const int r = lane & 31, hh = lane >> 5;
     const int idx = wmi * 32 + r;
+    const int WOFF = NBUF * A_F4, ZOFF = NBUF * A_F4 + ntc * W_F4;
 
     // N tile of this block (persistent over M): blocks b, b + ntiles_n, ... share it -- with one N tile (every FireNet layer) all do
     const int ntile = blockIdx.x % ntiles_n, n0 = ntile * 32 * NB;
@@ -1234,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
     auto issue_band = [&](int m0, int bi, int buf) {      // band bi = (source bi / 3, dy = bi % 3 - 1) of the tile at m0
         const bool second = bi >= 3;
         const int shift = (bi % 3 - 1) * W;
-        for (int p = wmi; p < A_PIECES; p += WM) {
+        for (int p = wmi; p < A_PIECES; p += WM) {        // wave 0: pieces 0, 4, 8; the others two each (npw below)
             const int row = p * 16 + (lane >> 2);
             const int pix = m0 - 1 + row + shift;
             unsigned voff = OOB_OFFSET;
@@ -1245,17 +1254,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
         }
     };
     const int nbands = 3 * nsrc;
+    // the request stream runs DIST bands ahead of the multiply stream; both walk (tile, band) in the same order
     int mt = mstart;
-    int cur = 0;                                          // band buffer of the band being multiplied; toggles with every band, across tiles
-    if (mt < mtiles) issue_band(mt * TM, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int rq_mt = mstart, rq_bi = 0, rq_buf = 0;
+    int ahead = 0;                                        // bands requested and not yet multiplied
+    auto request_next = [&]() {
+        if (rq_mt < mtiles) { issue_band(rq_mt * TM, rq_bi, rq_buf); ++ahead; }
+        rq_buf = (rq_buf + 1) & (NBUF - 1);
+        if (++rq_bi == nbands) { rq_bi = 0; rq_mt += mstep; }
+    };
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) request_next();
+    int cur = 0;                                          // ring slot of the band being multiplied
     const int sw = swz<16>(r);
-    for (; mt < mtiles; mt += mstep) {
+    // requests of one wave per band: wave 0 carries pieces 0, 4, 8, the others two -- wave-uniform wait counts
+    const int npw = (wmi == 0) ? 3 : 2;
+    // the accumulators start at the bias of the block's N tile: fetched ONCE (a per-tile fetch sits behind the requested bands in the
+    // in-order return stream, and waiting for it would drain the look-ahead at every tile)
+    f32x16 bias0[NB];
+    {
+        f32x16 pre0[NB]; EpiCtx ec0_;
+        epi_setup<NB, false, false>(a, 0, M, hw, n0, hh, bias0, pre0, ec0_, true, false);
+    }
+    while (mt < mtiles) {
         const int m0 = mt * TM;
         f32x16 acc[NB];
         f32x16 pre[NB];
         EpiCtx ec;
-        epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, hh, acc, pre, ec, true, false);
+        epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, hh, acc, pre, ec, true, false);      // (its bias loads are dead: replaced below)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = bias0[nb];
         unsigned vmask = 0;
         {
             const int m = m0 + idx;
@@ -1270,11 +1298,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
             }
         }
         for (int bi = 0; bi < nbands; ++bi) {
+            // band `cur` has landed once at most DIST - 1 later bands of this wave are outstanding (requests complete in order; anything
+            // else in flight -- the previous tile's stores -- only makes the wait conservative); the barrier publishes every wave's
+            // pieces and tells that everyone has left the band multiplied before this one, whose slot the next request reuses
+            // (the stream's tail, where fewer than DIST bands are ahead: wait for everything)
+            if (DIST == 1 || ahead < DIST) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (npw == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            static_assert(DIST == 1 || DIST == 3, "update the counted waits: (DIST - 1) bands of 3 | 2 requests");
+            --ahead;
+            // the epilogue's operands are requested BEFORE the last band's look-ahead request, so that waiting for them later does
+            // not wait for the bands requested behind them
+            if (bi + 1 == nbands) epi_prefetch<NB, false, false>(a, n0, hh, pre, ec);
+            request_next();
             const int buf = cur;
-            cur ^= 1;
-            // the next band of this tile -- or, during the last band, the first band of the block's NEXT tile
-            if (bi + 1 < nbands) issue_band(m0, bi + 1, buf ^ 1);
-            else if (mt + mstep < mtiles) issue_band((mt + mstep) * TM, 0, buf ^ 1);
+            cur = (cur + 1) & (NBUF - 1);
             const int src = bi / 3, dy = bi % 3;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
@@ -1293,12 +1331,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc[nb], 0, 0, 0);
                 }
             }
-            if (bi + 1 < nbands) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the next tile's band stays in flight under the epilogue
         }
-        epi_prefetch<NB, false, false>(a, n0, hh, pre, ec);
         epi_finish<NB, false, false, true>(a, ec, n0, hh, acc, pre, img_out);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                  // ... and has landed for everyone before the next tile reads it
+        mt += mstep;
     }
 #endif
 }
@@ -1307,9 +1342,21 @@ template <int NB>
 static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int mtiles = (M + 127) / 128, ntiles_n = a.cout / (32 * NB);
-    int per_n = 256 * 2;                                  // persistent: two blocks per CU (55 KB of LDS each) walk the M tiles
+    const int nsrc = (a.in_mode == IN_CAT && a.c1) ? 2 : 1;
+    static const int c16_blocks = getenv("EVR_C16_BLOCKS") ? atoi(getenv("EVR_C16_BLOCKS")) : 3;      // (A/B: blocks per CU of the one-source form)
+    const int nbuf = nsrc == 1 ? 2 : 4;
+    const size_t lds_bytes = ((size_t)nbuf * (128 + 16) * 4 + (size_t)9 * nsrc * 32 * NB * 4 + 4) * sizeof(float4);
+    int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : 2;      // (measured 3 > 4 > 2: 157 / 183 / 189 us for FireNet's residual convolutions)
+    int per_n = 256 * per_cu;                             // persistent: the resident blocks walk the M tiles
     if (per_n > mtiles) per_n = mtiles;
-    hipLaunchKernelGGL((conv3x3_c16_kernel<NB>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), 0, stream, d_args, img);
+    static std::atomic<unsigned> attr_done{0};
+    if (!attr_done.load(std::memory_order_relaxed)) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done.store(1, std::memory_order_relaxed);
+    }
+    if (nbuf == 2) hipLaunchKernelGGL((conv3x3_c16_kernel<NB, 2>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), lds_bytes, stream, d_args, img);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<NB, 4>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), lds_bytes, stream, d_args, img);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

@@ -93,6 +93,17 @@ def test_drift_100_frames_346x260_8_sequences():
     print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
 
 
+def test_recurrence_1000_frames_at_the_64_sequence_dispatch():
+    """The recurrence at the dispatch bench.py times: 64 sequences advanced together (the 256 x 128 / 256 x 256-tile ConvLSTM kernels, the
+    twin-form decoders with the fused prediction epilogue), 1000 frames, sequence 37 replayed through the CPU oracle at every frame;
+    final ConvLSTM states checked.  (Round 3 ran this from tools/drift_run.py only: profiles/r03_drift_1000_*.json.)"""
+    from evreal_amd import weights
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    m, o = _pair(dict(weights.E2VID_KWARGS), seed=21)
+    worst = _run(m, o, 260, 346, 3, frames=1000, n_seq=64, n_events=15000, seed0=90000, check_states=True, oracle_seqs=[37])
+    print(f'1000-frame drift, 64 sequences: worst per-pixel error {worst:.2e}')
+
+
 def test_e2vid_640x480_vs_oracle():
     from evreal_amd import weights
     m, o = _pair(dict(weights.E2VID_KWARGS), seed=22)
