@@ -14,7 +14,8 @@ SURVEY 8e): raw events (resident in HBM) -> voxel grid -> [event-tensor normaliz
 -> crop -> [robust percentile normalization] -> clip -> MSE + SSIM + LPIPS against the reference frame (LPIPS =
 AlexNet v0.1 structure on synthetic weights unless EVREAL_LPIPS_WEIGHTS names a real state_dict: they cannot be
 downloaded here).  The evaluation half of a frame runs on a second HIP stream and overlaps the reconstruction of
-the next frame (`--no-overlap`: one stream); all of a step's work is inside the timed region.
+the next frame (`--no-overlap`: one stream); all of a step's work is inside the timed region.  `--unique-steps` (40)
+distinct windows per sequence are resident; later steps reuse them in order while the recurrent state keeps evolving.
 
 `--config` selects the workload (BASELINE.json configs 2-5; the default `e2vid` is the configuration the metric is
 quoted on):
@@ -24,25 +25,26 @@ quoted on):
     color    ColorNet over the E2VID+ layout, 970x624 (BS-ERGB's 970x625 cropped to even sides: the reference's ColorNet
              raises on odd sides), 50k events/window, 1 sequence = 5 recurrent streams; no metrics (the reference skips them)
     e2vidplus / etnet / spade   the other methods of the reference's registry (E2VID+ = SSL-E2VID layout, ET-Net, SPADE-E2VID), 346x260
-Arithmetic (csrc/conv.h): default split f16 + MX-fp6 ("mx6") where the layout's packed tensors all come from matrix-core epilogues
-(E2VID), split f16 + MX-fp8 ("mx") for the other layouts and under EVR_ARITH=mx; EVR_ARITH=h3 three f16 products, fp32-grade;
-EVR_FP32=1 exact fp32 MFMA.  `config.arithmetic_mode` / `dtype` report what the model actually ran (evr_model_arith).
+    ckpt     a user's trained checkpoint: EVREAL_MODEL_CKPT=<file> EVREAL_MODEL_METHOD=<E2VID|E2VID+|SSL-E2VID|FireNet|FireNet+|HyperE2VID>
+Arithmetic (csrc/conv.h): default `h3` = three f16 products per term on H2 tensors, fp32-grade (the reference computes in fp32; image
+gate 1e-5); EVR_ARITH=mx6 the opt-in fast mode (f16 + MX-fp6 cross terms; the `fast` block), EVR_ARITH=mx (f16 + MX-fp8), EVR_FP32=1 exact
+fp32 MFMA.  `config.arithmetic_mode` / `dtype` report what the model actually ran (evr_model_arith).
 
-Rank 0 prints ONE JSON line (contract in the task statement).  Besides `roofline` (dominant kernel) and
-`cpu_baseline` it carries, all measured OUTSIDE the timed region of the same run:
+Rank 0 prints ONE JSON line < 4 KB as the LAST stdout line (compact_line: every key of the task's contract + `roofline` (dominant kernel)
++ `cpu_baseline`, scalars only for the side blocks); the full object is written to gpurun_out/bench_full.json.  `--sub` runs (the side
+blocks' sub-processes) print the full object.  Blocks of the full object, all measured OUTSIDE the timed region of the same run:
   roofline_voxelizer  HIP-event time of the tensorizer launches (in the step and standalone at S and 512 windows)
-  score_parity        the first frames of sequence 0 replayed on the GPU and through the CPU oracle: per-frame image
+  score_parity        the first frames of sequences 0 and 37 replayed on the GPU and through the CPU oracle: per-frame image
                       error, mean MSE/SSIM/LPIPS of both, relative error, agreement to 3 significant figures
-  fp8_cross_terms     the same steps in a sub-process with EVR_ARITH=mx (f16 + MX-fp8: last round's arithmetic), with its own parity
-  fp32_equiv          the same steps in a sub-process with EVR_ARITH=h3 (three f16 products: fp32-grade), with its own parity
-  fp32_exact          ... with EVR_FP32=1 (exact fp32 MFMA arithmetic), with its own parity
+  fast / fp8_cross_terms / fp32_exact   the same steps in a sub-process with EVR_ARITH=mx6 / mx / EVR_FP32=1, each with its own parity
   sensor_640x480      the same workload on 640x480 streams (north_star's second sensor size), with its own parity
-  configs             BASELINE configs 3, 4, 5 (`--config firenet|hyper|color` sub-processes), each with frames/s, dominant
-                      layer + roofline fraction and an oracle comparison
+  configs             BASELINE configs 3, 4, 5 (`--config firenet|hyper|color` sub-processes) + the other registry methods, each with
+                      frames/s, dominant layer + roofline fraction and an oracle comparison
+  user_checkpoint     `--config ckpt` when EVREAL_MODEL_CKPT is set
   eval_cli            the drop-in `evreal_amd.eval.evaluate` on a synthetic dataset tree (8 sequences), images on / off
-  large_batch         128 sequences per GPU (sub-process, own parity): the headline's 64 is the quoted configuration, not a limit
-  small_batch         1, 4, 8, 16 and 32 sequences per GPU (the reference's regime is batch 1; evreal_amd.eval defaults to 8)
-  steady_state        >= 2 s of back-to-back steps (the timed region of a 20-step run is 0.25 s)
+  large_batch / small_batch   128 and 1, 4, 8, 16, 32 sequences per GPU
+  steady_state        >= 2 s of back-to-back steps
+  per_rank            (N > 1) slowest / fastest rank's own frames/s
 """
 import argparse
 import hashlib
