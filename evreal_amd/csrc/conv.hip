@@ -47,6 +47,7 @@
 #include "packed.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 // This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
 // exact-fp32 kernels -- EVR_ARITH = 3 -- three f16 products on H2 tensors -- and EVR_ARITH = 4 -- f16 + MX-fp6 on P6 tensors, the
@@ -1226,16 +1227,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
     const int r = lane & 31, hh = lane >> 5;
     const int idx = wmi * 32 + r;
-    const int WOFF = NBUF * A_F4, ZOFF = NBUF * A_F4 + ntc * W_F4;
+    // (a layer with at most 16 real output columns -- the ConvGRU candidate convolution -- keeps only weight rows 0..15 in LDS: lanes
+    // of rows 16..31 read the zero row, their accumulator columns are padding nobody stores; 18 KB less, a third block per CU)
+    const int wrows = (NB == 1 && a.n_valid <= 16) ? 16 : W_ROWS, w_f4 = wrows * SP, w_pieces = wrows / 16;
+    const int WOFF = NBUF * A_F4, ZOFF = NBUF * A_F4 + ntc * w_f4;
 
     // N tile of this block (persistent over M): blocks b, b + ntiles_n, ... share it -- with one N tile (every FireNet layer) all do
     const int ntile = blockIdx.x % ntiles_n, n0 = ntile * 32 * NB;
     const int mstart = blockIdx.x / ntiles_n, mstep = gridDim.x / ntiles_n;
     // ---- weights: all (tap, source) tiles of the N tile, once
-    for (int p = wmi; p < ntc * W_PIECES; p += WM) {
-        const int tc = p / W_PIECES, row = (p % W_PIECES) * 16 + (lane >> 2);
+    (void)W_F4; (void)W_PIECES;
+    for (int p = wmi; p < ntc * w_pieces; p += WM) {
+        const int tc = p / w_pieces, row = (p % w_pieces) * 16 + (lane >> 2);
         const unsigned off = (unsigned)((n0 + row) * ktot + tc * 16 + (((lane & 3) ^ swz<16>(row)) * 4));
-        lds_ptr_t dst = (lds_ptr_t)&lds[WOFF + tc * W_F4 + (p % W_PIECES) * 64];
+        lds_ptr_t dst = (lds_ptr_t)&lds[WOFF + tc * w_f4 + (p % w_pieces) * 64];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, off * 4u, 0, 0, 0);
     }
     if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1322,7 +1327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
                 const float4* la = &lds[keep ? buf * A_F4 + i * SP : ZOFF];
                 const int swi = swz<16>(i);
                 const u32x4_t xh = __builtin_bit_cast(u32x4_t, la[hh ^ swi]), xl = __builtin_bit_cast(u32x4_t, la[(2 + hh) ^ swi]);
-                const float4* lb = &lds[WOFF + (t * nsrc + src) * W_F4 + r * SP];
+                const float4* lb = &lds[(NB > 1 || r < wrows) ? WOFF + (t * nsrc + src) * w_f4 + r * SP : ZOFF];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const u32x4_t wh = __builtin_bit_cast(u32x4_t, lb[nb * 32 * SP + (hh ^ sw)]), wl = __builtin_bit_cast(u32x4_t, lb[nb * 32 * SP + ((2 + hh) ^ sw)]);
@@ -1344,9 +1349,16 @@ static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t str
     const int mtiles = (M + 127) / 128, ntiles_n = a.cout / (32 * NB);
     const int nsrc = (a.in_mode == IN_CAT && a.c1) ? 2 : 1;
     static const int c16_blocks = getenv("EVR_C16_BLOCKS") ? atoi(getenv("EVR_C16_BLOCKS")) : 3;      // (A/B: blocks per CU of the one-source form)
-    const int nbuf = nsrc == 1 ? 2 : 4;
-    const size_t lds_bytes = ((size_t)nbuf * (128 + 16) * 4 + (size_t)9 * nsrc * 32 * NB * 4 + 4) * sizeof(float4);
-    int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : 2;      // (measured 3 > 4 > 2: 157 / 183 / 189 us for FireNet's residual convolutions)
+    // one-source layers (residual convolutions): two band buffers, three blocks per CU (measured 3 > 4 > 2: 157 / 183 / 189 us);
+    // two-source layers with 32 real columns (ConvGRU z|r gates): a ring of four, two blocks; with <= 16 real columns (the ConvGRU
+    // candidate convolution: half the weight rows) EVR_C16_OUT=<nbuf>,<blocks> (default 2,3)
+    const bool half_w = NB == 1 && a.n_valid <= 16;
+    static const int out_nbuf = [] { const char* e = getenv("EVR_C16_OUT"); return e ? atoi(e) : 2; }();
+    static const int out_blocks = [] { const char* e = getenv("EVR_C16_OUT"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 3; }();
+    const int nbuf = nsrc == 1 ? 2 : (half_w ? (out_nbuf == 4 ? 4 : 2) : 4);
+    const int wrows = half_w ? 16 : 32 * NB;
+    const size_t lds_bytes = ((size_t)nbuf * (128 + 16) * 4 + (size_t)9 * nsrc * wrows * 4 + 4) * sizeof(float4);
+    int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : (half_w ? (out_blocks > 0 ? out_blocks : 3) : 2);
     int per_n = 256 * per_cu;                             // persistent: the resident blocks walk the M tiles
     if (per_n > mtiles) per_n = mtiles;
     static std::atomic<unsigned> attr_done{0};
