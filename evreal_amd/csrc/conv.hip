@@ -48,6 +48,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 // This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
 // exact-fp32 kernels -- EVR_ARITH = 3 -- three f16 products on H2 tensors -- and EVR_ARITH = 4 -- f16 + MX-fp6 on P6 tensors, the
@@ -739,8 +741,8 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0) ? ((WM == 4 && !LSTM) ? 2 : 1) :
 // phases, so the (tap, block) pairs the transposed kernel does not connect -- phase py = 1 never takes dy = -1, px = 1
 // never dx = -1 -- are dropped at COMPILE time (no branches in the step): 1 = block nb is phase (nb >> 1, nb & 1)
 // [32 columns per phase], 2 = blocks {0,1} px = 0, {2,3} px = 1 [64 columns per phase; py is per tile], 0 = unknown.
-template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false, int PHASES = 0>
-__global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+template <int WM, int RING, bool LSTM, bool GROUPED, bool OVL = false, int PHASES = 0, bool KSPLIT = false>
+__global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out, int ksplit_arg, float* __restrict__ kws) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int NB = 4, SP = 8;
@@ -773,11 +775,19 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
         const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
         lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
+    // split K (round 4, launches with fewer tiles than resident slots: small batches, the deep layers): ksplit consecutive blocks share
+    // a tile and each takes a run of the input-channel chunks; partial accumulators go to `kws`, conv_ksplit_epilogue_kernel sums them
+    // in a fixed order and runs the epilogue
+    // (KSPLIT is its own instantiation: the one-tile-per-block form has no register to spare for the run bookkeeping)
+    const int ksplit = KSPLIT ? ksplit_arg : 1;
+    const int ks_i = KSPLIT ? lin % ksplit : 0;
+    if (KSPLIT) lin /= ksplit;
     const int ntile = lin % ntiles, mtile = lin / ntiles;
     const int m0 = mtile * TMV, n0 = ntile * 32 * NB;      // band row 0 = source pixel m0 - 1 (+ dy*W)
     const int c0 = a.c0, c1 = a.c1;
     const int nchunks = (c0 + (a.in_mode == IN_CAT ? c1 : 0)) / 32;
     const int ktot = 9 * nchunks * 32;
+    const int cbeg = KSPLIT ? (ks_i * nchunks) / ksplit : 0, cend = KSPLIT ? ((ks_i + 1) * nchunks) / ksplit : nchunks;
     const unsigned in_pix = (unsigned)M;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * (unsigned)c0 * 4u);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * (unsigned)(a.in1 ? c1 : c0) * 4u);
@@ -845,6 +855,12 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     // (only the ConvLSTM cell state -- 16 registers -- is requested a main loop early; the 64 registers of a residual /
     // skip operand are loaded in the epilogue: the split fragments of a step already take 80)
     epi_setup<NB, LSTM, GROUPED>(a, m0 + idx - SHIFT, M, hw, n0, h, acc, pre, ec, lane_ok, LSTM);
+    if (KSPLIT && ks_i > 0) {      // the bias belongs to the first run only
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    }
 
     // ConvTranspose2d(k5, s2) as a 3x3 conv whose N is phase-major (model.cpp prep_tconv): a (tap, phase) pair the
     // transposed kernel does not connect has a zero weight block.  tap_use[t] = phases of THIS N tile that use tap t:
@@ -884,17 +900,17 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     // prologue: the zero row, band 0 and the first RING-1 weight tiles
     // (bare s_barrier below: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the ring)
     if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    issue_band(0, 0, 0, band_use(0));
-    issue_w(0, 0, 0, tap_use(0) != 0);
+    issue_band(cbeg, 0, 0, band_use(0));
+    issue_w(0, cbeg, 0, tap_use(0) != 0);
     if constexpr (RING == 3) {
-        issue_w(1, 0, 1, tap_use(1) != 0);
+        issue_w(1, cbeg, 1, tap_use(1) != 0);
         if constexpr (NBW == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
-    for (int c = 0; c < nchunks; ++c) {
-        const int pa = c & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1
+    for (int c = cbeg; c < cend; ++c) {
+        const int pa = (c - cbeg) & 1;        // parity of band index 3c + t/3 is (c + t/3) & 1 (c counted from the run's first chunk)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // ---- requests: weight tile of step s+2, and at the first tap of a band the NEXT band
@@ -902,7 +918,7 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
                 constexpr int D = RING - 1;
                 const int t2 = (t + D) % 9;
                 int c2 = c + (t + D) / 9;
-                if (c2 >= nchunks) c2 = nchunks - 1;                 // tail: harmless re-load into a free slot
+                if (c2 >= cend) c2 = cend - 1;                       // tail: harmless re-load into a free slot
                 // ring slot of step s = 9c + t: s % 3, or s & 1 = (c + t) & 1
                 const int slot2 = (RING == 3) ? (t + D) % 3 : (pa ^ ((t + D) & 1));
                 if (!(ablate & 2)) issue_w(t2, c2, slot2, tap_use(t2) != 0);
@@ -910,7 +926,7 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
             if (t % 3 == 0 && !(ablate & 2)) {
                 const int d2 = (t / 3 + 1) % 3;
                 int c2 = c + (t / 3 + 1) / 3;
-                if (c2 >= nchunks) c2 = nchunks - 1;
+                if (c2 >= cend) c2 = cend - 1;
                 issue_band(c2, d2, (pa ^ ((t / 3 + 1) & 1)), band_use(d2));
             }
             // ---- 12 MFMAs (8 f16 + 4 fp8) on band (c, t/3) rows r + t%3 and weight tile t%3 of the ring
@@ -958,9 +974,71 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
         }
     }
     if (ablate & 4) return;
+    if constexpr (KSPLIT) {      // partial accumulators, register order: [tile][run][wave][block * 4 + quad][lane] x 16 B
+        float4* o = (float4*)kws + ((((size_t)lin * ksplit + ks_i) * WM + wmi) * (NB * 4)) * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[(nb * 4 + q) * 64] = make_float4(acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+    } else {
+        if constexpr (!LSTM) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
+        epi_finish<NB, LSTM, GROUPED, true>(a, ec, n0, h, acc, pre, img_out);
+    }
+#endif
+}
+
+// Second half of a split-K launch of conv3x3_band_kernel: one block per tile, same lane -> (pixel, channel) mapping; the ksplit partial
+// accumulator sets are summed in run order (deterministic), then the shared epilogue runs as if the main loop had just ended.
+template <bool LSTM, bool GROUPED>
+__global__ __launch_bounds__(256, 2) void conv_ksplit_epilogue_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out, int ksplit, const float* __restrict__ kws) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int NB = 4, WM = 4, TM = 32 * WM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = a.hin * a.win, M = a.n * hw;
+    const int ntiles = a.cout / (32 * NB);
+    const int lin = blockIdx.x;
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;
+    const int r = lane & 31, h = lane >> 5;
+    f32x16 acc[NB], dummy[NB];
+    constexpr int PN = LSTM ? 1 : NB;
+    f32x16 pre[PN];
+    EpiCtx ec;
+    epi_setup<NB, LSTM, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n0, h, dummy, pre, ec, true, LSTM);      // (the bias sits in run 0's partials)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float4* o = (const float4*)kws + ((((size_t)lin * ksplit + s) * WM + wmi) * (NB * 4)) * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = o[(nb * 4 + q) * 64];
+                acc[nb][4 * q] += v.x; acc[nb][4 * q + 1] += v.y; acc[nb][4 * q + 2] += v.z; acc[nb][4 * q + 3] += v.w;
+            }
+    }
     if constexpr (!LSTM) epi_prefetch<NB, LSTM, GROUPED>(a, n0, h, pre, ec);
     epi_finish<NB, LSTM, GROUPED, true>(a, ec, n0, h, acc, pre, img_out);
 #endif
+}
+
+// per-stream workspace of the split-K launches (two streams -- reconstruction and evaluation -- may both run one at the same time)
+static float* ksplit_workspace(hipStream_t stream, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, std::pair<float*, size_t>> ws;
+    std::lock_guard<std::mutex> g(mu);
+    auto& e = ws[stream];
+    if (e.second < bytes) {
+        if (e.first) { (void)hipStreamSynchronize(stream); (void)hipFree(e.first); }
+        e.first = nullptr; e.second = 0;
+        if (hipMalloc((void**)&e.first, bytes) != hipSuccess) return nullptr;
+        e.second = bytes;
+    }
+    return e.first;
 }
 
 template <int WM, int RING, bool LSTM, bool GROUPED = false, bool OVL = false, int PHASES = 0>
@@ -969,8 +1047,33 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
     const int tmv = OVL ? 32 * WM - 2 : 32 * WM;
     const int mtiles = (M + tmv - 1) / tmv;
     const int total = mtiles * (a.cout / 128);
-    hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES>), dim3(total), dim3(64 * WM), 0, stream, d_args, img);
+    // split K when the launch leaves most of the 512 resident slots empty (small batches; the deep layers: a 346x260 sequence is 12
+    // 128-pixel tiles at the bottom of the UNet) and K is long enough to cut: runs of >= 1 input-channel chunk, at most 4, never more
+    // blocks than slots.  (A cost model that also split launches of 200-1000 tiles into more than one round measured slower: 1487 vs
+    // 1599 frames/s at one sequence, 4098 vs 4356 at eight -- the partial accumulators are 64 KB per block each way.)
+    int ks = 1;
+    if constexpr (WM == 4 && !OVL) {
+        static const int ks_max = getenv("EVR_KSPLIT") ? atoi(getenv("EVR_KSPLIT")) : 4;      // (0 / 1: never)
+        const int nchunks = (a.c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) / 32;
+        if (ks_max > 1 && total <= 192 && nchunks >= 2 && !a.pred_w) {
+            ks = 512 / total;
+            if (ks > nchunks) ks = nchunks;
+            if (ks > ks_max) ks = ks_max;
+            if (ks < 2) ks = 1;
+        }
+    }
+    float* kws = nullptr;
+    if (ks > 1) {
+        kws = ksplit_workspace(stream, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4));
+        if (!kws) ks = 1;
+    }
+    if (ks > 1) hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES, true>), dim3(total * ks), dim3(64 * WM), 0, stream, d_args, img, ks, kws);
+    else hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES, false>), dim3(total), dim3(64 * WM), 0, stream, d_args, img, 1, (float*)nullptr);
     EVR_LAUNCH_CHECK();
+    if (ks > 1) {
+        hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<LSTM, GROUPED>), dim3(total), dim3(256), 0, stream, d_args, img, ks, (const float*)kws);
+        EVR_LAUNCH_CHECK();
+    }
     return EVR_OK;
 }
 
