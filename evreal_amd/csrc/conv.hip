@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_epilogue_kernel(const Conv
     constexpr int NB = 4, WM = 4, TM = 32 * WM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wmi = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hw = a.hin * a.win, M = a.n * hw;
+    const int hw = a.hm * a.wm, M = a.n * hw;      // the GEMM's own pixel grid (= the input grid for the stride-1 band kernel, half of it for the k5 s2 form)
     const int ntiles = a.cout / (32 * NB);
     const int lin = blockIdx.x;
     const int ntile = lin % ntiles, mtile = lin / ntiles;
@@ -1832,8 +1832,8 @@ static int launch_wide(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
 // row pitch of two input rows -- loaded once and read by its dx taps at row offsets 0/1/2, exactly as in
 // conv3x3_band_kernel; the implicit GEMM re-fetches the A tile for all 25 taps (2.4x the L2 -> LDS bytes).
 // Weight tiles: 2-slot ring, requested one step ahead; counted vmcnt + bare s_barrier.
-template <int NB>
-__global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+template <int NB, bool KSPLIT = false>
+__global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out, int ksplit_arg, float* __restrict__ kws) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int WM = 4, SP = 8, TM = 32 * WM;
@@ -1857,6 +1857,10 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
         const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
         lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
     }
+    // (split K as in conv3x3_band_kernel: ksplit consecutive blocks share a tile, each walks a run of whole BANDS of the step program)
+    const int ksplit = KSPLIT ? ksplit_arg : 1;
+    const int ks_i = KSPLIT ? lin % ksplit : 0;
+    if (KSPLIT) lin /= ksplit;
     const int ntile = lin % ntiles, mtile = lin / ntiles;
     const int m0 = mtile * TM, n0 = ntile * 32 * NB;
     const int C = a.c0;
@@ -1919,6 +1923,12 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
     f32x16 pre[NB];
     EpiCtx ec;
     epi_setup<NB, false, false>(a, m0 + idx, M, hw, n0, h, acc, pre, ec, true, false);   // operands are loaded in the epilogue
+    if (KSPLIT && ks_i > 0) {      // the bias belongs to the first run only
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+    }
 
     unsigned vmask = 0;      // validity of the 9 neighbour blocks of this lane's output pixel
     {
@@ -1934,22 +1944,36 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
         }
     }
 
-    const int nsteps = a.prog_steps;
+    const int nsteps_all = a.prog_steps;
     const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
     auto kofs_of = [&](unsigned e) -> int { return (int)(((e & 15u) * (unsigned)nch2 + ((e >> 8) & 255u)) * 32u); };
+    // this block's steps [s_first, nsteps]: everything, or (KSPLIT) the run from the first band start at or after its share's
+    // beginning up to the step before the next run's
+    int s_first = 1, nsteps = nsteps_all;
+    if constexpr (KSPLIT) {
+        auto band_start = [&](int s) { while (s <= nsteps_all && !(entry(s) & 16u)) ++s; return s; };
+        s_first = band_start(1 + (ks_i * nsteps_all) / ksplit);
+        nsteps = (ks_i + 1 == ksplit) ? nsteps_all : band_start(1 + ((ks_i + 1) * nsteps_all) / ksplit) - 1;
+    }
     {
-        const unsigned e0 = entry(0), e1 = entry(1);
+        const unsigned e1 = entry(s_first);
         if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        issue_band((int)((e0 >> 16) & 1023u), (int)((e0 >> 26) & 3u) - 1, 0);
+        if (s_first == 1) {
+            const unsigned e0 = entry(0);
+            issue_band((int)((e0 >> 16) & 1023u), (int)((e0 >> 26) & 3u) - 1, 0);
+        } else {      // the run's first band, decoded from its own first step: K chunk cc = phase * (C / 32) + channel chunk, dy from the tap
+            const int cc = (int)((e1 >> 8) & 255u), nch = C / 32, phase = cc / nch;
+            issue_band((phase >> 1) | ((phase & 1) << 1) | ((cc - phase * nch) << 2), (int)(e1 & 15u) / 3 - 1, 0);
+        }
         issue_w(kofs_of(e1), 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     int abuf = 0;
-    for (int s = 1; s <= nsteps; ++s) {
+    for (int s = s_first; s <= nsteps; ++s) {
         const unsigned e = entry(s);
-        const int slot = (s - 1) & 1;
+        const int slot = (s - s_first) & 1;
         if (s < nsteps) issue_w(kofs_of(entry(s + 1)), slot ^ 1);
-        if ((e & 16u) && s > 1) abuf ^= 1;
+        if ((e & 16u) && s > s_first) abuf ^= 1;
         if (e & 32u) issue_band((int)((e >> 16) & 1023u), (int)((e >> 26) & 3u) - 1, abuf ^ 1);
         const int t = (int)(e & 15u);
         const int dxi = t - (t / 3) * 3;
@@ -1969,8 +1993,16 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
         if (e & 64u) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    epi_prefetch<NB, false, false>(a, n0, h, pre, ec);
-    epi_finish<NB, false, false, true>(a, ec, n0, h, acc, pre, img_out);
+    if constexpr (KSPLIT) {      // partial accumulators for conv_ksplit_epilogue_kernel (NB == 4)
+        float4* o = (float4*)kws + ((((size_t)lin * ksplit + ks_i) * WM + wmi) * (NB * 4)) * 64 + lane;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[(nb * 4 + q) * 64] = make_float4(acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]);
+    } else {
+        epi_prefetch<NB, false, false>(a, n0, h, pre, ec);
+        epi_finish<NB, false, false, true>(a, ec, n0, h, acc, pre, img_out);
+    }
 #endif
 }
 
@@ -1978,7 +2010,29 @@ template <int NB>
 static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
     const int total = ((M + 127) / 128) * (a.cout / (32 * NB));
-    hipLaunchKernelGGL((conv_band_prog_kernel<NB>), dim3(total), dim3(256), 0, stream, d_args, img);
+    int ks = 1;
+    if constexpr (NB == 4) {      // split K for under-filled launches (launch_band's rule; runs are whole bands of the step program)
+        static const int ks_max = getenv("EVR_KSPLIT") ? atoi(getenv("EVR_KSPLIT")) : 4;
+        const int nbands = a.prog_steps / 2;      // (>= 2 steps per band on average: an upper bound that keeps every run non-empty)
+        if (ks_max > 1 && total <= 192 && nbands >= 4) {
+            ks = 512 / total;
+            if (ks > nbands / 2) ks = nbands / 2;
+            if (ks > ks_max) ks = ks_max;
+            if (ks < 2) ks = 1;
+        }
+    }
+    float* kws = nullptr;
+    if (ks > 1) { kws = ksplit_workspace(stream, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4)); if (!kws) ks = 1; }
+    if constexpr (NB == 4) {
+        if (ks > 1) {
+            hipLaunchKernelGGL((conv_band_prog_kernel<NB, true>), dim3(total * ks), dim3(256), 0, stream, d_args, img, ks, kws);
+            EVR_LAUNCH_CHECK();
+            hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<false, false>), dim3(total), dim3(256), 0, stream, d_args, img, ks, (const float*)kws);
+            EVR_LAUNCH_CHECK();
+            return EVR_OK;
+        }
+    }
+    hipLaunchKernelGGL((conv_band_prog_kernel<NB, false>), dim3(total), dim3(256), 0, stream, d_args, img, 1, (float*)nullptr);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }
