@@ -64,3 +64,28 @@ def test_out_of_sensor_coordinates_raise_before_upload(tmp_path):
                        voxel_method={'method': 'k_events', 'k': 500, 'sliding_window_w': 0})
     with pytest.raises(IndexError, match='outside the 32x20 sensor'):
         ds.upload()
+
+
+def test_validation_covers_the_windows_events_only(tmp_path):
+    """the reference fails from index_put_ only on a window it actually voxelises; events no window of this dataset object
+    touches (here: beyond max_length) must not refuse the sequence.  The polarity column is checked in one pass, and the validated
+    columns are handed out once more from the cache (eval's grouping validates before the batch that uploads is formed)."""
+    from evreal_amd.dataset import MemMapDataset
+    w = synth.write_sequence(str(tmp_path / 'a'), 1, 5000, 1.0e5, 32, 24, 100.0)
+    xy = w['xy'].copy()
+    xy[4000:, 0] = 40                                             # beyond the 32-wide sensor, in the last 1000 events only
+    np.save(tmp_path / 'a' / 'events_xy.npy', xy)
+    vm = {'method': 'k_events', 'k': 500, 'sliding_window_w': 0}
+    with pytest.raises(IndexError, match='outside the 32x24 sensor'):
+        MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm).host_events()
+    ds = MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7)      # length = min(L, max_length + 1) (dataset.py:190-191): windows cover events [0, 4000)
+    assert len(ds) == 8
+    cols = ds.host_events(keep=True)
+    assert cols[0].dtype == np.int16 and cols[1].dtype == np.float64 and cols[2].dtype == np.uint8 and len(cols[1]) == 5000
+    assert ds.host_events() is cols and ds._host_cols is None     # handed over once, then released
+    np.save(tmp_path / 'a' / 'events_p.npy', (w['p'].astype(np.int8) * 2 - 1))              # -1 / +1 instead of 0 / 1
+    with pytest.raises(ValueError, match='must hold 0/1'):
+        MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7).host_events()
+    np.save(tmp_path / 'a' / 'events_p.npy', np.full(5000, 2, np.uint8))
+    with pytest.raises(ValueError, match='must hold 0/1'):
+        MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7).host_events()
