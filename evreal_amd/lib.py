@@ -101,6 +101,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel carries its own libamdhip64, and the process must end up with ONE HIP runtime -- loaded the other way
+    # round (this library before torch, e.g. __graft_entry__.build() followed by smoke() in one process) the library's runtime sees
+    # no device (hipGetDevice: error 100) while torch's does
+    import torch  # noqa: F401
     path = os.environ.get('EVR_LIB') or LIB_PATH      # (EVR_LIB: another BUILD of this library -- timing-ablation variants, tools/ablate_wide.sh)
     if not os.path.exists(path):
         raise EvrError(f"{path} not found: build it with `python -m evreal_amd.build` "
