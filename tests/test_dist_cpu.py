@@ -130,3 +130,37 @@ def test_checkpoint_config_parser_shim(tmp_path):
     if os.path.exists(real):
         ck = _load_checkpoint(real)
         assert ck['config']['arch']['type'] == 'FireNet' and 'num_bins' in ck['config']['arch']['args']
+
+
+def _cost_worker(rank, world, port, root, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from evreal_amd import eval as ev
+    if rank == 1:       # a rank-local read failure (NFS hiccup, permissions): this rank could not have computed the costs itself
+        def boom(*a, **k):
+            raise OSError("simulated rank-local failure")
+        ev.MemMapDataset = boom
+    vm = {'method': 'k_events', 'k': 500, 'sliding_window_w': 0}
+    seqs = [{'name': n, 'sequence_path': os.path.join(root, n), 'dataset_kwargs': {'num_bins': 5, 'voxel_method': vm}} for n in ('a', 'b', 'c')]
+    costs = ev.sequence_costs(seqs)
+    q.put((rank, costs, assign_sequences(costs, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sequence_costs_come_from_rank_0(tmp_path):
+    """every rank must partition the sequences by the SAME cost vector; it is computed on rank 0 and broadcast, so a
+    rank that cannot read the files still derives the same plan (and fails later, loudly, on the sequences it owns)."""
+    from evreal_amd import synth
+    for n, ev_count in (('a', 5000), ('b', 20000), ('c', 9000)):
+        synth.write_sequence(str(tmp_path / n), 7, ev_count, 1.0e5, 32, 24, 100.0)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cost_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == [10 * 32 * 32, 40 * 32 * 32, 18 * 32 * 32]      # windows x padded pixels, from rank 0's files
+    assert res[0][2] == res[1][2] and sorted(sum(res[0][2], [])) == [0, 1, 2]
