@@ -1300,7 +1300,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     constexpr int WM = 4, SP = 4, TM = 32 * WM;         // SP: 16-B slots per 64-B row (hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15)
-    constexpr int A_ROWS = TM + 16, A_PIECES = A_ROWS / 16, A_F4 = A_ROWS * SP;      // a DMA piece = 16 rows
+    // a band = TM + 2 pixel rows of 64 B: eight 16-row DMA pieces and a ninth of which only two rows (8 lanes) are requested -- a
+    // whole ninth piece made a two-buffer block of the two-source layers 55.4 KB, 1.6 KB too much for a third block per CU
+    constexpr int A_ROWS = TM + 2, A_PIECES = (A_ROWS + 15) / 16, A_F4 = A_ROWS * SP;
     constexpr int W_ROWS = 32 * NB, W_F4 = W_ROWS * SP, W_PIECES = W_ROWS / 16;      // one (tap, source) weight tile
     constexpr int MAX_TC = 18;                           // 9 taps x 2 sources
     // Round 4: a RING of NBUF band buffers, requests DIST bands ahead of the one being multiplied (across tile boundaries).  These
@@ -1357,8 +1359,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c16_kernel(const ConvArgs* __r
             unsigned voff = OOB_OFFSET;
             if ((unsigned)pix < in_pix) voff = ((unsigned)pix * 16u + (unsigned)(((lane & 3) ^ swz<16>(row)) * 4)) * 4u;
             lds_ptr_t dst = (lds_ptr_t)&lds[buf * A_F4 + p * 64];
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            if (p * 16 + 16 <= A_ROWS || lane < (A_ROWS - p * 16) * 4) {      // (the last piece: its two real rows only -- the rest would land in the next buffer)
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
         }
     };
     const int nbands = 3 * nsrc;
@@ -1458,10 +1462,12 @@ static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t str
     const bool half_w = NB == 1 && a.n_valid <= 16;
     static const int out_nbuf = [] { const char* e = getenv("EVR_C16_OUT"); return e ? atoi(e) : 2; }();
     static const int out_blocks = [] { const char* e = getenv("EVR_C16_OUT"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 3; }();
-    const int nbuf = nsrc == 1 ? 2 : (half_w ? (out_nbuf == 4 ? 4 : 2) : 4);
+    static const int zr_nbuf = [] { const char* e = getenv("EVR_C16_ZR"); return e ? atoi(e) : 2; }();      // (the z|r gate launches: <nbuf>,<blocks>)
+    static const int zr_blocks = [] { const char* e = getenv("EVR_C16_ZR"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 3; }();
+    const int nbuf = nsrc == 1 ? 2 : (half_w ? (out_nbuf == 4 ? 4 : 2) : (zr_nbuf == 4 ? 4 : 2));
     const int wrows = half_w ? 16 : 32 * NB;
-    const size_t lds_bytes = ((size_t)nbuf * (128 + 16) * 4 + (size_t)9 * nsrc * wrows * 4 + 4) * sizeof(float4);
-    int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : (half_w ? (out_blocks > 0 ? out_blocks : 3) : 2);
+    const size_t lds_bytes = ((size_t)nbuf * (128 + 2) * 4 + (size_t)9 * nsrc * wrows * 4 + 4) * sizeof(float4);
+    int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : (half_w ? (out_blocks > 0 ? out_blocks : 3) : (zr_blocks > 0 ? zr_blocks : 3));
     int per_n = 256 * per_cu;                             // persistent: the resident blocks walk the M tiles
     if (per_n > mtiles) per_n = mtiles;
     static std::atomic<unsigned> attr_done{0};
