@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict
 // runs per lane (C <= 512).
 struct ScoreArgs { const float* feat[5]; const float* lin[5]; int hw[5], C[5], packed[5]; };
 // (one launch for the five layers -- grid.z = layer -- so their small grids share the chip instead of queueing one by one)
-__global__ __launch_bounds__(256) void lpips_score_kernel(const ScoreArgs sa, int n, double* __restrict__ partials_all, int blocks_per_img) {
+__global__ __launch_bounds__(256) void lpips_score_kernel(const ScoreArgs sa, int n, double* __restrict__ partials_all, int blocks_per_img, int layer0) {
     __shared__ double red[4];
-    const int layer = blockIdx.z;
+    const int layer = layer0 + blockIdx.z;
     const float* __restrict__ feat = sa.feat[layer]; const float* __restrict__ lin = sa.lin[layer];
     const int hw = sa.hw[layer], C = sa.C[layer], packed = sa.packed[layer];
     double* __restrict__ partials = partials_all + (size_t)layer * n * blocks_per_img;
@@ -527,16 +527,28 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
         EVR_LAUNCH_CHECK();
         return EVR_OK;
     };
-    if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1], 0))) return rc;
-    if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
-    if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2], pk))) return rc;
-    for (int i = 1; i < 4; ++i)
-        if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
+    // The layer scores read both images' features again: scored right behind the layer that wrote them (EVR_LPIPS_SCORE_SPLIT, default
+    // 1) they come from the Infinity Cache -- 446 MB per 64-frame step that one launch at the end fetched from HBM (conv1's 180 MB of
+    // features are long evicted by then).  Same partial sums, same final reduction: bit-identical scores.
+    static const int score_split = getenv("EVR_LPIPS_SCORE_SPLIT") ? atoi(getenv("EVR_LPIPS_SCORE_SPLIT")) : 1;
     const int C[5] = {64, 192, 384, 256, 256};
     ScoreArgs sa;
     for (int l = 0; l < 5; ++l) { sa.feat[l] = m->feat[l]; sa.lin[l] = m->d_lin[l]; sa.hw[l] = m->h[l] * m->w[l]; sa.C[l] = C[l]; sa.packed[l] = l > 0 ? pk : 0; }
-    hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n, 5), dim3(256), 0, stream, sa, n, m->partials, SCORE_BLOCKS);
-    EVR_LAUNCH_CHECK();
+    auto score = [&](int l0, int nl) -> int {
+        hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n, nl), dim3(256), 0, stream, sa, n, m->partials, SCORE_BLOCKS, l0);
+        EVR_LAUNCH_CHECK();
+        return EVR_OK;
+    };
+    if (score_split && (rc = score(0, 1))) return rc;
+    if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1], 0))) return rc;
+    if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
+    if (score_split && (rc = score(1, 1))) return rc;
+    if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2], pk))) return rc;
+    for (int i = 1; i < 4; ++i) {
+        if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
+        if (score_split && (rc = score(i + 1, 1))) return rc;
+    }
+    if (!score_split && (rc = score(0, 5))) return rc;
     hipLaunchKernelGGL(lpips_final_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, m->partials, out, SCORE_BLOCKS, 5, n, m->d_hw);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
