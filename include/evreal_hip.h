@@ -38,7 +38,9 @@ enum evr_status {
 
 /* Message for the last failure on this thread ("" if none). */
 const char* evr_last_error(void);
-/* ABI version (major*1000 + minor). */
+/* ABI version (major*1000 + minor).  1001 (round 4): evr_percentile_normalize rejects a NULL workspace (size it with
+ * evr_percentile_normalize_workspace_bytes); evr_model_arith reports the mode the convolutions actually run (FireNet's 16-channel
+ * layers: h3 whatever EVR_ARITH says). */
 int evr_version(void);
 /* Device facts used by bench.py's roofline block: CU count, clock (MHz), name. */
 int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_t name_len);

@@ -17,7 +17,7 @@ def built():
 def test_library_builds_and_loads(built):
     from evreal_amd import lib
     l = lib.load()
-    assert l.evr_version() >= 1000
+    assert l.evr_version() >= 1001      # (1001: percentile workspace contract, effective evr_model_arith)
     assert l.evr_last_error() is not None
 
 
