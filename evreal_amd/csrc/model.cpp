@@ -1496,7 +1496,7 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
         for (int k = 0; k < t.ndim; ++k) t.shape[k] = tensors[i].shape[k];
         m->sd[tensors[i].name] = t;
     }
-    // mx6 (f16 + MX-fp6, P6 tensors; opt-in): P6 groups carry their own scale and are written WHOLE -- by matrix-core epilogues
+    // mx6 (f16 + MX-fp6, P6 tensors; the default): P6 groups carry their own scale and are written WHOLE -- by matrix-core epilogues
     // and by the bilinear upsampling kernel's group form.  That covers UNetRecurrent with ConvLSTM blocks, transposed-conv or
     // upsample-conv decoders, BatchNorm or no norm, and the 5-bin k5 32-channel head: the E2VID / E2VID+ / SSL-E2VID checkpoints'
     // layouts (BASELINE configurations 2 and 5).  Layouts with 4-channel producers of packed tensors (the dynamic decoder,
@@ -1743,7 +1743,7 @@ extern "C" int evr_model_arith(const evr_model* m) {
 
 // Range guard of the packed activation formats (packed.h sat_note): how many output runs (4 or 16 channels of one pixel)
 // of the matrix-core producers left the format's exact range since the counters were last cleared, and in which layer most.
-// PACKED (EVR_ARITH=mx) keeps only the f16 half of such values (2^-12 relative); H2 (the default h3 arithmetic) CLAMPS them at
+// PACKED (default arithmetic) keeps only the f16 half of such values (2^-12 relative); H2 (EVR_ARITH=h3) CLAMPS them at
 // +-4094.  Synchronises the stream.  Zero means the arithmetic's error analysis held for every frame so far.
 extern "C" int evr_model_saturation(evr_model* m, int64_t* runs_host, char* worst_layer, size_t worst_len, int clear, evr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
