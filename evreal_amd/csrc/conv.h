@@ -104,7 +104,12 @@ struct ConvArgs {
     int band_lds_pad;         // conv_bandk_kernel: extra dynamic LDS bytes per block (caps the blocks per CU; host-side only)
     int no_band5;             // keep a 5x5 stride-1 convolution on the implicit GEMM (LPIPS conv2: on the evaluation stream the band form's
                               //   three 51-KB blocks per CU crowd the reconstruction stream's work-groups out: 6.0k vs 6.8k frames/s)
+    float* ksplit_ws;         // split-K partial sums (conv.hip launch_band / launch_band_prog): KSPLIT_WS_BYTES of device memory owned by the
+                              //   handle whose launches use it (evr_model per shape, evr_lpips per plan) -- launches of ONE handle are ordered
+                              //   on one stream, so they can share it; null: never split.  Host-side only.
 };
+// A split launch has at most 512 blocks (one per resident slot) of 64 KB of partial accumulators each
+constexpr size_t KSPLIT_WS_BYTES = (size_t)512 * 4 * 16 * 64 * 16;
 
 // Division of n < 2^31 by an invariant d >= 1 as (umulhi(n, mul) + n) >> sh (Granlund-Montgomery, round-up form):
 // sh = ceil(log2 d), mul = floor(2^32 (2^sh - d) / d) + 1 (0 for powers of two).  A run-time v_udiv costs ~35 VALU

@@ -48,8 +48,6 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <unordered_map>
 
 // This file is compiled once per split arithmetic (build.py): EVR_ARITH = 2 -- f16 + MX-fp8 on PACKED tensors, plus the
 // exact-fp32 kernels -- EVR_ARITH = 3 -- three f16 products on H2 tensors -- and EVR_ARITH = 4 -- f16 + MX-fp6 on P6 tensors, the
@@ -1026,20 +1024,10 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_epilogue_kernel(const Conv
 #endif
 }
 
-// per-stream workspace of the split-K launches (two streams -- reconstruction and evaluation -- may both run one at the same time)
-static float* ksplit_workspace(hipStream_t stream, size_t bytes) {
-    static std::mutex mu;
-    static std::unordered_map<hipStream_t, std::pair<float*, size_t>> ws;
-    std::lock_guard<std::mutex> g(mu);
-    auto& e = ws[stream];
-    if (e.second < bytes) {
-        if (e.first) { (void)hipStreamSynchronize(stream); (void)hipFree(e.first); }
-        e.first = nullptr; e.second = 0;
-        if (hipMalloc((void**)&e.first, bytes) != hipSuccess) return nullptr;
-        e.second = bytes;
-    }
-    return e.first;
-}
+// workspace of the split-K launches: ConvArgs::ksplit_ws, KSPLIT_WS_BYTES owned by the handle (model / LPIPS) whose plan this is --
+// allocated with the plan, freed with it, never touched in the launch path (no hipMalloc / synchronisation here: a step can be
+// captured into a hipGraph, and two devices or two handles never share partial sums)
+static float* ksplit_workspace(const ConvArgs& a, size_t bytes) { return (a.ksplit_ws && bytes <= KSPLIT_WS_BYTES) ? a.ksplit_ws : nullptr; }
 
 template <int WM, int RING, bool LSTM, bool GROUPED = false, bool OVL = false, int PHASES = 0>
 static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
@@ -1064,7 +1052,7 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
     }
     float* kws = nullptr;
     if (ks > 1) {
-        kws = ksplit_workspace(stream, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4));
+        kws = ksplit_workspace(a, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4));
         if (!kws) ks = 1;
     }
     if (ks > 1) hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES, true>), dim3(total * ks), dim3(64 * WM), 0, stream, d_args, img, ks, kws);
@@ -1456,9 +1444,10 @@ static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t str
     const int mtiles = (M + 127) / 128, ntiles_n = a.cout / (32 * NB);
     const int nsrc = (a.in_mode == IN_CAT && a.c1) ? 2 : 1;
     static const int c16_blocks = getenv("EVR_C16_BLOCKS") ? atoi(getenv("EVR_C16_BLOCKS")) : 3;      // (A/B: blocks per CU of the one-source form)
-    // one-source layers (residual convolutions): two band buffers, three blocks per CU (measured 3 > 4 > 2: 157 / 183 / 189 us);
-    // two-source layers with 32 real columns (ConvGRU z|r gates): a ring of four, two blocks; with <= 16 real columns (the ConvGRU
-    // candidate convolution: half the weight rows) EVR_C16_OUT=<nbuf>,<blocks> (default 2,3)
+    // SHIPPED DEFAULTS: two band buffers and three blocks per CU for every layer.  One-source layers (residual convolutions): measured
+    // 3 > 4 > 2 blocks (157 / 183 / 189 us); two-source layers (ConvGRU z|r gates, 32 real columns; the candidate convolution, <= 16
+    // real columns = half the weight rows): three blocks with two buffers beat the ring of four at two blocks (273 vs 312-320 us,
+    // 265 vs 308-381).  EVR_C16_ZR / EVR_C16_OUT=<nbuf>,<blocks> select the ring of four (nbuf = 4, 70 KB) for A/B runs.
     const bool half_w = NB == 1 && a.n_valid <= 16;
     static const int out_nbuf = [] { const char* e = getenv("EVR_C16_OUT"); return e ? atoi(e) : 2; }();
     static const int out_blocks = [] { const char* e = getenv("EVR_C16_OUT"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 3; }();
@@ -1470,11 +1459,14 @@ static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t str
     int per_cu = nsrc == 1 ? (c16_blocks > 0 ? c16_blocks : 3) : (half_w ? (out_blocks > 0 ? out_blocks : 3) : (zr_blocks > 0 ? zr_blocks : 3));
     int per_n = 256 * per_cu;                             // persistent: the resident blocks walk the M tiles
     if (per_n > mtiles) per_n = mtiles;
-    static std::atomic<unsigned> attr_done{0};
-    if (!attr_done.load(std::memory_order_relaxed)) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done.store(1, std::memory_order_relaxed);
+    // the LDS-size attribute is per device (the ring-of-four forms need 70 KB): remember it per (device, NB)
+    static std::atomic<unsigned> attr_done[64];
+    int dev = 0;
+    EVR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_relaxed)) {
+        EVR_HIP(hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EVR_HIP(hipFuncSetAttribute((const void*)conv3x3_c16_kernel<NB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr_done[dev].store(1, std::memory_order_relaxed);
     }
     if (nbuf == 2) hipLaunchKernelGGL((conv3x3_c16_kernel<NB, 2>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), lds_bytes, stream, d_args, img);
     else hipLaunchKernelGGL((conv3x3_c16_kernel<NB, 4>), dim3((unsigned)(per_n * ntiles_n)), dim3(256), lds_bytes, stream, d_args, img);
@@ -2028,7 +2020,7 @@ static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream
         }
     }
     float* kws = nullptr;
-    if (ks > 1) { kws = ksplit_workspace(stream, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4)); if (!kws) ks = 1; }
+    if (ks > 1) { kws = ksplit_workspace(a, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4)); if (!kws) ks = 1; }
     if constexpr (NB == 4) {
         if (ks > 1) {
             hipLaunchKernelGGL((conv_band_prog_kernel<NB, true>), dim3(total * ks), dim3(256), 0, stream, d_args, img, ks, kws);

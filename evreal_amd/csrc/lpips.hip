@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
 #include "conv.h"
 #include "packed.h"
 
@@ -488,6 +489,13 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
     }
+    {   // split-K partial sums of conv3..conv5 at small batches (conv.h KSPLIT_WS_BYTES): this handle's own -- it runs on the evaluation
+        // stream beside a model's launches
+        float* kws = nullptr;
+        EVR_HIP(hipMalloc((void**)&kws, KSPLIT_WS_BYTES));
+        m->allocs.push_back((void*)kws);
+        for (int i = 0; i < 4; ++i) m->args[i].ksplit_ws = kws;
+    }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));
     m->allocs.push_back((void*)m->d_args);
     EVR_HIP(hipMemcpy(m->d_args, m->args, 4 * sizeof(ConvArgs), hipMemcpyHostToDevice));
@@ -505,11 +513,13 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     c1.img = img; c1.ref = ref; c1.n = n; c1.H = H; c1.W = W; c1.h1 = m->h[0]; c1.w1 = m->w[0]; c1.clip = clip;
     c1.wg = m->d_wg; c1.wb = m->d_wb; c1.bias = m->d_b1; c1.bias_in = m->d_b1in; c1.out = m->feat[0];
     c1.wfrag = (const unsigned*)m->d_wfrag1; c1.wbsum = m->d_wbsum;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned> attr_done[64];      // the LDS-size attribute is per device
+    int dev = 0;
+    EVR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_relaxed)) {
         EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EVR_HIP(hipFuncSetAttribute((const void*)lpips_conv1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        if (dev >= 0 && dev < 64) attr_done[dev].store(1, std::memory_order_relaxed);
     }
     static const bool conv1_valu = getenv("EVR_LPIPS_CONV1_VALU") != nullptr;      // A/B switch: the direct VALU kernel in split mode too
     if (m->d_wfrag1 && !conv1_valu) {

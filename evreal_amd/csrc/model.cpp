@@ -358,7 +358,7 @@ int finish_conv(evr_model* m, Conv& c) {
     // run the three-f16-product arithmetic on UNPADDED tensors (conv.hip conv3x3_c16_kernel) whatever the mode of the 32-channel
     // layers -- fp32-grade (the goldens hold 1e-5), and no longer the 1/16-rate fp32 MFMA.  EVR_FIRENET_H3=0: the exact-fp32 path.
     static const bool fire_h3 = getenv("EVR_FIRENET_H3") ? atoi(getenv("EVR_FIRENET_H3")) != 0 : true;
-    if (c.kc == 16 && arith_mode() != 0 && fire_h3 && c.k == 3 && c.stride == 1 && !c.transposed && c.cin0 == 16 && (c.cin1 == 0 || c.cin1 == 16) &&
+    if (c.kc == 16 && m->arith != 0 && fire_h3 && c.k == 3 && c.stride == 1 && !c.transposed && c.cin0 == 16 && (c.cin1 == 0 || c.cin1 == 16) &&
         (m->desc.arch == EVR_ARCH_FIRENET_LEGACY || m->desc.arch == EVR_ARCH_FIRENET) && c.n_gemm == 32)
         c.x3 = 3;
     if (c.x3 && c.k == 5 && c.stride == 2 && !c.transposed && c.cin1 == 0 && c.n_gemm % 64 == 0 && 25 * (c.cin0 / 32) < BAND_PROG_MAX - 2) {
@@ -488,7 +488,7 @@ int prep_head_pred(evr_model* m, const std::string& head_prefix, const std::stri
     for (int c = 0; c < C; ++c) m->pred_w[c] = (float)((double)w->data[c] * ap.scale[0]);
     m->pred_b = (float)ap.shift[0];
     if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
-    if (arith_mode() != 0 && B == 5 && k == 5 && C == 32) {
+    if (m->arith != 0 && B == 5 && k == 5 && C == 32) {
         std::vector<unsigned> wf;
         m->head_wfrag_e = head_pack_wfrag(m->head_w.data(), B, wf);
         EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -610,7 +610,7 @@ int build_firenet(evr_model* m) {
     const std::string pred = legacy ? "net.pred" : "pred";
     static const bool pad32 = getenv("EVR_FIRENET_PAD32") ? atoi(getenv("EVR_FIRENET_PAD32")) != 0 : false;
     m->fire_C = C;
-    if (C == 16 && arith_mode() != 0 && pad32) {
+    if (C == 16 && m->arith != 0 && pad32) {
         firenet_pad_state_dict(m, head, pred);
         C = m->fire_C = 32;
     }
@@ -685,7 +685,7 @@ int build_spade(evr_model* m) {
         }
         if ((rc = upload(m->head_w, &m->d_head_w))) return rc;
         if ((rc = upload(m->head_b, &m->d_head_b))) return rc;
-        if (arith_mode() != 0) {
+        if (m->arith != 0) {
             std::vector<unsigned> wf;
             m->head_wfrag_e = head_pack_wfrag(m->head_w.data(), 5, wf);
             EVR_HIP(hipMalloc((void**)&m->d_head_wfrag, wf.size() * sizeof(unsigned)));
@@ -1502,6 +1502,13 @@ extern "C" int evr_model_create(const evr_model_desc* desc, const evr_tensor* te
     // layouts (BASELINE configurations 2 and 5).  Layouts with 4-channel producers of packed tensors (the dynamic decoder,
     // InstanceNorm, ConvGRU's epilogue, SPADE, ET-Net, FireNet) keep the f16 + MX-fp8 mode.
     m->arith = arith_mode();
+    // per-model override (evr_model_desc::reserved[2] = mode + 1): the drop-in loop builds an exact-fp32 twin of a model whose
+    // activations left the split format's range and re-runs the sequence on it (evreal_amd/eval.py), in the same process
+    if (desc->reserved[2] != 0) {
+        const int want = desc->reserved[2] - 1;
+        if (want != 0 && want != 2 && want != 3 && want != 4) { delete m; set_error("evr_model_create: reserved[2] = %d is not an arithmetic mode + 1", desc->reserved[2]); return EVR_ERR_INVALID; }
+        m->arith = want;
+    }
     if (m->arith == 4) {
         const evr_model_desc& d = *desc;
         const bool ok = d.arch == EVR_ARCH_UNET_RECURRENT && d.recurrent_block == EVR_REC_CONVLSTM && !(d.reserved[1] & 1) &&
@@ -1570,6 +1577,13 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     if (rc) { m->release_shape(); return rc; }
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)(fire_padded ? m->desc.base_num_channels : m->pred_c);
+    {   // split-K partial sums of this model's under-filled launches (conv.h KSPLIT_WS_BYTES): owned by the shape -- one device, one
+        // stream at a time -- freed with it, never zeroed (every split launch writes what its epilogue kernel reads)
+        float* kws = nullptr;
+        EVR_HIP(hipMalloc((void**)&kws, KSPLIT_WS_BYTES));
+        m->shape_consts.push_back(kws);
+        for (auto& c : m->convs) { c.args[0].ksplit_ws = kws; c.args[1].ksplit_ws = kws; }
+    }
     // upload the launch plans
     std::vector<ConvArgs> all;
     for (auto& c : m->convs) { c.arg_slot = (int)all.size(); all.push_back(c.args[0]); all.push_back(c.args[1]); }
@@ -1756,6 +1770,19 @@ extern "C" int evr_model_saturation(evr_model* m, int64_t* runs_host, char* wors
     for (size_t i = 0; i < h.size(); ++i) { total += h[i]; if (h[i] > h[worst]) worst = i; }
     *runs_host = total;
     if (worst_layer && worst_len) snprintf(worst_layer, worst_len, "%s", total == 0 ? "" : (worst < m->convs.size() ? m->convs[worst].name.c_str() : "head"));
+    return EVR_OK;
+}
+
+// The same counters without a host synchronisation: an asynchronous copy on `stream` into caller-owned (pinned) host memory; the
+// caller sums them once an event recorded behind this call has completed.  How the drop-in frame loop polls every chunk of frames
+// before it books the chunk's scores and files, without stalling its two-deep pipeline (evreal_amd/eval.py).
+extern "C" int evr_model_saturation_async(evr_model* m, unsigned* counters_host, int max_counters, int* n_counters, evr_stream_t stream_) {
+    EVR_REQUIRE(m && n_counters, "evr_model_saturation_async: null argument");
+    const int n = (int)m->convs.size() + 1;
+    *n_counters = n;
+    if (!counters_host) return EVR_OK;           // (size query)
+    EVR_REQUIRE(max_counters >= n, "evr_model_saturation_async: %d counters, room for %d", n, max_counters);
+    EVR_HIP(hipMemcpyAsync(counters_host, m->d_sat, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     return EVR_OK;
 }
 

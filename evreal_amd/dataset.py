@@ -259,7 +259,17 @@ class MemMapDataset:
         # dataset.py:227 computes p*2-1 from {0,1}; a file that stores -1/+1 (or anything else) would silently become
         # 255 -> weight 509 after a uint8 cast
         # (one max / min pass: np.isin over millions of events was a third of a short call's set-up)
-        if pol.size and ((pol.max() > 1) if pol.dtype.kind in 'ub' else (pol.max() > 1 or pol.min() < 0 or pol.dtype.kind not in 'iu')):
+        # (a float file holding exactly 0.0 / 1.0 is accepted, as the reference's p.astype(float32)*2-1 accepts it)
+        if pol.size:
+            if pol.dtype.kind in 'ub':
+                bad_pol = pol.max() > 1
+            elif pol.dtype.kind == 'i':
+                bad_pol = pol.max() > 1 or pol.min() < 0
+            elif pol.dtype.kind == 'f':
+                bad_pol = not bool(((pol == 0) | (pol == 1)).all())
+            else:
+                bad_pol = True
+        if pol.size and bad_pol:
             raise ValueError(f"{self.data_path}: events_p.npy must hold 0/1 (or bool) polarities, found values "
                              f"{np.unique(pol)[:6].tolist()}")
         cols = (xy.astype(np.int16), np.array(fh["t"], dtype=np.float64), pol.astype(np.uint8))

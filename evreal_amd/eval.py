@@ -111,8 +111,13 @@ _MODEL_CACHE = OrderedDict()      # (method, checkpoint identity, arithmetic swi
 
 
 def _model_cache_key(model_name, checkpoint_path):
+    from . import lib as _lib
+    _lib.require_gpu()          # (EvrError on a machine without a GPU, before torch is asked for its current device)
     st = os.stat(checkpoint_path)
-    switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('EVR_')))     # every kernel / arithmetic switch is read at create time
+    # EVR_ARITH / EVR_FP32 / EVR_FIRENET_* are read when a model is created, so they belong in the key.  Most other EVR_* switches
+    # (EVR_KSPLIT, EVR_C16_*, EVR_WIDE*, EVR_LPIPS_*) are function-local statics of the library, read ONCE PER PROCESS: changing
+    # them inside a process gives a new cache entry that still runs the old setting -- set them before the first call.
+    switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('EVR_')))
     return (model_name, os.path.abspath(checkpoint_path), st.st_mtime_ns, st.st_size, torch.cuda.current_device(), switches)
 
 
@@ -129,7 +134,8 @@ def get_model_from_checkpoint_path(model_name, checkpoint_path):
         model = _build_model(model_name, checkpoint_path)
         _MODEL_CACHE[key] = model
         while len(_MODEL_CACHE) > 4:
-            _MODEL_CACHE.popitem(last=False)
+            _, old = _MODEL_CACHE.popitem(last=False)
+            old.destroy()       # its HBM (weights, activations and state of the largest batch it ran) goes back now, not at some later GC
     else:
         _MODEL_CACHE.move_to_end(key)
     return model
@@ -196,6 +202,24 @@ def _plan_items(ds, tb, sequence, infer_all):
     return todo, bad, idx
 
 
+class _Saturated(Exception):
+    """Activations of the running chunk left the split arithmetic's exact range (evr_model_saturation): nothing of it is booked."""
+
+
+def _rerun_exact(model, trackers, names):
+    """Saturation must not change results (the reference computes in fp32 throughout, model/submodules.py:227-245, and has no range
+    limit): drain the GPU, drop what the first pass produced -- its trackers are closed, and the re-run's trackers truncate every
+    file they own when they are created -- say so, and hand back the model's exact-fp32 twin (the library's fp32-MFMA HIP kernels
+    on PLAIN tensors; never the oracle, never a CPU path)."""
+    torch.cuda.synchronize()
+    n, layer = model.saturation(clear=True)
+    for t in trackers:
+        t.discard()
+    print(f"[evreal_amd.eval] {n} activation runs of {names} left the exact range of the '{model.arith}' split format (most in layer "
+          f"'{layer}'): re-running in exact fp32 on the GPU (the library's fp32 kernels); no score, image or line of the first pass is kept")
+    return model.exact_twin()
+
+
 def eval_method_on_sequence(dataset_name, eval_config, method_name, model, method_config, sequence, metrics):
     """eval.py:189-246.  Grayscale evaluation is the one-slot case of eval_method_on_sequences (same pipelined chunk loop);
     colour evaluation (ColorNet, eval.py:222-232) keeps its own frame loop: no outer pad/crop, no metrics."""
@@ -203,6 +227,16 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
         return eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, [sequence], metrics)[0]
     ds = open_sequence(sequence)
     tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
+    try:
+        return _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequence)
+    except _Saturated:
+        exact = _rerun_exact(model, [tracker], sequence['name'])
+        tracker = get_eval_metrics_tracker(dataset_name, eval_config, method_name, sequence, metrics)
+        return _eval_color_sequence(ds, tracker, eval_config, exact, method_config, sequence)
+
+
+def _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequence):
+    guard = hasattr(model, 'saturation') and getattr(model, 'arith', 'fp32') != 'fp32'
     model.reset_states()
     infer_all = eval_config.get('eval_infer_all', False)
     post_norm = method_config.get('post_process_norm', "none")
@@ -219,6 +253,8 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
         if norm_in:
             normalize_event_tensor(grid, stats)
         bgr = [model(grid[j:j + 1])['image'][0] for j in range(n)]
+        if guard and model.saturation()[0]:        # (synchronises; this loop copies every frame to the host anyway)
+            raise _Saturated()
         tracker.update_batch_color(items, torch.stack(bgr), [float(v) for v in tb['voxel_timestamp'][items]])
         for i in items:
             cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
@@ -251,6 +287,7 @@ class _ChunkBuffers:
         self.ev_done = None
         self.items = None
         self.n = 0
+        self.h_sat = None       # pinned copy of the model's range-guard counters as of this chunk (eval_method_on_sequences)
 
 
 def eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, sequences, metrics):
@@ -264,7 +301,19 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     network steps run back to back on the main stream; post-normalisation, MSE/SSIM/LPIPS of every frame of the chunk and
     the uint8 conversion for the PNG writers run on a second HIP stream (as pipeline.HotPath does per step) and land in
     pinned host memory; the host books chunk c (text files, PNG pool) while the GPU is already inside chunk c + 1.
-    Returns [(num_evaluated, mean_scores)] in the order of `sequences`."""
+    Returns [(num_evaluated, mean_scores)] in the order of `sequences`.
+
+    Range guard: the split arithmetic's activation formats have a finite exact range (h3: +-4094).  The counters of every chunk are
+    copied to pinned memory behind its last network step (evr_model_saturation_async, no synchronisation) and checked BEFORE the
+    chunk is booked; a non-zero counter abandons the pass and the whole group is re-run on the model's exact-fp32 twin."""
+    try:
+        return _eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, sequences, metrics)
+    except _Saturated as e:
+        exact = _rerun_exact(model, e.args[0], ', '.join(q['name'] for q in sequences))
+        return _eval_method_on_sequences(dataset_name, eval_config, method_name, exact, method_config, sequences, metrics)
+
+
+def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, method_config, sequences, metrics):
     from .dataset import SequenceBatch
     import time as _time
     _t = {'setup': -_time.perf_counter(), 'enqueue': 0.0, 'book': 0.0, 'finalize': 0.0}
@@ -289,6 +338,12 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
                           all(ds.has_images for ds in dss)) for _ in range(2)]
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(device=dev)
+    guard = hasattr(model, 'saturation_async') and getattr(model, 'arith', 'fp32') != 'fp32'
+    if guard:
+        model._ensure(S, H, W)              # (the counters exist from the first reset on)
+        model.saturation(clear=True)        # counters are cumulative: start this group from zero
+        for b in bufs:
+            b.h_sat = torch.zeros((model.saturation_counters(),), dtype=torch.int32).pin_memory()
 
     def enqueue(c0, b):
         items = [p[0][c0:c0 + CHUNK] for p in plans]
@@ -297,6 +352,8 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
         n = batch.voxel_steps(items, b.grid, b.stats)
         for i in range(n):
             model(b.grid[i], stats=b.stats[i] if norm_in else None, out=b.imgs[i])
+        if guard:
+            model.saturation_async(b.h_sat)     # lands before ev_model -> before ev_done, which book() waits for
         b.ev_model.record(main)
         b.items, b.n = items, n
         with torch.cuda.stream(side):
@@ -321,6 +378,8 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
 
     def book(b):
         b.ev_done.synchronize()
+        if guard and bool(b.h_sat.any()):
+            raise _Saturated(trackers)          # before anything of this chunk is written
         n = b.n
         sc = b.h_scores[:n * S].numpy().reshape(n, S, 2) if b.h_scores is not None else None
         lp = b.h_lp[:n * S].numpy().reshape(n, S) if b.h_lp is not None else None
@@ -373,8 +432,6 @@ def eval_method_on_sequences(dataset_name, eval_config, method_name, model, meth
     del TIMINGS[:-64]
     if os.environ.get('EVR_EVAL_TIMING'):
         print('[evreal_amd.eval] host seconds: ' + ', '.join(f'{k} {v:.3f}' for k, v in _t.items()) + f' ({S} sequences, {steps} steps)', file=sys.stderr)
-    if hasattr(model, 'warn_if_saturated'):
-        model.warn_if_saturated(', '.join(q['name'] for q in sequences))
     batch.raise_if_dropped()
     for j in range(S):      # the reference raises inside the sequence loop: same message, after the files are written
         bad = plans[j][1]
@@ -449,7 +506,17 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
     except Exception as e:
         print(f"Exception while getting method {method_name} from checkpoint path {method_config['model_path']}")
         print(e); print(traceback.format_exc())
-        return method_metrics
+        model = None
+    if world > 1:
+        # the dataset loop below holds collectives (sequence_costs' broadcast, the per-dataset all-reduce): a rank whose checkpoint
+        # load failed locally must not leave the others waiting in them -- agree first, then skip the method everywhere
+        ok = torch.tensor([0.0 if model is None else 1.0], device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and model is not None:
+            print(f"[rank {rank}] method {method_name}: another rank failed to load the checkpoint -- skipped on every rank")
+            model = None
+    if model is None:
+        return method_metrics           # eval.py:348-352: the method is skipped
     for dataset in datasets:
         dataset_metrics = MetricTracker()
         seqs = dataset['sequences']

@@ -418,6 +418,17 @@ class EvalMetricsTracker:
         self._pending = []
         self._close_files()
 
+    def discard(self):
+        """Abandon this tracker (its sequence is re-run from the start with a fresh one, which truncates the same files): wait for
+        the PNG writers still holding its frames -- they must not race the re-run's writes to the same paths -- and close the files."""
+        for f in self._pending:
+            try:
+                f.result()
+            except Exception:
+                pass
+        self._pending = []
+        self._close_files()
+
     def get_num_quan_evaluations(self):
         return len(self.quan_eval_indices)
 

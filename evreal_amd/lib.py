@@ -60,6 +60,7 @@ SYMBOLS = {
     'evr_model_flops_per_step': (c_double, [c_void_p]),
     'evr_model_arith': (c_int, [c_void_p]),
     'evr_model_saturation': (c_int, [c_void_p, ctypes.POINTER(c_int64), c_char_p, c_size_t, c_int, c_void_p]),
+    'evr_model_saturation_async': (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_int), c_void_p]),
     'evr_model_profile_enable': (c_int, [c_void_p, c_char_p]),
     'evr_model_profile_read': (c_int, [c_void_p, c_int, c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_double),
                                        ctypes.POINTER(c_int64), ctypes.POINTER(c_int), c_void_p]),

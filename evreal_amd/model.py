@@ -39,6 +39,8 @@ class _HipModel:
         self.device = torch.device('cuda', torch.cuda.current_device())
         self._shape = None
         self._needs_reset = True
+        self.arith_override = None   # None: the process-wide EVR_ARITH / EVR_FP32; 'fp32' | 'mx' | 'h3' | 'mx6': this model only
+        self._exact = None           # exact_twin()
 
     # -- construction ----------------------------------------------------------------------
     def _desc(self):
@@ -62,6 +64,7 @@ class _HipModel:
         desc = self._desc()
         desc.reserved[0] = 1 if self.debug_taps else 0
         desc.reserved[1] = 1 if getattr(self, 'kwargs', {}).get('use_dynamic_decoder', False) else 0
+        desc.reserved[2] = 0 if self.arith_override is None else {'fp32': 0, 'mx': 2, 'h3': 3, 'mx6': 4}[self.arith_override] + 1
         _lib.check(self.lib.evr_model_create(ctypes.byref(desc), tensors, len(sd), ctypes.byref(h)),
                    'evr_model_create')
         self.handle = h
@@ -82,6 +85,26 @@ class _HipModel:
         if self.handle is not None:
             self.lib.evr_model_destroy(self.handle)
             self.handle = None
+        twin, self._exact = getattr(self, '_exact', None), None
+        if twin is not None:
+            twin.destroy()
+
+    def exact_twin(self):
+        """The same network on the library's exact-fp32 HIP kernels (fp32 MFMA, PLAIN tensors: the reference's arithmetic,
+        model/submodules.py:227-245, and no range limit) -- what a sequence is re-run on when its activations left the split
+        format's range (saturation()).  Built once from the weights this model was loaded with; `self` if it already is exact."""
+        if self.arith == 'fp32':
+            return self
+        if self._exact is None:
+            if getattr(self, '_sd', None) is None:
+                raise _lib.EvrError("exact_twin: the model has no weights")
+            import copy
+            twin = copy.copy(self)
+            twin.handle, twin._shape, twin._needs_reset, twin._exact = None, None, True, None
+            twin.arith_override = 'fp32'
+            twin.load_state_dict(self._sd)
+            self._exact = twin
+        return self._exact
 
     def __del__(self):
         try:
@@ -160,6 +183,19 @@ class _HipModel:
                    'evr_model_saturation')
         return n.value, name.value.decode()
 
+    def saturation_counters(self):
+        """Number of range-guard counters evr_model_saturation_async copies (matrix-core layers + the head)."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.evr_model_saturation_async(self.handle, None, 0, ctypes.byref(n), _lib.stream_ptr()), 'evr_model_saturation_async')
+        return n.value
+
+    def saturation_async(self, host_pinned):
+        """Copy the range-guard counters (cumulative since the last clear) into `host_pinned` (pinned int32/uint32 CPU tensor)
+        asynchronously on the current stream: no host synchronisation; read it after an event recorded behind this call."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.evr_model_saturation_async(self.handle, ctypes.c_void_p(host_pinned.data_ptr()), int(host_pinned.numel()),
+                                                       ctypes.byref(n), _lib.stream_ptr()), 'evr_model_saturation_async')
+
     def warn_if_saturated(self, what=''):
         """Once per sequence (eval loops): report activations beyond the split format's range instead of degrading silently."""
         n, layer = self.saturation(clear=True)
@@ -168,7 +204,8 @@ class _HipModel:
             how = {'h3': " (clamped at +-4094)", 'mx6': " (beyond +-65504: clamped)"}.get(mode, " (f16 only, 2^-12 relative)")
             print(f"WARNING: {n} activation runs{(' of ' + what) if what else ''} left the exact range of the '{mode}' packed "
                   f"format (most in layer '{layer}'): those values kept reduced precision" + how
-                  + "; rerun with EVR_FP32=1 for data of this magnitude")
+                  + "; evreal_amd.eval re-runs such sequences on exact_twin() itself -- a caller stepping the model directly should do "
+                  "the same (or set EVR_FP32=1) for data of this magnitude")
         return n
 
     def flops_per_step(self):
@@ -331,10 +368,12 @@ class ColorNet:
         if getattr(model, '_sd', None) is None:
             raise _lib.EvrError("ColorNet needs a model with loaded weights")
         import copy
-        self.half = copy.copy(model)             # shallow: same kwargs/desc, own handle
+        self.half = copy.copy(model)             # shallow: same kwargs/desc (and arithmetic), own handle
         self.half.handle = None
         self.half._shape = None
+        self.half._exact = None
         self.half.load_state_dict(model._sd)
+        self._exact = None
         self.lib = _lib.load()
         import os
         self._side = torch.cuda.Stream(device=model.device) if os.environ.get('EVR_COLOR_STREAMS', '2') != '1' else None
@@ -343,6 +382,24 @@ class ColorNet:
     @property
     def num_encoders(self):
         return self.model.num_encoders
+
+    @property
+    def arith(self):
+        return self.model.arith
+
+    def saturation(self, clear=False):
+        """Range-guard counters of both executors (see _HipModel.saturation)."""
+        n0, l0 = self.model.saturation(clear)
+        n1, l1 = self.half.saturation(clear)
+        return n0 + n1, (l0 if n0 >= n1 else l1)
+
+    def exact_twin(self):
+        """ColorNet over the exact-fp32 twin of the base network (both executors)."""
+        if self.arith == 'fp32':
+            return self
+        if getattr(self, '_exact', None) is None:
+            self._exact = ColorNet(self.model.exact_twin())
+        return self._exact
 
     def reset_states(self):
         self.model.reset_states()

@@ -252,6 +252,27 @@ def synth_state_dict(schema, seed=0, gain=1.0, fixed=None):
     return out
 
 
+def rescale_encoder_conv(sd, enc=1, K=4096.0, prefix='unetrecurrent.'):
+    """The SAME network function with one intermediate tensor K times larger: the output of encoder `enc`'s strided ConvLayer
+    (BN layout: gamma and beta times K -- relu is positively homogeneous; no-norm layout: weight and bias times K) and the
+    ConvLSTM gate weights that read it (the x half of cat(x, h), submodules.py:227-231) divided by K.  That tensor feeds nothing
+    else (model/unet.py:120-123).  With K a power of two every fp32 product scales exactly, so the reference's outputs are
+    bit-identical to the unscaled network's -- while the tensor leaves the +-4094 range of the H2 activation format: the test
+    vehicle for 'saturation must not change results' (tests/test_gpu_eval.py, tests/golden/eval_loop_e2vid.json)."""
+    out = OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items())
+    p = f'{prefix}encoders.{enc}'
+    if p + '.conv.norm_layer.weight' in out:
+        out[p + '.conv.norm_layer.weight'] *= np.float32(K)
+        out[p + '.conv.norm_layer.bias'] *= np.float32(K)
+    else:
+        out[p + '.conv.conv2d.weight'] *= np.float32(K)
+        out[p + '.conv.conv2d.bias'] *= np.float32(K)
+    g = out[p + '.recurrent_block.Gates.weight']
+    C = g.shape[1] // 2
+    g[:, :C] /= np.float32(K)
+    return out
+
+
 def state_dict_digest(sd):
     """sha256 over names, shapes and raw bytes (order-independent of dict order)."""
     h = hashlib.sha256()

@@ -38,7 +38,8 @@ enum evr_status {
 
 /* Message for the last failure on this thread ("" if none). */
 const char* evr_last_error(void);
-/* ABI version (major*1000 + minor).  1001 (round 4): evr_percentile_normalize rejects a NULL workspace (size it with
+/* ABI version (major*1000 + minor).  1002 (round 5): evr_model_desc.reserved[2] (per-model arithmetic), evr_model_saturation_async.
+ * 1001 (round 4): evr_percentile_normalize rejects a NULL workspace (size it with
  * evr_percentile_normalize_workspace_bytes); evr_model_arith reports the mode the convolutions actually run (FireNet's 16-channel
  * layers: h3 whatever EVR_ARITH says). */
 int evr_version(void);
@@ -146,7 +147,11 @@ typedef struct evr_model_desc {
     int recurrent_block;     /* evr_recurrent */
     int final_activation;    /* evr_activation */
     int pad_multiple_log2;   /* cropper's num_encoders (FireNet legacy: 4, FireNet+: 0) */
-    int reserved[5];         /* reserved[1] bit 0: use_dynamic_decoder (HyperE2VID, model/submodules.py:100-127);
+    int reserved[5];         /* reserved[2]: arithmetic of THIS model's convolutions, as mode + 1 (1 exact fp32, 3 "mx", 4 "h3", 5 "mx6");
+                              *   0 = what EVR_ARITH / EVR_FP32 select for the process.  The reference computes in fp32
+                              *   (model/submodules.py:227-245): the exact-fp32 twin is what a sequence is re-run on when its
+                              *   activations leave a split format's range (evr_model_saturation);
+                              * reserved[1] bit 0: use_dynamic_decoder (HyperE2VID, model/submodules.py:100-127);
                               * reserved[0] bit 0: debug -- keep every intermediate readable by
                               * evr_model_read_tensor (otherwise the last decoder's NHWC output is never
                               * stored: the prediction layer is fused into its epilogue) */
@@ -193,6 +198,12 @@ int evr_model_arith(const evr_model* m);
  * with EVR_ARITH=h3 (fp32-grade, range +-4094) or EVR_FP32=1.  The reference runs fp32 (model/submodules.py:227-245) and
  * has no such limit.  Synchronises the stream. */
 int evr_model_saturation(evr_model* model, int64_t* runs_host, char* worst_layer, size_t worst_len, int clear, evr_stream_t stream);
+/* The same per-layer counters (cumulative since the last clear) WITHOUT a synchronisation: copied asynchronously on `stream` to
+ * counters_host (caller-owned, pinned host memory, room for max_counters unsigned); *n_counters = how many there are
+ * (counters_host == NULL: size query only).  Read them once an event recorded behind this call has completed.  evreal_amd's frame
+ * loop polls every chunk of frames this way BEFORE it books the chunk, and re-runs the sequences on an exact-fp32 twin of the
+ * model (reserved[2] = 1) when any counter is non-zero: out-of-range activations never reach a score or an output file. */
+int evr_model_saturation_async(evr_model* model, unsigned* counters_host, int max_counters, int* n_counters, evr_stream_t stream);
 /* Per-layer timing for the roofline block of bench.py.  While enabled, evr_model_step brackets every
  * convolution launch whose layer name contains `filter` ("" = all layers) with HIP events on the launch
  * stream; filter == NULL disables.  evr_model_profile_read synchronises the stream, then returns per

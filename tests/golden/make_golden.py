@@ -419,7 +419,104 @@ def make_eval():
     save_json('eval_loop.json', dict(seqs=EVAL_SEQS, cfgs=EVAL_CFGS, files=files, scores=captured))
 
 
+# ---------------------------------------------------------------- 9b. the 'E2VID' registry branch and a pickled-ConfigParser method, end to end
+# eval.py:141-144 (checkpoint['model'] kwargs + final_activation = 'sigmoid') with config/method/E2VID.json's
+# event_tensor_normalization = true and post_process_norm = 'robust' (eval.py:380-395) INSIDE the frame loop, and
+# eval.py:149-151 (checkpoint['config'] is a pickled parse_config.ConfigParser; config.init_obj('arch', model_arch)) with
+# config/method/E2VID+.json's settings.  The E2VID / E2VID+ blobs are absent (.MISSING_LARGE_BLOBS): the checkpoints hold
+# evreal_amd.weights' deterministic synthetic weights in the reference's own checkpoint layouts.  70x50 sensor: the
+# cropper pads to 72x56 and crops back (utils/util.py:30-59).
+E2VID_EVAL_SEQS = {   # name: (seed, n_events, rate_hz, W, H, fps, start_time_s, end_time_s)
+    'seqC': (81, 36000, 2.0e5, 70, 50, 50.0, None, None),
+    'seqD': (82, 27000, 2.0e5, 70, 50, 50.0, 0.03, 0.10),
+}
+E2VID_EVAL_CFGS = {k: EVAL_CFGS[k] for k in ('std', 'k3k')}
+E2VID_METHODS = {
+    'E2VID': {"model_name": "E2VID", "event_tensor_normalization": True, "post_process_norm": "robust"},
+    'E2VID+': {"model_name": "E2VID+", "event_tensor_normalization": False, "post_process_norm": "none"},
+    # the E2VID checkpoint with ONE intermediate tensor 65536 times larger (weights.rescale_encoder_conv: the same function, bit for
+    # bit in fp32) -- activations beyond +-4094: what a split-precision drop-in must still get right
+    'E2VID_big': {"model_name": "E2VID", "event_tensor_normalization": True, "post_process_norm": "robust"},
+}
+E2VID_EVAL_SEEDS = {'E2VID': 21, 'E2VID+': 22, 'E2VID_big': 21}
+E2VID_BIG_K = 65536.0
+
+
+def e2vid_eval_checkpoints(root, config_parser_cls):
+    """Writes the two checkpoints in the layouts the reference's registry parses; returns {method: path}."""
+    out = {}
+    kw = {k: v for k, v in weights.E2VID_KWARGS.items() if k != 'final_activation'}        # eval.py:143 sets it
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=E2VID_EVAL_SEEDS['E2VID'])
+    out['E2VID'] = os.path.join(root, 'e2vid.pth')
+    torch.save({'model': dict(kw), 'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, out['E2VID'])
+    big = weights.rescale_encoder_conv(sd, enc=1, K=E2VID_BIG_K)
+    out['E2VID_big'] = os.path.join(root, 'e2vid_big.pth')
+    torch.save({'model': dict(kw), 'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in big.items()}}, out['E2VID_big'])
+    kwp = dict(weights.E2VID_PLUS_KWARGS)
+    sdp = weights.synth_state_dict(weights.unet_recurrent_schema(**kwp), seed=E2VID_EVAL_SEEDS['E2VID+'])
+    out['E2VID+'] = os.path.join(root, 'e2vid_plus.pth')
+    torch.save({'config': config_parser_cls({'arch': {'type': 'E2VIDRecurrent', 'args': {'unet_kwargs': kwp}}}),
+                'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sdp.items()}}, out['E2VID+'])
+    return out
+
+
+def make_eval_e2vid():
+    import contextlib
+    import utils.eval_metrics as em
+    from oracle import metrics as omet
+    from parse_config import ConfigParser           # the reference's own class: what its checkpoints pickle
+    em.mse = lambda ref, img: omet.mse(img, ref)
+    em.ssim = lambda ref, img, **kw: omet.ssim(img, ref, sigma=kw.get('sigma', 1.5), data_range=kw.get('data_range', 1.0))
+    sys.modules['cv2'].imwrite = lambda path, img: True
+
+    class NoTimer(contextlib.ContextDecorator):
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+    ref_eval.CudaTimer = NoTimer
+    captured = {}
+    ref_eval.print_scores = lambda all_metrics, methods, dsets, cfg: captured.__setitem__(
+        cfg, [[dm.data_dict for dm in mm] for mm in all_metrics])
+    cwd = os.getcwd()
+    methods = list(E2VID_METHODS)
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ('eval', 'method', 'dataset'):
+            os.makedirs(os.path.join(d, 'config', sub), exist_ok=True)
+        for name, cfg in E2VID_EVAL_CFGS.items():
+            json.dump(cfg, open(os.path.join(d, 'config', 'eval', name + '.json'), 'w'))
+        paths = e2vid_eval_checkpoints(d, ConfigParser)
+        for mname, mcfg in E2VID_METHODS.items():
+            json.dump(dict(mcfg, model_path=paths[mname]), open(os.path.join(d, 'config', 'method', mname + '.json'), 'w'))
+        seqs = {}
+        for name, (seed, n, rate, W, H, fps, st, en) in E2VID_EVAL_SEQS.items():
+            synth.write_sequence(os.path.join(d, 'data', 'SYN', name), seed, n, rate, W, H, fps)
+            seqs[name] = {} if st is None else {"start_time_s": st, "end_time_s": en}
+        json.dump({"root_path": os.path.join(d, 'data', 'SYN'), "sequences": seqs},
+                  open(os.path.join(d, 'config', 'dataset', 'SYN.json'), 'w'))
+        os.chdir(d)
+        try:
+            ref_eval.evaluate(methods, list(E2VID_EVAL_CFGS), ['SYN'], ['mse', 'ssim'])
+        finally:
+            os.chdir(cwd)
+        files = {}
+        for base, _, fs in os.walk(os.path.join(d, 'outputs')):
+            for f in fs:
+                if f.endswith('.txt'):
+                    rel = os.path.relpath(os.path.join(base, f), d)
+                    files[rel] = open(os.path.join(base, f)).read()
+    assert files and all(captured[c][i][0] for c in captured for i in range(len(methods))), 'the reference run scored nothing'
+    # the rescaled network IS the same function in the reference's fp32: its files are the E2VID files, byte for byte
+    for rel, txt in files.items():
+        if '/E2VID_big/' in rel:
+            assert txt == files[rel.replace('/E2VID_big/', '/E2VID/')], rel
+    save_json('eval_loop_e2vid.json', dict(seqs=E2VID_EVAL_SEQS, cfgs=E2VID_EVAL_CFGS, methods=E2VID_METHODS, method_order=methods,
+                                           seeds=E2VID_EVAL_SEEDS, big_k=E2VID_BIG_K, files=files, scores=captured))
+
+
 # ---------------------------------------------------------------- 10. ColorNet streams
+COLOR_EDGE_TOL = 1e-3      # in uint8 codes: 4e-6 of the image range
+
+
 def make_color():
     import model.model as mm
     kw = dict(weights.E2VID_PLUS_KWARGS)
@@ -431,17 +528,43 @@ def make_color():
     mm.merge_channels_into_color_image = lambda ch: (captured.append({k: v.copy() for k, v in ch.items()}),
                                                      np.zeros(ch['grayscale'].shape + (3,), np.uint8))[1]
     mm.transforms.functional = types.SimpleNamespace(to_tensor=lambda a: torch.zeros(3, *a.shape[:2]))
+    # model.py:101 truncates: np.clip(img * 255, 0, 255).astype(np.uint8).  A truncation is discontinuous: two fp32 evaluations of the
+    # same network that differ in the last bits (a summation order, a thread count) disagree by one code wherever img * 255 sits on
+    # an integer edge.  Record the reference's OWN float argument of that clip, to store where those pixels are.
+    floats = []
+
+    class _NpSpy:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        def clip(self, a, lo, hi):
+            floats.append(np.array(a, dtype=np.float32, copy=True))
+            return np.clip(a, lo, hi)
+    mm.np = _NpSpy()
     net = mm.ColorNet(base)
     H, W, F = 96, 128, 3
     vox = synth.sparse_voxels(91, F, 5, H, W)
-    with torch.no_grad():
-        for f in range(F):
-            net(torch.from_numpy(vox[f:f + 1]))
+    try:
+        with torch.no_grad():
+            for f in range(F):
+                net(torch.from_numpy(vox[f:f + 1]))
+    finally:
+        mm.np = np
     out = {}
+    names = list(net.channels)          # R, G, B, W, grayscale: the order ColorNet.forward visits them (model.py:54-58)
+    assert len(floats) == F * len(names)
     for f, ch in enumerate(captured):
-        for k, v in ch.items():
+        for ci, k in enumerate(names):
+            v = ch[k]
             out[f'f{f}.{k}'] = v
+            x = floats[f * len(names) + ci]
+            assert np.array_equal(np.clip(x, 0, 255).astype(np.uint8), v)
+            # pixels whose value the reference itself computed within COLOR_EDGE_TOL of a truncation edge (an integer in (0, 255]):
+            # the only ones where an implementation that matches the floats to 1e-4 / 255 may land on the neighbouring code
+            near = (np.abs(x - np.rint(x)) < COLOR_EDGE_TOL) & (x > 0.5) & (x < 255.5)
+            out[f'f{f}.{k}.edge'] = np.packbits(near)
     save_npz('colornet_seq.npz', voxel_sha=np.array(sha(vox)), voxel_args=np.array([91, F, 5, H, W]), seed=np.array(9),
+             edge_tol=np.array(COLOR_EDGE_TOL),
              kwargs=np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8),
              weights_sha=np.array(weights.state_dict_digest(sd)), **out)
 
@@ -532,7 +655,7 @@ def make_spade():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'color', 'spade', 'metrics', 'etnet']
+    which = sys.argv[1:] or ['voxel', 'dataset', 'helpers', 'firenet', 'e2vid', 'eval', 'eval_e2vid', 'color', 'spade', 'metrics', 'etnet']
     for w in which:
         {'voxel': make_voxel, 'dataset': make_dataset, 'helpers': make_helpers,
-         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'color': make_color, 'spade': make_spade, 'metrics': make_metrics_published, 'etnet': make_etnet}[w]()
+         'firenet': make_firenet, 'e2vid': make_e2vid, 'eval': make_eval, 'eval_e2vid': make_eval_e2vid, 'color': make_color, 'spade': make_spade, 'metrics': make_metrics_published, 'etnet': make_etnet}[w]()

@@ -89,3 +89,10 @@ def test_validation_covers_the_windows_events_only(tmp_path):
     np.save(tmp_path / 'a' / 'events_p.npy', np.full(5000, 2, np.uint8))
     with pytest.raises(ValueError, match='must hold 0/1'):
         MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7).host_events()
+    # a float file holding exactly 0.0 / 1.0 is what the reference's p.astype(float32)*2-1 (dataset.py:227) accepts: so do we
+    np.save(tmp_path / 'a' / 'events_p.npy', w['p'].astype(np.float32))
+    cols = MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7).host_events()
+    assert cols[2].dtype == np.uint8 and np.array_equal(cols[2], w['p'].astype(np.uint8))
+    np.save(tmp_path / 'a' / 'events_p.npy', w['p'].astype(np.float32) * 0.5)                # 0.0 / 0.5: not polarities
+    with pytest.raises(ValueError, match='must hold 0/1'):
+        MemMapDataset(str(tmp_path / 'a'), num_bins=5, voxel_method=vm, max_length=7).host_events()

@@ -1,5 +1,5 @@
-"""GPU parity of ColorNet: the five recurrent streams' uint8 planes vs the reference (pinned); merge vs the oracle
-restatement (unpinned -- cv2 is absent)."""
+"""GPU parity of ColorNet: the five recurrent streams' uint8 planes vs the reference (pinned: bit-exact outside the truncation
+edges the reference's own floats mark); merge vs the oracle restatement (unpinned -- cv2 is absent)."""
 import json
 
 import numpy as np
@@ -25,19 +25,28 @@ def test_colornet_streams_match_reference_planes():
     vox = synth.sparse_voxels(seed, F, B, H, W)
     assert sha(vox) == str(z['voxel_sha'])
     net.reset_states()
+    flips = edges = 0
     for f in range(F):
         out = net(torch.from_numpy(vox[f:f + 1]).cuda())
         planes = out['planes'][0].cpu().numpy(); gray = out['gray'][0, 0].cpu().numpy()
-        for ci, name in enumerate(['R', 'G', 'B', 'W']):
-            got, want = oc.to_u8(planes[ci]).astype(int), z[f'f{f}.{name}'].astype(int)
+        # model.py:101 TRUNCATES clip(img * 255): bit-exact planes everywhere except where the reference's own float value sits
+        # within edge_tol (1e-3 of a code = 4e-6 of the image range) of an integer edge -- the golden stores those pixels (0.19 % of
+        # them), computed from the reference's own floats.  There, and only there, an evaluation that differs in the last bits (the
+        # reference's own result moves with its thread count) may land on the neighbouring code.
+        for ci, name in enumerate(['R', 'G', 'B', 'W', 'grayscale']):
+            img = gray if name == 'grayscale' else planes[ci]
+            got, want = oc.to_u8(img).astype(int), z[f'f{f}.{name}'].astype(int)
+            edge = np.unpackbits(z[f'f{f}.{name}.edge'])[:want.size].reshape(want.shape).astype(bool)
             d = np.abs(got - want)
-            assert d.max() <= 1 and (d == 0).mean() > 0.995, (f, name, d.max(), (d == 0).mean())   # truncation flips at integer edges only
-        d = np.abs(oc.to_u8(gray).astype(int) - z[f'f{f}.grayscale'].astype(int))
-        assert d.max() <= 1 and (d == 0).mean() > 0.995, (f, 'gray')
+            assert np.array_equal(got[~edge], want[~edge]), (f, name, int(d[~edge].max()), int((d[~edge] != 0).sum()))
+            assert d.max() <= 1, (f, name, d.max())
+            flips += int((d != 0).sum()); edges += int(edge.sum())
         bgr = out['image'][0].cpu().numpy()
         want = oc.merge(planes, gray)
         dd = np.abs(bgr.astype(int) - want.astype(int))
         assert dd.max() <= 2 and (dd == 0).mean() > 0.98, (dd.max(), (dd == 0).mean())          # float-vs-float restatement
+    assert float(z['edge_tol']) == 1e-3 and flips <= edges
+    print(f'colornet planes: {flips} of {edges} edge pixels landed on the neighbouring code; every other pixel is bit-exact')
 
 
 def test_bayer_split_matches_slicing():

@@ -1,6 +1,8 @@
 """GPU parity of the evaluation loop (dataset reader + window planner + frame loop + trackers + output files)
-against the reference's own evaluate() run (tests/golden/eval_loop.json: FireNet real weights, synthetic
-sequences, between_frames / k_events / t_seconds configs incl. start/end-time gating and eval_infer_all)."""
+against the reference's own evaluate() runs (tests/golden/eval_loop.json: FireNet real weights, synthetic
+sequences, between_frames / k_events / t_seconds configs incl. start/end-time gating and eval_infer_all;
+tests/golden/eval_loop_e2vid.json: the E2VID registry branch with 'robust' post-normalisation and a pickled-ConfigParser
+method, synthetic weights in the reference's checkpoint layouts)."""
 import json
 import os
 
@@ -72,6 +74,115 @@ def test_evaluate_with_batched_sequences_matches_reference_run(tmp_path, monkeyp
     """--batch-sequences: the sequences of a dataset advance together, one batch slot each; every output file and
     score must still equal the reference's one-sequence-at-a-time run."""
     _evaluate_and_compare(tmp_path, monkeypatch, 3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The 'E2VID' registry branch (eval.py:141-144: checkpoint['model'] kwargs + sigmoid; config/method/E2VID.json:
+# event_tensor_normalization + 'robust' post-normalisation inside the frame loop, eval.py:380-395) and a method whose
+# checkpoint carries a pickled parse_config.ConfigParser (eval.py:149-151, the E2VID+ / HyperE2VID / FireNet+ / ET-Net
+# form), against tests/golden/eval_loop_e2vid.json = the reference's own evaluate() on the same checkpoints
+# (make_golden.py make_eval_e2vid: synthetic weights in the reference's checkpoint layouts, 70x50 -> padded 72x56).
+def _write_e2vid_tree(root, g):
+    import sys
+    import types
+    from evreal_amd import synth, weights
+    for sub in ('eval', 'method', 'dataset'):
+        os.makedirs(os.path.join(root, 'config', sub), exist_ok=True)
+    for name, cfg in g['cfgs'].items():
+        json.dump(cfg, open(os.path.join(root, 'config', 'eval', name + '.json'), 'w'))
+    # the checkpoints, written as make_golden.py e2vid_eval_checkpoints writes them.  The reference's ConfigParser is not on
+    # this box: an object of a same-named class in a module called parse_config pickles to the same GLOBAL reference.
+    mod = types.ModuleType('parse_config')
+
+    class ConfigParser:
+        def __init__(self, config):
+            self._config = config
+    ConfigParser.__module__ = 'parse_config'
+    ConfigParser.__qualname__ = 'ConfigParser'
+    mod.ConfigParser = ConfigParser
+    kw = {k: v for k, v in weights.E2VID_KWARGS.items() if k != 'final_activation'}
+    sd = weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=g['seeds']['E2VID'])
+    kwp = dict(weights.E2VID_PLUS_KWARGS)
+    sdp = weights.synth_state_dict(weights.unet_recurrent_schema(**kwp), seed=g['seeds']['E2VID+'])
+    paths = {'E2VID': os.path.join(root, 'e2vid.pth'), 'E2VID+': os.path.join(root, 'e2vid_plus.pth'),
+             'E2VID_big': os.path.join(root, 'e2vid_big.pth')}
+    torch.save({'model': dict(kw), 'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, paths['E2VID'])
+    big = weights.rescale_encoder_conv(sd, enc=1, K=float(g['big_k']))      # the same function with one tensor beyond +-4094
+    torch.save({'model': dict(kw), 'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in big.items()}}, paths['E2VID_big'])
+    had = sys.modules.get('parse_config')
+    sys.modules['parse_config'] = mod
+    try:
+        torch.save({'config': ConfigParser({'arch': {'type': 'E2VIDRecurrent', 'args': {'unet_kwargs': kwp}}}),
+                    'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sdp.items()}}, paths['E2VID+'])
+    finally:
+        if had is not None:
+            sys.modules['parse_config'] = had
+        else:
+            del sys.modules['parse_config']
+    for mname, mcfg in g['methods'].items():
+        json.dump(dict(mcfg, model_path=paths[mname]), open(os.path.join(root, 'config', 'method', mname + '.json'), 'w'))
+    seqs = {}
+    for name, (seed, n, rate, W, H, fps, st, en) in g['seqs'].items():
+        synth.write_sequence(os.path.join(root, 'data', 'SYN', name), seed, n, rate, W, H, fps)
+        seqs[name] = {} if st is None else {"start_time_s": st, "end_time_s": en}
+    json.dump({"root_path": os.path.join(root, 'data', 'SYN'), "sequences": seqs},
+              open(os.path.join(root, 'config', 'dataset', 'SYN.json'), 'w'))
+
+
+def _evaluate_e2vid_and_compare(tmp_path, monkeypatch, batch_sequences, methods):
+    from evreal_amd import eval as ev
+    monkeypatch.setenv('EVREAL_BATCH_SEQUENCES', str(batch_sequences))
+    g = load_json('eval_loop_e2vid.json')
+    _write_e2vid_tree(str(tmp_path), g)
+    monkeypatch.chdir(tmp_path)
+    order = g['method_order']
+    res = ev.evaluate(methods, list(g['cfgs']), ['SYN'], ['mse', 'ssim'])
+    assert len(g['files']) == 3 * 2 * 2 * 4
+    for rel, want in g['files'].items():
+        if rel.split(os.sep)[4] not in methods:
+            continue
+        got = open(tmp_path / rel).read()
+        name = os.path.basename(rel)
+        if name in ('timestamps.txt', 'event_rate.txt'):
+            assert got == want, rel                      # byte-identical
+        else:
+            a, b = _parse(got), _parse(want)
+            assert [i for i, _ in a] == [i for i, _ in b], rel
+            np.testing.assert_allclose([s for _, s in a], [s for _, s in b], rtol=0, atol=2e-5, err_msg=rel)
+    for cfg, want in g['scores'].items():
+        for mi, mname in enumerate(methods):
+            dm = res[cfg][mi][0].data_dict
+            ref = want[order.index(mname)][0]
+            assert set(dm) == set(ref), (cfg, mname)
+            for metric, d in ref.items():
+                assert dm[metric]['count'] == d['count'] > 0, (cfg, mname, metric)
+                assert abs(dm[metric]['average'] - d['average']) < 2e-5, (cfg, mname, metric, dm[metric]['average'], d['average'])
+
+
+def test_evaluate_e2vid_branch_matches_reference_run(tmp_path, monkeypatch):
+    _evaluate_e2vid_and_compare(tmp_path, monkeypatch, 1, ['E2VID', 'E2VID+'])
+
+
+def test_evaluate_e2vid_branch_batched_matches_reference_run(tmp_path, monkeypatch):
+    _evaluate_e2vid_and_compare(tmp_path, monkeypatch, 2, ['E2VID', 'E2VID+'])
+
+
+@pytest.mark.parametrize('batch_sequences', [1, 2])
+def test_out_of_range_activations_are_rerun_in_exact_fp32(tmp_path, monkeypatch, capsys, batch_sequences):
+    """Saturation must not change results.  'E2VID_big' is the E2VID checkpoint with one intermediate tensor 65536 times larger
+    (weights.rescale_encoder_conv: the same function bit for bit in fp32 -- make_golden.py asserts the reference writes the same
+    files for both): its activations leave the +-4094 range of the default arithmetic's H2 format.  evaluate() must notice before
+    it books anything of the chunk, say so, re-run the sequences on the library's exact-fp32 kernels and produce the reference's
+    files: timestamps / event rates byte-identical, scores within 2e-5."""
+    from evreal_amd import eval as ev
+    _evaluate_e2vid_and_compare(tmp_path, monkeypatch, batch_sequences, ['E2VID_big'])
+    out = capsys.readouterr().out
+    exact = bool(os.environ.get('EVR_FP32')) or os.environ.get('EVR_ARITH') == 'fp32'
+    if exact:
+        assert 're-running in exact fp32' not in out          # (the whole suite on the exact mode: nothing to re-run)
+    else:
+        assert out.count('re-running in exact fp32') >= 2 and "layer 'enc1.conv'" in out, out[-2000:]      # once per eval config at least
+    ev._MODEL_CACHE.clear()
 
 
 def test_png_writers_async_equals_sync(tmp_path, monkeypatch):

@@ -94,6 +94,32 @@ def test_drift_100_frames_346x260_8_sequences():
     print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
 
 
+def test_drift_100_frames_346x260_one_sequence_split_k():
+    """The reference's own operating point -- ONE sequence, batch 1 (eval.py:72) -- runs the deep layers (12 tiles of 128 pixels at
+    33 x 44) through the split-K forms of the band kernels (conv.hip launch_band / launch_band_prog: up to four blocks per tile, partial
+    sums through the model's workspace, conv_ksplit_epilogue_kernel): 100 recurrent frames at 346x260 against the oracle, states at
+    the end.  EVR_TEST_SPLITK_FRAMES shortens it for the EVR_KSPLIT=0 pass below."""
+    from evreal_amd import weights
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    frames = int(os.environ.get('EVR_TEST_SPLITK_FRAMES', '100'))
+    m, o = _pair(dict(weights.E2VID_KWARGS), seed=21)
+    worst = _run(m, o, 260, 346, 3, frames=frames, n_seq=1, n_events=15000, seed0=120000, check_states=True)
+    print(f'{frames}-frame drift, 1 sequence (split K {os.environ.get("EVR_KSPLIT", "default")}): worst per-pixel error {worst:.2e}')
+
+
+def test_one_sequence_without_split_k():
+    """the same one-sequence run with the split switched off (EVR_KSPLIT=0 is read once per process: a fresh interpreter),
+    so that both forms are held to the same oracle at the same gate."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVR_KSPLIT='0', EVR_TEST_SPLITK_FRAMES='12')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_fullsize.py::test_drift_100_frames_346x260_one_sequence_split_k'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_recurrence_at_the_64_sequence_dispatch():
     """The recurrence at the dispatch bench.py times: 64 sequences advanced together (the 256 x 128 / 256 x 256-tile ConvLSTM kernels, the
     twin-form decoders with the fused prediction epilogue), sequence 37 replayed through the CPU oracle at every frame; final ConvLSTM

@@ -375,6 +375,39 @@ def test_large_activations_are_reported_not_silent():
                 assert runs > 0, scale                 # inputs beyond the half-precision range itself (+-65504) are clamped: reported
 
 
+def test_exact_twin_is_the_reference_arithmetic_without_a_range_limit():
+    """_HipModel.exact_twin(): the same weights on the library's exact-fp32 kernels, in the same process as the default arithmetic
+    (evr_model_desc.reserved[2]).  On a network whose enc1.conv output is 65536 times larger (weights.rescale_encoder_conv: the same
+    function in fp32) the default arithmetic reports saturation, the twin reports none and matches the oracle to 1e-4 -- in fact to
+    the level the unscaled network reaches -- frame after frame through the recurrence."""
+    from evreal_amd import model, synth, weights
+    from oracle import model as omod, prepost as op
+    kw = dict(weights.E2VID_KWARGS)
+    sd = weights.rescale_encoder_conv(weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=21), enc=1, K=65536.0)
+    m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
+    twin = m.exact_twin()
+    assert twin.arith == 'fp32' and twin.exact_twin() is twin and m.exact_twin() is twin
+    okeys = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size', 'norm', 'use_upsample_conv',
+             'recurrent_block_type', 'final_activation']
+    o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **{k: kw[k] for k in okeys})
+    vox = synth.sparse_voxels(3, 4, 5, 50, 70, density=0.1)
+    crop = op.CropParams(70, 50, 3)
+    m.reset_states(); twin.reset_states(); o.reset_states()
+    m.saturation(clear=True)
+    worst_twin = worst_m = 0.0
+    for f in range(4):
+        x = torch.from_numpy(vox[f:f + 1]).cuda()
+        with torch.no_grad():
+            want = crop.crop(o(torch.from_numpy(crop.pad(vox[f:f + 1]))).numpy())
+        worst_twin = max(worst_twin, float(np.abs(twin(x)['image'].cpu().numpy() - want).max()))
+        worst_m = max(worst_m, float(np.abs(m(x)['image'].cpu().numpy() - want).max()))
+    assert worst_twin < 1e-5, worst_twin
+    assert twin.saturation()[0] == 0
+    if m.arith != 'fp32':
+        runs, layer = m.saturation()
+        assert runs > 0 and layer == 'enc1.conv', (runs, layer, worst_m)
+
+
 def test_arithmetic_is_narrowed_per_layout():
     """evr_model_arith: the default is the fp32-grade three-f16-product arithmetic for every layout; the opt-in f16 + MX-fp6 arithmetic (EVR_ARITH=mx6) needs a layout whose packed tensors are written as whole 16-channel groups
     (ConvLSTM UNets with transposed or upsample-conv decoders, BN / no norm, the 5-bin k5 32-channel head); every other layout runs
