@@ -294,11 +294,12 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
         return (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)
 
     t_start = time.perf_counter()
-    best, best_t = None, None
+    best, best_t, tried = None, None, {}
     for nt in ([threads] if threads else sorted({min(8, os.cpu_count()), min(32, os.cpu_count())})):
         torch.set_num_threads(nt)
         frame(0)                                   # warm-up at this thread count
         dt = sum(frame(1 % xy.shape[0]))
+        tried[str(nt)] = round(1.0 / dt, 2)        # frames/s of the probe frame at this thread count (both go on the line)
         if best_t is None or dt < best_t:
             best, best_t = nt, dt
     torch.set_num_threads(best)
@@ -314,6 +315,7 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
            "sample": f"{done} frames of one {W_}x{H_} sequence (#{seq}), batch 1, {wl.name} forward on {best} torch threads of the "
                      f"{os.cpu_count()}-core host (C voxelizer and numpy/scipy stages 1 thread), torch {torch.__version__}",
            "ms_per_frame": {kk: round(1e3 * v / max(done, 1), 3) for kk, v in times.items()},
+           "threads_tried": tried,      # one probe frame per torch thread count; `cores` is the faster one, used for the timed sample
            "mevents_per_s_voxelizer": round(k * done / max(times['voxel'], 1e-9) / 1e6, 2)}
     return res, kept
 
@@ -477,7 +479,7 @@ def compact_line(out, full_path=None):
                                    "bytes_per_window": rv.get('bytes_per_window')}
     cb = out.get('cpu_baseline')
     o["cpu_baseline"] = None if not cb else {"value": cb.get('value'), "unit": cb.get('unit'), "cores": cb.get('cores'), "kind": cb.get('kind'),
-                                             "sample": str(cb.get('sample', ''))[:170]}
+                                             "threads_tried": cb.get('threads_tried'), "sample": str(cb.get('sample', ''))[:170]}
     sp = out.get('score_parity')
     if sp:
         o["score_parity"] = {"frames": sp.get('frames'), "sequences": sp.get('sequences'), "image_max_abs_err": _r(sp.get('image_max_abs_err'), 3),
