@@ -1024,6 +1024,104 @@ __global__ __launch_bounds__(256, 2) void conv_ksplit_epilogue_kernel(const Conv
 #endif
 }
 
+// The same, four times as wide (round 5): at one sequence the deep layers are 24-96 tiles, and the one-block-per-tile form above spent
+// 15-19 us per launch -- as long as the split main loop it follows -- on four (ksplit) dependent rounds of 16 loads per lane with 24
+// blocks on the chip.  Here a block is one (tile, 32-pixel row block): its four waves each take ONE 32-column block (plain epilogues)
+// or ONE 4-channel quad of every gate (ConvLSTM), so a lane sums 4 x ksplit float4 partials that are all requested up front (run
+// index clamped, not branched: one round trip), then runs the shared epilogue for its slice.  Same run order of the sums as above
+// (0 + run 0 + run 1 + ...): bit-identical results.  9 launches of a one-sequence frame: 16.6 -> ~6 us each.
+template <bool LSTM, bool GROUPED, int KSMAX>
+__global__ __launch_bounds__(256, (KSMAX > 4) ? 1 : 2) void conv_ksplit_epi4_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out, int ksplit, const float* __restrict__ kws) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, TM = 32 * WM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = a.hm * a.wm, M = a.n * hw;
+    const int ntiles = a.cout / 128;
+    const int lin = blockIdx.x >> 2, wmi = blockIdx.x & 3;
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 128;
+    const int r = lane & 31, h = lane >> 5;
+    // partial accumulators: [tile][run][wave][block * 4 + quad][lane] x 16 B (conv3x3_band_kernel / conv_band_prog_kernel)
+    const size_t run_stride = (size_t)WM * 16 * 64;
+    const float4* base = (const float4*)kws + (((size_t)lin * ksplit) * WM + wmi) * 16 * 64 + lane;
+    float4 v[KSMAX][4];
+    if constexpr (LSTM) {
+        const int q = wv;
+        const int m = m0 + wmi * 32 + r;
+        const bool mvalid = m < M;
+        const unsigned lstm_o = (unsigned)(mvalid ? m : 0) * (unsigned)a.hidden + (unsigned)((n0 >> 2) + 4 * h);
+        const f4 cprev = *(const f4*)(a.state + lstm_o + 8 * q);
+#pragma unroll
+        for (int s = 0; s < KSMAX; ++s) {
+            const size_t so = (size_t)(s < ksplit ? s : ksplit - 1) * run_stride;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v[s][g] = base[so + (g * 4 + q) * 64];
+        }
+        f4 gate[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s)
+                if (s < ksplit) { t[0] += v[s][g].x; t[1] += v[s][g].y; t[2] += v[s][g].z; t[3] += v[s][g].w; }
+            if constexpr (ARITH == 3 || ARITH == 4) t *= a.acc_scale;
+            gate[g] = t;
+        }
+        if (!mvalid) return;
+        f4 cn, hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {      // submodules.py:227-245, as epi_finish<4, true>
+            const float gi = sigmoid_t<true>(gate[0][j]);
+            const float gf = sigmoid_t<true>(gate[1][j]);
+            const float go = sigmoid_t<true>(gate[2][j]);
+            const float gc = tanh_t<true>(gate[3][j]);
+            cn[j] = __fadd_rn(__fmul_rn(gf, cprev[j]), __fmul_rn(gi, gc));
+            hn[j] = go * tanh_t<true>(cn[j]);
+        }
+        *(f4*)(a.state + lstm_o + 8 * q) = cn;
+        if (!a.out_packed) *(f4*)(a.out + lstm_o + 8 * q) = hn;
+        else store4_fmt<FMT>(a.out, (unsigned)m * (unsigned)a.hidden, (n0 >> 2) + 4 * h + 8 * q, hn);
+    } else {
+        const int nb = wv, n1 = n0 + nb * 32;
+        f32x16 acc[1], dummy[1], pre[1];
+        EpiCtx ec;
+        epi_setup<1, false, GROUPED>(a, m0 + wmi * 32 + r, M, hw, n1, h, dummy, pre, ec, true, false);      // (the bias sits in run 0's partials)
+#pragma unroll
+        for (int s = 0; s < KSMAX; ++s) {
+            const size_t so = (size_t)(s < ksplit ? s : ksplit - 1) * run_stride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[s][q] = base[so + (nb * 4 + q) * 64];
+        }
+        epi_prefetch<1, false, GROUPED>(a, n1, h, pre, ec);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s)
+                if (s < ksplit) { t[0] += v[s][q].x; t[1] += v[s][q].y; t[2] += v[s][q].z; t[3] += v[s][q].w; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][4 * q + j] = t[j];
+        }
+        epi_finish<1, false, GROUPED, true>(a, ec, n1, h, acc, pre, img_out);
+    }
+#endif
+}
+
+// the epilogue launch of a split-K convolution (ks runs per tile)
+template <bool LSTM, bool GROUPED>
+static void launch_ksplit_epilogue(const ConvArgs* d_args, float* img, int total, int ks, const float* kws, hipStream_t stream) {
+    static const int wide = getenv("EVR_KSPLIT_EPI4") ? atoi(getenv("EVR_KSPLIT_EPI4")) : 1;      // (A/B: 0 = one block per tile)
+    constexpr bool can4 = !(LSTM && ARITH == 4);      // (P6 tensors are written as whole 16-channel groups: the ConvLSTM quad form has no writer)
+    if constexpr (can4) if (wide) {
+        if (ks <= 4) hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 4>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws);
+        else hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 8>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws);
+        return;
+    }
+    hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<LSTM, GROUPED>), dim3(total), dim3(256), 0, stream, d_args, img, ks, kws);
+}
+
 // workspace of the split-K launches: ConvArgs::ksplit_ws, KSPLIT_WS_BYTES owned by the handle (model / LPIPS) whose plan this is --
 // allocated with the plan, freed with it, never touched in the launch path (no hipMalloc / synchronisation here: a step can be
 // captured into a hipGraph, and two devices or two handles never share partial sums)
@@ -1055,11 +1153,13 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
         kws = ksplit_workspace(a, (size_t)total * ks * 4 * 16 * 64 * sizeof(float4));
         if (!kws) ks = 1;
     }
+    // (round 5: the 3-slot weight ring -- tiles requested TWO steps ahead, 84 KB of LDS -- for the split launches, which have one
+    // block per CU and nobody to hide a DMA latency behind: 2095 vs 2206 frames/s at one sequence, 3856 vs 3944 at four.  Not kept.)
     if (ks > 1) hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES, true>), dim3(total * ks), dim3(64 * WM), 0, stream, d_args, img, ks, kws);
     else hipLaunchKernelGGL((conv3x3_band_kernel<WM, RING, LSTM, GROUPED, OVL, PHASES, false>), dim3(total), dim3(64 * WM), 0, stream, d_args, img, 1, (float*)nullptr);
     EVR_LAUNCH_CHECK();
     if (ks > 1) {
-        hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<LSTM, GROUPED>), dim3(total), dim3(256), 0, stream, d_args, img, ks, (const float*)kws);
+        launch_ksplit_epilogue<LSTM, GROUPED>(d_args, img, total, ks, (const float*)kws, stream);
         EVR_LAUNCH_CHECK();
     }
     return EVR_OK;
@@ -2025,7 +2125,7 @@ static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream
         if (ks > 1) {
             hipLaunchKernelGGL((conv_band_prog_kernel<NB, true>), dim3(total * ks), dim3(256), 0, stream, d_args, img, ks, kws);
             EVR_LAUNCH_CHECK();
-            hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<false, false>), dim3(total), dim3(256), 0, stream, d_args, img, ks, (const float*)kws);
+            launch_ksplit_epilogue<false, false>(d_args, img, total, ks, (const float*)kws, stream);
             EVR_LAUNCH_CHECK();
             return EVR_OK;
         }

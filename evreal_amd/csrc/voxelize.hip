@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "common.h"
 
@@ -86,13 +87,13 @@ template <bool RAW>
 __global__ __launch_bounds__(K1T) void vox_split_kernel(
     EventSrc src, const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end,
     const int64_t* __restrict__ rec_base, float4* __restrict__ rec, int* __restrict__ table, VoxHeader* hdr,
-    int S, int G, int rows, unsigned rows_magic, int B, int H, int W) {
+    int S, int G, int rows, unsigned rows_magic, int B, int H, int W, int w0) {
     extern __shared__ int smem[];
     int* hist = smem;                  // [K1W][G]  per-wave counts, then exclusive offsets of the wave inside its range
     int* bbase = smem + K1W * G;       // [G + 1]   first record of each range inside the segment
     int* wsum = bbase + G + 1;         // [K1W]
 
-    const int w = blockIdx.x / S, s0 = blockIdx.x % S;
+    const int w = w0 + blockIdx.x / S, s0 = blockIdx.x % S;      // (w0: first window of this launch's chunk, voxelize_impl)
     const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;
     const int64_t a = win_begin[w];
     const int64_t ne = win_end[w] - a;
@@ -248,9 +249,11 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end, const int64_t* __restrict__ rec_base,
     const float4* __restrict__ rec, const int* __restrict__ table, float* __restrict__ out,
     double* __restrict__ partials, VoxHeader* hdr, int n_windows, int G, int rows, int Rp, int B, int H, int W, int vec_out, int xcd_map,
-    unsigned rq_magic) {
+    unsigned rq_magic, int w0, int publish) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {       // K1 has finished (kernel boundary): publish its count, re-arm the counter
+    // (n_windows: END of this launch's chunk [w0, n_windows); publish: the call's LAST range launch -- every split launch of the call
+    // has finished by then, voxelize_impl orders them with events)
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {       // K1 has finished (kernel boundary): publish its count, re-arm the counter
         hdr->dropped_last = hdr->dropped_acc;
         hdr->dropped_total += hdr->dropped_acc;
         hdr->dropped_acc = 0;
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     int w, g;
     if (xcd_map) {      // blocks b, b+8, b+16, ... run on one XCD: give them the ranges of the same windows
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        w = (slot / G) * 8 + xcd; g = slot % G;
+        w = w0 + (slot / G) * 8 + xcd; g = slot % G;
     } else {
-        w = blockIdx.x / G; g = blockIdx.x % G;
+        w = w0 + blockIdx.x / G; g = blockIdx.x % G;
     }
     if (w >= n_windows) return;
     const int64_t HW = (int64_t)H * W;
@@ -497,6 +500,28 @@ bool make_plan(int64_t n_events_total, int n_windows, int B, int H, int W, VoxPl
     return true;
 }
 
+// internal second stream of the chunked form (voxelize_impl), one per device, created on first use and kept for the process
+constexpr int MAX_CHUNKS = 16;
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr; hipEvent_t done[MAX_CHUNKS] = {}; };
+SideStream* side_stream(int dev) {
+    static SideStream pool[64];
+    static std::atomic<int> state[64];      // 0 none, 1 being created, 2 ready, 3 failed
+    if (dev < 0 || dev >= 64) return nullptr;
+    int st = state[dev].load(std::memory_order_acquire);
+    if (st == 2) return &pool[dev];
+    if (st == 3) return nullptr;
+    int expect = 0;
+    if (!state[dev].compare_exchange_strong(expect, 1)) {      // another thread is creating it: this call runs unchunked
+        return state[dev].load(std::memory_order_acquire) == 2 ? &pool[dev] : nullptr;
+    }
+    SideStream& p = pool[dev];
+    bool ok = hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < MAX_CHUNKS; ++i) ok = hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming) == hipSuccess;
+    state[dev].store(ok ? 2 : 3, std::memory_order_release);
+    return ok ? &p : nullptr;
+}
+
 int split_groups_env() {
     const char* e = getenv("EVR_VOX_SPLIT");       // tuning knob: split workgroups per window
     return e ? atoi(e) : 0;
@@ -544,20 +569,62 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     }
     // floor(y / rows) = umulhi(y, magic) for y < 2^16 (rows == 1: magic would not fit 32 bits -> 0 = identity)
     const unsigned rows_magic = pl.rows == 1 ? 0u : (unsigned)((0x100000000ULL + pl.rows - 1) / pl.rows);
-    hipLaunchKernelGGL(vox_split_kernel<RAW>, dim3((unsigned)n_windows * S), dim3(K1T), pl.lds1, stream, src, win_begin,
-                       win_end, rec_base, rec, table, hdr, S, pl.G, pl.rows, rows_magic, B, H, W);
-    EVR_LAUNCH_CHECK();
     const int64_t HW = (int64_t)H * W;
     const int vec_out = (HW % 4 == 0) && (((int64_t)pl.rows * W) % 4 == 0 || pl.G == 1) && (((uintptr_t)out & 15) == 0);
     // flush index -> (bin, group) by multiply-high: groups per bin of a full range; exact for every index < B * Rq <= 2^15
     const unsigned rq_full = (unsigned)(((int64_t)pl.rows * W) >> 2);
     const unsigned rq_magic = (vec_out && rq_full >= 2 && (int64_t)B * HW < (1LL << 31)) ? (unsigned)((0x100000000ULL + rq_full - 1) / rq_full) : 0u;
     const int xcd_map = n_windows >= 8;
-    const int64_t blocks = xcd_map ? (int64_t)((n_windows + 7) / 8) * 8 * pl.G : (int64_t)n_windows * pl.G;
-    EVR_REQUIRE(blocks < (1LL << 31), "evr_voxelize: %d windows x %d ranges exceed the grid", n_windows, pl.G);
-    hipLaunchKernelGGL(vox_range_kernel<RAW>, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
-                       rec, table, out, partials, hdr, n_windows, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic);
-    EVR_LAUNCH_CHECK();
+    EVR_REQUIRE((int64_t)((n_windows + 7) / 8) * 8 * pl.G < (1LL << 31), "evr_voxelize: %d windows x %d ranges exceed the grid", n_windows, pl.G);
+    // The split kernel is bound by latency (one load round trip, ballot ranks, a prefix: ~25 % of a call at 346x260 where a window has
+    // many events per output byte), the range kernel by its store bursts -- they use different parts of a CU.  A VERY large call is cut
+    // into chunks of windows: the split of chunk c + 1 runs on an internal second stream UNDER the range launch of chunk c (events
+    // order split c -> range c; the chunks' records, table rows and output slices are disjoint).  Measured (round 5, 346x260, 15k
+    // events per window, us per call for 1 / 2 / 4 / 8 chunks): 64 windows 66 / 88 / 93 / 140, 512 windows 279 / 289 / 291 / 333,
+    // 2048 windows 1171 / 1081 / 1099 / 1090 -- the cross-stream hand-offs cost more than the overlap returns until a chunk is
+    // ~1000 windows, so: two chunks from 2048 windows on, one below.  EVR_VOX_CHUNKS=<n> forces a count.
+    static const int chunks_env = getenv("EVR_VOX_CHUNKS") ? atoi(getenv("EVR_VOX_CHUNKS")) : 0;
+    int C = chunks_env > 0 ? chunks_env : (n_windows >= 2048 ? 2 : 1);
+    if (C > MAX_CHUNKS) C = MAX_CHUNKS;
+    if (C > n_windows / 8) C = n_windows / 8 > 0 ? n_windows / 8 : 1;
+    SideStream* ss = nullptr;
+    if (C > 1) {
+        ss = side_stream(dev);
+        if (!ss) C = 1;
+    }
+    auto launch_split = [&](hipStream_t st, int w0, int w1) {
+        hipLaunchKernelGGL(vox_split_kernel<RAW>, dim3((unsigned)(w1 - w0) * S), dim3(K1T), pl.lds1, st, src, win_begin,
+                           win_end, rec_base, rec, table, hdr, S, pl.G, pl.rows, rows_magic, B, H, W, w0);
+    };
+    auto launch_range = [&](int w0, int w1, int publish) {
+        const int nw = w1 - w0;
+        const int64_t blocks = xcd_map ? (int64_t)((nw + 7) / 8) * 8 * pl.G : (int64_t)nw * pl.G;
+        hipLaunchKernelGGL(vox_range_kernel<RAW>, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
+                           rec, table, out, partials, hdr, w1, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic, w0, publish);
+    };
+    if (C <= 1) {
+        launch_split(stream, 0, n_windows);
+        EVR_LAUNCH_CHECK();
+        launch_range(0, n_windows, 1);
+        EVR_LAUNCH_CHECK();
+    } else {
+        static std::mutex mu;      // the side stream and its events are per device, shared by every caller: one enqueue at a time
+        std::lock_guard<std::mutex> lock(mu);
+        // the side stream joins behind the caller's earlier work (a previous call's range launch may still read this workspace)
+        EVR_HIP(hipEventRecord(ss->fork, stream));
+        EVR_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+        const int per = ((n_windows + C - 1) / C + 7) / 8 * 8;      // chunk sizes in multiples of 8 windows (the XCD map of the range kernel)
+        int c = 0;
+        for (int w0 = 0; w0 < n_windows; w0 += per, ++c) {
+            const int w1 = w0 + per < n_windows ? w0 + per : n_windows;
+            launch_split(ss->s, w0, w1);
+            EVR_LAUNCH_CHECK();
+            EVR_HIP(hipEventRecord(ss->done[c], ss->s));
+            EVR_HIP(hipStreamWaitEvent(stream, ss->done[c], 0));
+            launch_range(w0, w1, w1 == n_windows ? 1 : 0);
+            EVR_LAUNCH_CHECK();
+        }
+    }
     if (stats) {
         hipLaunchKernelGGL(vox_stats_kernel, dim3(n_windows), dim3(256), 0, stream, partials, stats, pl.G);
         EVR_LAUNCH_CHECK();
