@@ -227,6 +227,141 @@ __global__ __launch_bounds__(PCT_THREADS) void pct_select_kernel(const float* __
     if (threadIdx.x == 0) vals[(int64_t)blockIdx.y * 4 + sel] = x;
 }
 
+// ---- round 5: the same two order statistics in ONE pass over the image -----------------------------------------------------------
+// radix_select above reads the image once per radix level (four passes, each eleven dependent L2 round trips of eight loads per
+// thread: ~25 us per pass, 108 us per 64-frame launch).  Here a work-group (one per percentile and image, as above):
+//   1. reads PCT_S evenly spaced SAMPLE keys into LDS and selects two of their order statistics around the target rank (4 sigma of
+//      the sample rank's binomial spread + a margin) -- thresholds lo_t <= hi_t that bracket the wanted keys with near certainty;
+//   2. makes ONE pass over the image (16-B loads, four in flight per thread): counts the keys below lo_t and compacts the keys in
+//      [lo_t, hi_t] into LDS (wave-aggregated slot allocation: order is irrelevant for a selection);
+//   3. CHECKS the bracket -- below <= prev and next < below + candidates, list not overflowed -- and then selects ranks prev - below
+//      and next - below among the ~1000 candidates in LDS.  The answer is exact whenever the check passes; otherwise (a constant
+//      image, a pathological distribution) the work-group falls back to the four-pass select.  Nothing is approximate.
+constexpr int PCT_S = 4096;        // sample keys
+constexpr int PCT_CAP = 8192;      // candidate keys kept in LDS (32 KB; shares its space with the sample)
+struct PctFast {
+    unsigned list[PCT_CAP];
+    unsigned hist[256];
+    unsigned bcast[2];
+    unsigned wsum[16];
+    unsigned count, below, overflow;
+};
+// k-th smallest (0-based) of list[0..m) in LDS: MSB-first 8-bit radix select, every thread of the work-group takes part
+__device__ __forceinline__ unsigned lds_select(const unsigned* list, int m, int k, PctFast& sh) {
+    unsigned prefix = 0, pmask = 0;
+    int kk = k;
+    for (int level = 0; level < 4; ++level) {
+        const int shift = 24 - 8 * level;
+        __syncthreads();
+        if (threadIdx.x < 256) sh.hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int mr = (m + PCT_THREADS - 1) / PCT_THREADS * PCT_THREADS;      // whole waves take every trip: hist_add ballots
+        for (int i = threadIdx.x; i < mr; i += PCT_THREADS) {
+            const bool in = i < m;
+            const unsigned key = in ? list[i] : 0u;
+            hist_add(sh.hist, (key >> shift) & 255u, in && (key & pmask) == prefix, level == 0);
+        }
+        __syncthreads();
+        unsigned c = 0, incl = 0;
+        if (threadIdx.x < 256) {
+            c = sh.hist[threadIdx.x];
+            incl = c;
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) sh.wsum[threadIdx.x >> 6] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            unsigned base = 0;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += sh.wsum[w];
+            const unsigned excl = base + incl - c;
+            if (c > 0 && (unsigned)kk >= excl && (unsigned)kk < excl + c) { sh.bcast[0] = threadIdx.x; sh.bcast[1] = excl; }
+        }
+        __syncthreads();
+        prefix |= sh.bcast[0] << shift;
+        pmask |= 255u << shift;
+        kk -= (int)sh.bcast[1];
+    }
+    __syncthreads();
+    return prefix;
+}
+
+// n % 4 == 0 and 16-B aligned images (checked by the launcher).  vals[image][4] = {lo.prev, lo.next, hi.prev, hi.next}
+__global__ __launch_bounds__(PCT_THREADS) void pct_select_fast_kernel(const float* __restrict__ img, int n, float q_lo, float q_hi,
+                                                                       float* __restrict__ vals) {
+    __shared__ PctFast sh;
+    __shared__ PctShared shs;       // the fallback's histograms
+    const float* v = img + (int64_t)blockIdx.y * n;
+    const int which = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int prev, next; float gamma;
+    pct_rank(n, which ? q_hi : q_lo, prev, next, gamma);
+    if (tid == 0) { sh.count = 0; sh.below = 0; sh.overflow = 0; }
+    // ---- 1. sample -> thresholds
+    const int S = n < PCT_S ? n : PCT_S;
+    for (int j = tid; j < S; j += PCT_THREADS) sh.list[j] = f2key(v[(int)(((long long)j * n) / S)]);
+    const float sr = (float)prev * (float)S / (float)n;                       // expected sample rank of the target
+    const float var = sr * (1.0f - sr / (float)S);
+    const int d = 24 + (int)(4.0f * sqrtf(var > 0.f ? var : 0.f));
+    const int r_lo = (int)sr - d, r_hi = (int)sr + d + 1;
+    __syncthreads();
+    const unsigned lo_t = r_lo <= 0 ? 0u : lds_select(sh.list, S, r_lo, sh);
+    const unsigned hi_t = r_hi >= S - 1 ? 0xFFFFFFFFu : lds_select(sh.list, S, r_hi, sh);
+    __syncthreads();                                                          // the sample is dead: its space becomes the candidate list
+    // ---- 2. one pass: count below, compact the bracket
+    unsigned below = 0;
+    const float4* v4 = (const float4*)v;
+    const int n4 = n >> 2;
+    for (int i0 = 0; i0 < n4; i0 += PCT_THREADS * 4) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PCT_THREADS + tid;
+            x[u] = (i < n4) ? v4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = i0 + u * PCT_THREADS + tid < n4;
+            const float e[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned key = f2key(e[c]);
+                below += (in && key < lo_t) ? 1u : 0u;
+                const bool cand = in && key >= lo_t && key <= hi_t;
+                const unsigned long long m = __ballot(cand);
+                if (m) {                                                      // wave-uniform
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&sh.count, (unsigned)__popcll(m));
+                    base = (unsigned)__shfl((int)base, 0, 64);
+                    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (cand) { if (pos < (unsigned)PCT_CAP) sh.list[pos] = key; else sh.overflow = 1u; }
+                }
+            }
+        }
+    }
+    below = (unsigned)evr_wave_sum((float)below);                             // (< 2^24 per wave: exact in fp32)
+    if (lane == 0) atomicAdd(&sh.below, below);
+    __syncthreads();
+    const int nb = (int)sh.below, nc = (int)sh.count;
+    const bool ok = !sh.overflow && nb <= prev && next < nb + nc;             // block-uniform
+    float a, b;
+    if (ok) {
+        a = key2f(lds_select(sh.list, nc, prev - nb, sh));
+        b = (next == prev) ? a : key2f(lds_select(sh.list, nc, next - nb, sh));
+    } else {
+        if (tid < 4) shs.level_valid[tid] = 0;
+        __syncthreads();
+        const unsigned keys[PCT_MAXR] = {0u};
+        a = key2f(radix_select<false>(keys, 0, v, n, prev, shs));
+        b = (next == prev) ? a : key2f(radix_select<false>(keys, 0, v, n, next, shs));
+    }
+    if (tid == 0) { vals[(int64_t)blockIdx.y * 4 + 2 * which] = a; vals[(int64_t)blockIdx.y * 4 + 2 * which + 1] = b; }
+}
+
 __global__ __launch_bounds__(256) void pct_exp_kernel(float* __restrict__ img, int64_t total) {      // 'exprobust' (eval.py:391-393)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) img[i] = expf(img[i]);
 }
@@ -308,7 +443,13 @@ extern "C" int evr_percentile_normalize(float* img, int n, int H, int W, float q
     // two work-groups per image (one per percentile, both ranks each) instead of four (one per rank): half the image passes;
     // +0.3 .. +0.5 % on the headline in three A/B pairs on one box.  EVR_PCT_PAIR=0 restores the four-work-group form.
     static const int pair = [] { const char* e = getenv("EVR_PCT_PAIR"); return e ? atoi(e) : 1; }();
-    hipLaunchKernelGGL(pct_select_kernel, dim3(pair ? 2 : 4, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace, pair);
+    // round 5: the one-pass sampled-bracket select (exact: the bracket is verified, the four-pass select is its fallback);
+    // EVR_PCT_FAST=0 restores the four-pass form
+    static const int fast = [] { const char* e = getenv("EVR_PCT_FAST"); return e ? atoi(e) : 1; }();
+    if (fast && px % 4 == 0 && px >= 1024 && (((uintptr_t)img) & 15) == 0)
+        hipLaunchKernelGGL(pct_select_fast_kernel, dim3(2, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace);
+    else
+        hipLaunchKernelGGL(pct_select_kernel, dim3(pair ? 2 : 4, n), dim3(PCT_THREADS), 0, stream, img, px, q_lo, q_hi, (float*)workspace, pair);
     EVR_LAUNCH_CHECK();
     int gx = (px + 256 * 8 - 1) / (256 * 8);
     if (gx < 1) gx = 1;
