@@ -287,20 +287,26 @@ __global__ __launch_bounds__(256) void lpips_score_kernel(const ScoreArgs sa, in
     if (threadIdx.x == 0) partials[(int64_t)b * blocks_per_img + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-__global__ void lpips_final_kernel(const double* __restrict__ partials, double* __restrict__ out, int blocks_per_img, int nlayers,
+// one wave per image: lanes stride over a layer's partial sums, fixed-order tree (deterministic), layers added in order
+// (round 5: one THREAD per image walked 5 x blocks_per_img dependent loads -- 19 us of a one-sequence frame's evaluation chain)
+__global__ __launch_bounds__(64) void lpips_final_kernel(const double* __restrict__ partials, double* __restrict__ out, int blocks_per_img, int nlayers,
                                    int n, const int* __restrict__ hw) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n) return;
     double total = 0.0;
     for (int l = 0; l < nlayers; ++l) {
         double s = 0.0;
-        for (int k = 0; k < blocks_per_img; ++k) s += partials[((int64_t)l * n + b) * blocks_per_img + k];
+        for (int k = lane; k < blocks_per_img; k += 64) s += partials[((int64_t)l * n + b) * blocks_per_img + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         total += s / (double)hw[l];
     }
-    out[b] = total;
+    if (lane == 0) out[b] = total;
 }
 
-constexpr int SCORE_BLOCKS = 32;
+// work-groups per image and layer of the score kernel: 32 at 64 images (2048 per launch); a small batch takes more of them -- at one
+// image 32 work-groups walked relu1's 5440 pixels in eleven dependent rounds (16 us per layer)
+constexpr int SCORE_BLOCKS_MAX = 256;
+static int score_blocks(int n) { int b = 2048 / (n > 0 ? n : 1); return b < 32 ? 32 : (b > SCORE_BLOCKS_MAX ? SCORE_BLOCKS_MAX : b); }
 
 struct Layer { int cin, cout, k, pad; int x3 = 0; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
 
@@ -461,7 +467,7 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
     for (int l = 0; l < 5; ++l) if ((rc = dalloc(m, &m->feat[l], (size_t)n2 * m->h[l] * m->w[l] * C[l]))) return rc;
     if ((rc = dalloc(m, &m->pool1, (size_t)n2 * hp1 * wp1 * 64))) return rc;
     if ((rc = dalloc(m, &m->pool2, (size_t)n2 * hp2 * wp2 * 192))) return rc;
-    if ((rc = dalloc(m, &m->partials, (size_t)5 * n * SCORE_BLOCKS))) return rc;
+    if ((rc = dalloc(m, &m->partials, (size_t)5 * n * SCORE_BLOCKS_MAX))) return rc;
     if ((rc = dalloc(m, &m->d_hw, 8))) return rc;
     int hw[5]; for (int l = 0; l < 5; ++l) hw[l] = m->h[l] * m->w[l];
     EVR_HIP(hipMemcpy(m->d_hw, hw, sizeof(hw), hipMemcpyHostToDevice));
@@ -543,9 +549,10 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     static const int score_split = getenv("EVR_LPIPS_SCORE_SPLIT") ? atoi(getenv("EVR_LPIPS_SCORE_SPLIT")) : 1;
     const int C[5] = {64, 192, 384, 256, 256};
     ScoreArgs sa;
+    const int sblocks = score_blocks(n);
     for (int l = 0; l < 5; ++l) { sa.feat[l] = m->feat[l]; sa.lin[l] = m->d_lin[l]; sa.hw[l] = m->h[l] * m->w[l]; sa.C[l] = C[l]; sa.packed[l] = l > 0 ? pk : 0; }
     auto score = [&](int l0, int nl) -> int {
-        hipLaunchKernelGGL(lpips_score_kernel, dim3(SCORE_BLOCKS, n, nl), dim3(256), 0, stream, sa, n, m->partials, SCORE_BLOCKS, l0);
+        hipLaunchKernelGGL(lpips_score_kernel, dim3(sblocks, n, nl), dim3(256), 0, stream, sa, n, m->partials, sblocks, l0);
         EVR_LAUNCH_CHECK();
         return EVR_OK;
     };
@@ -559,7 +566,7 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
         if (score_split && (rc = score(i + 1, 1))) return rc;
     }
     if (!score_split && (rc = score(0, 5))) return rc;
-    hipLaunchKernelGGL(lpips_final_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, m->partials, out, SCORE_BLOCKS, 5, n, m->d_hw);
+    hipLaunchKernelGGL(lpips_final_kernel, dim3(n), dim3(64), 0, stream, m->partials, out, sblocks, 5, n, m->d_hw);
     EVR_LAUNCH_CHECK();
     return EVR_OK;
 }

@@ -386,7 +386,7 @@ def test_exact_twin_is_the_reference_arithmetic_without_a_range_limit():
     sd = weights.rescale_encoder_conv(weights.synth_state_dict(weights.unet_recurrent_schema(**kw), seed=21), enc=1, K=65536.0)
     m = model.E2VIDRecurrent(kw); m.load_state_dict(sd)
     twin = m.exact_twin()
-    assert twin.arith == 'fp32' and twin.exact_twin() is twin and m.exact_twin() is twin
+    assert twin.arith == 'fp32' and twin.exact_twin() is twin and m.exact_twin() is twin and (twin is m) == (m.arith == 'fp32')
     okeys = ['num_bins', 'base_num_channels', 'num_encoders', 'num_residual_blocks', 'kernel_size', 'norm', 'use_upsample_conv',
              'recurrent_block_type', 'final_activation']
     o = omod.UNetRecurrentOracle({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, **{k: kw[k] for k in okeys})
@@ -400,12 +400,16 @@ def test_exact_twin_is_the_reference_arithmetic_without_a_range_limit():
         with torch.no_grad():
             want = crop.crop(o(torch.from_numpy(crop.pad(vox[f:f + 1]))).numpy())
         worst_twin = max(worst_twin, float(np.abs(twin(x)['image'].cpu().numpy() - want).max()))
-        worst_m = max(worst_m, float(np.abs(m(x)['image'].cpu().numpy() - want).max()))
+        if twin is not m:        # (EVR_FP32=1: the model is its own twin -- one step per frame)
+            worst_m = max(worst_m, float(np.abs(m(x)['image'].cpu().numpy() - want).max()))
     assert worst_twin < 1e-5, worst_twin
     assert twin.saturation()[0] == 0
-    if m.arith != 'fp32':
+    if m.arith in ('h3', 'mx'):      # fixed-range formats: the excursion is reported (and evaluate() re-runs on the twin)
         runs, layer = m.saturation()
         assert runs > 0 and layer == 'enc1.conv', (runs, layer, worst_m)
+    elif m.arith == 'mx6':           # P6 scales every 16-channel group by its own maximum: 2e4 is inside the half-precision range
+        runs, layer = m.saturation()
+        assert runs > 0 or worst_m < 1e-4, (runs, layer, worst_m)
 
 
 def test_arithmetic_is_narrowed_per_layout():
