@@ -94,7 +94,7 @@ def test_drift_100_frames_346x260_8_sequences():
     print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
 
 
-def test_drift_100_frames_346x260_one_sequence_split_k():
+def test_one_sequence_split_k_100_frames_346x260():
     """The reference's own operating point -- ONE sequence, batch 1 (eval.py:72) -- runs the deep layers (12 tiles of 128 pixels at
     33 x 44) through the split-K forms of the band kernels (conv.hip launch_band / launch_band_prog: up to four blocks per tile, partial
     sums through the model's workspace, conv_ksplit_epilogue_kernel): 100 recurrent frames at 346x260 against the oracle, states at
@@ -115,7 +115,7 @@ def test_one_sequence_without_split_k():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, EVR_KSPLIT='0', EVR_TEST_SPLITK_FRAMES='12')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        'tests/test_gpu_fullsize.py::test_drift_100_frames_346x260_one_sequence_split_k'],
+                        'tests/test_gpu_fullsize.py::test_one_sequence_split_k_100_frames_346x260'],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
