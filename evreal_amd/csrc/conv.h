@@ -43,6 +43,8 @@ struct ConvTaps {
     int tap_groups[MAX_TAPS];   // bitmask over column groups
     int ngroups, grp_cols;      // columns per group (multiple of 32); ngroups*grp_cols == cout
     int grp_ofy[MAX_PHASES], grp_ofx[MAX_PHASES];   // output pixel = (my*os + ofy[g], mx*os + ofx[g])
+    int inter;                  // 1: the four phases are interleaved per 128-column tile (round 5; grp_cols == 32, ngroups == 4): column
+                                //   col = phase (col / 32) % 4, channel (col / 128) * 32 + col % 32 -- every tile then uses all nine taps
     void set_tap(int i, int dy, int dx, int groups) { tap[i] = (dy & 0xffff) | (dx * 65536); tap_groups[i] = groups; }
 };
 

@@ -191,11 +191,17 @@ __device__ __forceinline__ void st4(float* p, unsigned row, int c4, f4 v, int pa
     if (packed) store4_fmt<FMT>(p, row, c4, v);
     else *(f4*)(p + row + (unsigned)c4) = v;
 }
+// column group (sub-pixel phase) of the 32-column block that starts at GEMM column `col`, and the block's first channel inside
+// that group.  Phase-major N (tp.inter == 0): group = col / grp_cols.  Tile-interleaved N (tp.inter == 1, round 5: transposed
+// decoders with more than 32 output channels): a 128-column tile holds the four phases of 32 channels -- with whole groups per
+// tile, three of four tiles of dec0 walked steps whose taps their phase never uses (barrier, weight DMA and all)
+__device__ __forceinline__ int col_group(const ConvTaps& tp, int col) { return tp.inter ? ((col >> 5) & 3) : col / tp.grp_cols; }
+__device__ __forceinline__ int col_chan(const ConvTaps& tp, int col, int g) { return tp.inter ? (((col >> 7) << 5) + (col & 31)) : col - g * tp.grp_cols; }
 // output pixel and first channel (inside its column group) of the lane in 32-column block nb
 template <bool GROUPED>
 __device__ __forceinline__ void out_addr(const ConvArgs& a, const EpiCtx& ec, int n0, int h, int nb, unsigned& opx, int& cgb, int& oy, int& ox) {
-    const int g = GROUPED ? (n0 + nb * 32) / a.tp.grp_cols : 0;
-    cgb = n0 + nb * 32 - g * a.tp.grp_cols + 4 * h;
+    const int g = GROUPED ? col_group(a.tp, n0 + nb * 32) : 0;
+    cgb = (GROUPED ? col_chan(a.tp, n0 + nb * 32, g) : n0 + nb * 32) + 4 * h;
     oy = ec.e_my * a.os + a.tp.grp_ofy[g]; ox = ec.e_mx * a.os + a.tp.grp_ofx[g];
     opx = ec.direct ? (unsigned)ec.m : (unsigned)((ec.e_img * a.hout + oy) * a.wout + ox);
 }
@@ -546,10 +552,9 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0) ? ((WM == 4 && !LSTM) ? 2 : 1) :
     const int m0 = mtile * 32 * WM, n0 = ntile * 32 * NB;
 
     // column groups (sub-pixel phases of a transposed conv) covered by this N tile -> taps this block needs
-    const int grp_cols = tp.grp_cols;
     int tile_groups = 0;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0 + nb * 32) / grp_cols);
+    for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << col_group(tp, n0 + nb * 32);
     unsigned act_taps = (1u << tp.ntaps) - 1u;     // ntaps <= 25
     if constexpr (GROUPED) {
         act_taps = 0;
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0) ? ((WM == 4 && !LSTM) ? 2 : 1) :
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if constexpr (GROUPED) {
-                    if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
+                    if (!((groups_now >> col_group(tp, n0 + nb * 32)) & 1)) continue;   // wave-uniform: zero weight block
                 }
                 const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
                 acc[nb] = mma_split(acc[nb], wb, xa, mx_sb, mx_sa);
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(64 * WM, (X3 == 0) ? ((WM == 4 && !LSTM) ? 2 : 1) :
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 if constexpr (GROUPED) {
-                    if (!((groups_now >> ((n0 + nb * 32) / grp_cols)) & 1)) continue;   // wave-uniform: zero weight block
+                    if (!((groups_now >> col_group(tp, n0 + nb * 32)) & 1)) continue;   // wave-uniform: zero weight block
                 }
                 const float4 bv = lb[nb * 32 * SP + q];
                 // weights are the A operand (rows), activations the B operand (columns): acc = C^T (see epilogue)
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
     int tile_groups = 0;
     if constexpr (GROUPED) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0 + nb * 32) / a.tp.grp_cols);
+        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << col_group(a.tp, n0 + nb * 32);
     }
     auto tap_use = [&](int t) -> int { return GROUPED ? (a.tp.tap_groups[t] & tile_groups) : 1; };
     auto band_use = [&](int dyi) -> bool { return !GROUPED || (tap_use(3 * dyi) | tap_use(3 * dyi + 1) | tap_use(3 * dyi + 2)) != 0; };
@@ -1694,7 +1699,7 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
     int tile_groups = 0;         // phases of this wave's 128 columns, and per tap those that use it (conv3x3_band_kernel)
     if constexpr (GROUPED) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << ((n0w + nb * 32) / a.tp.grp_cols);
+        for (int nb = 0; nb < NB; ++nb) tile_groups |= 1 << col_group(a.tp, n0w + nb * 32);
     }
     auto tap_use = [&](int t) -> int { return GROUPED ? (a.tp.tap_groups[t] & tile_groups) : 1; };
     auto neighbours = [&](int m) -> unsigned {   // validity of the pixel's 9 neighbours (bit t = tap (t/3 - 1, t%3 - 1))
@@ -2104,6 +2109,198 @@ __global__ __launch_bounds__(256, 2) void conv_band_prog_kernel(const ConvArgs* 
 #endif
 }
 
+// The same convolution on 256-pixel tiles (round 5): conv3x3_wide_kernel's twin form for the programmed walk.  A step of the
+// 128-pixel kernel above is 24 (NB = 4) or 12 (NB = 2) MFMA groups per wave between two barriers, and a step costs a block about
+// 2000 cycles whatever it holds (weight-tile DMA issue and latency, fragment reads, the barrier): these layers sat at 0.34-0.40
+// matrix-pipe-busy where the ConvLSTM twin kernel, with 48 groups per step, reaches 0.72 (measured at 64 sequences: enc0.conv 493
+// -> 469 us, enc1.conv 461 -> 461 -- the step cadence was not the whole story --, headline +0.7 %).  Here a wave owns TWO 32-pixel blocks
+// (64 pixels x 32 NB columns, a weight fragment read once feeds both), four waves = 256 pixels, ONE band buffer of 264 block rows
+// (33.8 KB) + the 2-slot weight ring: 66 KB (NB = 4) / 50 KB (NB = 2) -> two / three blocks per CU.  The band is refetched behind
+// the last step that reads it (barrier, request, wait, barrier -- the other block's MFMAs cover it), so the program's "request the
+// next band now" bits are read at the band's FIRST step (where they sit) and honoured at its LAST.  Plain epilogues only, and no
+// split K: this form is for launches that fill the chip (launch_band_prog).
+template <int NB>
+__global__ __launch_bounds__(256, 2) void conv_band_prog_wide_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int WM = 4, MB = 2, SP = 8, TM = 32 * MB * WM;          // 256 pixels
+    constexpr int A_ROWS = TM + 8, A_PIECES = A_ROWS / 8, A_F4 = A_ROWS * SP, B_F4 = 32 * NB * SP;
+    constexpr int NA_MAX = (A_PIECES + WM - 1) / WM, NA_MIN = A_PIECES / WM;      // 9 / 8 band pieces per wave
+    constexpr int NBW = (B_F4 / 64) / WM;                               // 4 / 2 weight-tile pieces per wave
+    static_assert((B_F4 / 64) % WM == 0 && NA_MIN == 8, "tile bookkeeping");
+    __shared__ __attribute__((aligned(16))) float4 lds[A_F4 + 2 * B_F4 + SP];      // [band | weight slot 0 | 1 | a zero row]
+    constexpr int ZROW = (A_F4 + 2 * B_F4) / SP;                        // row index of the zero row, counted from lds[0]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wb = a.wm, Hb = a.hm;                 // block grid = output grid
+    const int hw = Hb * Wb;
+    const int M = a.n * hw;
+    const int nrows = a.n * Hb;
+    const int ntiles = a.cout / (32 * NB);
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int ntile = lin % ntiles, mtile = lin / ntiles;
+    const int m0 = mtile * TM, n0 = ntile * 32 * NB;
+    const int C = a.c0;
+    const int nch2 = 4 * C / 32;                    // K chunks per tap in space-to-depth form
+    const int ktot = 9 * nch2 * 32;
+    const unsigned row_pitch = 2u * (unsigned)a.win * (unsigned)C, pix_pitch = 2u * (unsigned)C;   // floats
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, (unsigned)a.n * a.hin * a.win * (unsigned)C * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt2, (unsigned)a.cout * ktot * 4u);
+    const unsigned prog_lo = a.prog[lane], prog_hi = a.prog[64 + lane];      // the step program in two VGPRs (conv_band_prog_kernel)
+    auto entry = [&](int s) -> unsigned {
+        return s < 64 ? (unsigned)__builtin_amdgcn_readlane((int)prog_lo, s) : (unsigned)__builtin_amdgcn_readlane((int)prog_hi, s - 64);
+    };
+
+    // DMA pieces: piece j = wv + 4 jj covers band rows 8j .. 8j + 7 (lane -> row 8j + lane / 8, 16-B slot lane % 8).  A wave's pieces
+    // are 32 rows apart: one swizzle serves all of them; their (row, x) block coordinates are decoded per request -- nine multiply-
+    // highs per band, a band every two or three steps -- instead of living in eighteen registers this kernel does not have
+    const int row0 = 8 * wv + (lane >> 3);
+    const unsigned a_q0 = (unsigned)((((lane & 7) ^ swz<32>(row0)) * 4));
+    const unsigned b_off0 = (unsigned)((n0 + row0) * ktot) + a_q0;
+    auto issue_band = [&](int src, int dy) {
+        const int py = src & 1, px = (src >> 1) & 1, cc = src >> 2;
+        const unsigned choff = (unsigned)((py * a.win + px) * C + cc * 32) + a_q0;
+#pragma unroll
+        for (int jj = 0; jj < NA_MAX; ++jj) {
+            if (jj < NA_MIN || wv + jj * WM < A_PIECES) {      // wave-uniform
+                const int mb = m0 - 1 + row0 + 32 * jj;
+                unsigned voff = OOB_OFFSET;
+                if ((unsigned)mb < (unsigned)M) {
+                    const int rho = fdiv(mb, a.div_w_mul, a.div_w_sh), x = mb - rho * Wb;
+                    if ((unsigned)(rho + dy) < (unsigned)nrows) voff = ((unsigned)(rho + dy) * row_pitch + (unsigned)x * pix_pitch + choff) * 4u;
+                }
+                lds_ptr_t dst = (lds_ptr_t)&lds[(wv + jj * WM) * 64];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int kofs, int slot) {
+#pragma unroll
+        for (int jj = 0; jj < NBW; ++jj) {
+            lds_ptr_t dst = (lds_ptr_t)&lds[A_F4 + slot * B_F4 + (wv + jj * WM) * 64];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, b_off0 * 4u, ((unsigned)kofs + (unsigned)(8 * WM * jj * ktot)) * 4u, 0, 0);
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int sw = swz<32>(r);
+    f32x16 acc0[NB], acc1[NB];
+    f32x16 late[NB];
+    EpiCtx ec0, ec1;
+    const int mA = m0 + wv * 64 + r, mB = mA + 32;
+    epi_setup<NB, false, false>(a, mA, M, hw, n0, h, acc0, late, ec0, true, false);   // operands are loaded in the epilogue
+    epi_setup<NB, false, false>(a, mB, M, hw, n0, h, acc1, late, ec1, true, false);
+    auto neighbours = [&](int m) -> unsigned {   // validity of the 9 neighbour blocks of the lane's output pixel
+        unsigned vm = 0;
+        if (m < M) {
+            const int img = fdiv(m, a.div_hw_mul, a.div_hw_sh), rem = m - img * hw;
+            const int py = fdiv(rem, a.div_w_mul, a.div_w_sh), px = rem - py * Wb;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)Hb && (unsigned)xx < (unsigned)Wb) vm |= 1u << t;
+            }
+        }
+        return vm;
+    };
+    const unsigned vmask0 = neighbours(mA), vmask1 = neighbours(mB);
+    const int nsteps = a.prog_steps;
+    const int mx_sa = a.mx_sa, mx_sb = a.mx_sb;
+    auto kofs_of = [&](unsigned e) -> int { return (int)(((e & 15u) * (unsigned)nch2 + ((e >> 8) & 255u)) * 32u); };
+    {
+        const unsigned e0 = entry(0);
+        if (tid < SP) lds[A_F4 + 2 * B_F4 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        issue_band((int)((e0 >> 16) & 1023u), (int)((e0 >> 26) & 3u) - 1);
+        issue_w(kofs_of(entry(1)), 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    unsigned next_band = 0;      // bits 16-27 of the current band's first step: the band after it
+    for (int s = 1; s <= nsteps; ++s) {
+        const unsigned e = entry(s);
+        const int slot = (s - 1) & 1;
+        const unsigned e_next = s < nsteps ? entry(s + 1) : 0u;
+        if (s < nsteps) issue_w(kofs_of(e_next), slot ^ 1);
+        if (e & 16u) next_band = e;
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = (int)(e & 15u);
+        const int dxi = t - (t / 3) * 3;
+        int l0 = wv * 64 + r + dxi;                 // band row of the lane's (dx) neighbour block
+        asm volatile("" : "+v"(l0));
+        const int l1 = l0 + 32;
+        const int i0 = ((vmask0 >> t) & 1u) ? l0 : ZROW, i1 = ((vmask1 >> t) & 1u) ? l1 : ZROW;      // invalid neighbours read the zero row
+        const float4* lb = &lds[A_F4 + slot * B_F4 + r * SP];
+        const SplitFrag xa0 = ld_split(&lds[i0 * SP], h, swz<32>(l0));
+        const SplitFrag xa1 = ld_split(&lds[i1 * SP], h, swz<32>(l1));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const SplitFrag wb = ld_split(lb + nb * 32 * SP, h, sw);
+            acc0[nb] = mma_split(acc0[nb], wb, xa0, mx_sb, mx_sa);
+            acc1[nb] = mma_split(acc1[nb], wb, xa1, mx_sb, mx_sa);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (e_next & 16u) {      // this was the band's last step and everyone has left it: fetch the next one into the same buffer
+            issue_band((int)((next_band >> 16) & 1023u), (int)((next_band >> 26) & 3u) - 1);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    // plain epilogues, one pixel block at a time; the second block's accumulators wait in LDS (idle now), as in conv3x3_wide_kernel
+    float4* park = &lds[wv * (NB * 4 * 64)];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            park[(nb * 4 + q) * 64 + lane] = make_float4(acc1[nb][4 * q], acc1[nb][4 * q + 1], acc1[nb][4 * q + 2], acc1[nb][4 * q + 3]);
+    if constexpr (FMT != 3) {
+        {
+            f32x16 op4[NB];
+            epi_prefetch<NB, false, false>(a, n0, h, op4, ec0);
+            epi_finish<NB, false, false, true>(a, ec0, n0, h, acc0, op4, img_out);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            f32x16 op4[NB];
+            epi_prefetch<NB, false, false>(a, n0, h, op4, ec1);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = park[(nb * 4 + q) * 64 + lane];
+                    acc0[nb][4 * q] = v.x; acc0[nb][4 * q + 1] = v.y; acc0[nb][4 * q + 2] = v.z; acc0[nb][4 * q + 3] = v.w;
+                }
+            epi_finish<NB, false, false, true>(a, ec1, n0, h, acc0, op4, img_out);
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x16 one[1], op[1];
+            one[0] = acc0[nb];
+            epi_prefetch<1, false, false>(a, n0 + 32 * nb, h, op, ec0);
+            epi_finish<1, false, false, true>(a, ec0, n0 + 32 * nb, h, one, op, img_out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x16 one[1], op[1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = park[(nb * 4 + q) * 64 + lane];
+                one[0][4 * q] = v.x; one[0][4 * q + 1] = v.y; one[0][4 * q + 2] = v.z; one[0][4 * q + 3] = v.w;
+            }
+            epi_prefetch<1, false, false>(a, n0 + 32 * nb, h, op, ec1);
+            epi_finish<1, false, false, true>(a, ec1, n0 + 32 * nb, h, one, op, img_out);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
+}
+
 template <int NB>
 static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     const int M = a.n * a.hm * a.wm;
@@ -2117,6 +2314,16 @@ static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream
             if (ks > nbands / 2) ks = nbands / 2;
             if (ks > ks_max) ks = ks_max;
             if (ks < 2) ks = 1;
+        }
+    }
+    {   // 256-pixel tiles once a launch has enough of them to fill the chip (two or three blocks per CU; EVR_PROG_WIDE=0: never)
+        static const int pw_on = getenv("EVR_PROG_WIDE") ? atoi(getenv("EVR_PROG_WIDE")) : 1;
+        static const int pw_min = getenv("EVR_PROG_WIDE_MIN") ? atoi(getenv("EVR_PROG_WIDE_MIN")) : 1024;
+        const int total2 = ((M + 255) / 256) * (a.cout / (32 * NB));
+        if (pw_on && total2 >= pw_min && ks == 1) {
+            hipLaunchKernelGGL((conv_band_prog_wide_kernel<NB>), dim3(total2), dim3(256), 0, stream, d_args, img);
+            EVR_LAUNCH_CHECK();
+            return EVR_OK;
         }
     }
     float* kws = nullptr;
@@ -2168,7 +2375,9 @@ using namespace EVR_ANS;
 
 int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
     EVR_REQUIRE(!a.pred_w || (a.cout == 32 * nb && img), "conv_igemm: fused prediction needs a single N tile and an image pointer");
-    EVR_REQUIRE(a.tp.grp_cols % 32 == 0 && a.tp.ngroups * a.tp.grp_cols == a.cout && a.tp.ngroups <= MAX_PHASES, "conv_igemm: bad column groups");
+    EVR_REQUIRE(a.tp.grp_cols % 32 == 0 && a.tp.ngroups <= MAX_PHASES &&
+                (a.tp.inter ? (a.tp.ngroups == 4 && a.tp.grp_cols == 32 && a.cout % 128 == 0 && !a.pred_w) : a.tp.ngroups * a.tp.grp_cols == a.cout),
+                "conv_igemm: bad column groups");
     EVR_REQUIRE(a.cout % (32 * nb) == 0, "conv_igemm: cout %d not a multiple of %d", a.cout, 32 * nb);
     EVR_REQUIRE(a.c0 % kc == 0 && (a.in_mode != IN_CAT || a.c1 % kc == 0), "conv_igemm: channels %d/%d not multiples of %d", a.c0, a.c1, kc);
     EVR_REQUIRE(a.epi != EPI_LSTM || nb == 4, "conv_igemm: the LSTM epilogue needs nb == 4");

@@ -561,10 +561,13 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
     if (score_split && (rc = score(1, 1))) return rc;
     if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2], pk))) return rc;
+    // (relu3 .. relu5 are 69 MB together at 64 frames -- they outlive their convolutions in the Infinity Cache -- so ONE launch scores
+    // the three of them behind conv5 (grid.z = layer): two launches fewer on the evaluation stream; EVR_LPIPS_SCORE_SPLIT=2: one each)
     for (int i = 1; i < 4; ++i) {
         if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
-        if (score_split && (rc = score(i + 1, 1))) return rc;
+        if (score_split == 2 && (rc = score(i + 1, 1))) return rc;
     }
+    if (score_split == 1 && (rc = score(2, 3))) return rc;
     if (!score_split && (rc = score(0, 5))) return rc;
     hipLaunchKernelGGL(lpips_final_kernel, dim3(n), dim3(64), 0, stream, m->partials, out, sblocks, 5, n, m->d_hw);
     EVR_LAUNCH_CHECK();

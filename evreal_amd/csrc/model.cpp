@@ -250,6 +250,11 @@ int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout
                 "'%s': transposed weight shape mismatch", c.name.c_str());
     memset(&c.tp, 0, sizeof(c.tp));
     c.tp.ngroups = 4; c.tp.grp_cols = grp_cols;
+    // more than 32 output channels: interleave the four phases per 128-column tile (conv.h ConvTaps::inter) -- EVR_TCONV_INTER=0: phase-major
+    static const bool inter_on = getenv("EVR_TCONV_INTER") ? atoi(getenv("EVR_TCONV_INTER")) != 0 : true;
+    const bool inter = inter_on && c.kc == 32 && cout == grp_cols && cout % 32 == 0 && cout > 32;
+    auto row_of = [&](int g, int co) { return inter ? (co / 32) * 128 + g * 32 + co % 32 : g * grp_cols + co; };
+    if (inter) { c.tp.inter = 1; c.tp.grp_cols = 32; }
     // shared taps
     std::vector<std::pair<int, int>> taps;
     auto tap_index = [&](int dy, int dx) {
@@ -287,12 +292,12 @@ int prep_tconv(Conv& c, const HostTensor* w, const Affine& af, int cin, int cout
     c.w.assign((size_t)n_gemm * nt * cin, 0.f);
     c.b.assign(n_gemm, 0.f);
     for (int g = 0; g < 4; ++g)
-        for (int co = 0; co < cout; ++co) c.b[g * grp_cols + co] = (float)af.shift[co];
+        for (int co = 0; co < cout; ++co) c.b[row_of(g, co)] = (float)af.shift[co];
     for (const Use& u : uses) {
         c.tp.tap_groups[u.t] |= 1 << u.g;
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                c.w[((size_t)(u.g * grp_cols + co) * nt + u.t) * cin + ci] =
+                c.w[((size_t)row_of(u.g, co) * nt + u.t) * cin + ci] =
                     (float)((double)w->data[(((size_t)ci * cout + co) * k + u.ky) * k + u.kx] * af.scale[co]);
     }
     c.useful_taps = (double)uses.size() / 4.0;   // per output pixel of one phase on average: k*k/4

@@ -43,12 +43,13 @@ def test_parity_on_the_implicit_gemm():
 
 def test_parity_with_wide_band_kernel_on_small_shapes():
     # the 256 x 256-tile ConvLSTM kernel the 64-sequence bench runs (conv3x3_wide_kernel), on the golden sequences
-    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '3'})
+    # (EVR_PROG_WIDE_MIN=1: the k5 s2 encoders on the 256-pixel form of the programmed band kernel too, round 5)
+    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '3', 'EVR_PROG_WIDE_MIN': '1'})
 
 
 def test_parity_with_twin_band_kernel_on_small_shapes():
     # its two-blocks-per-CU form (256 x 128 tiles, one band buffer), the default for ConvLSTM layers of up to 256 input channels
-    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '2'})
+    _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '2', 'EVR_PROG_WIDE_MIN': '1'})
 
 
 def test_parity_in_exact_fp32_mode():
@@ -107,7 +108,7 @@ def test_drift_100_frames_in_the_fast_mode():
     """100 frames x 8 sequences at 346x260 in the f16 + MX-fp6 mode on the kernels the 64-sequence bench runs, gate 1e-4 per pixel
     (measured 4e-6).  The GPU advances all 8 sequences; sequences 0 and 7 are replayed through the CPU oracle (the default-mode run in
     test_gpu_fullsize.py -- h3, gate 1e-5 -- replays all 8)."""
-    env = dict(os.environ, EVR_ARITH='mx6', EVR_WIDE_MIN='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')
+    env = dict(os.environ, EVR_ARITH='mx6', EVR_WIDE_MIN='1', EVR_PROG_WIDE_MIN='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
@@ -116,7 +117,7 @@ def test_drift_100_frames_in_the_fast_mode():
 def test_drift_100_frames_with_wide_band_kernel():
     """The 100-frame, 8-sequence, 346x260 drift gate again in the default arithmetic with the ConvLSTM gates on the kernel the 64-sequence
     bench times (8 sequences alone stay below its 1024-block threshold).  Sequences 0 and 7 against the oracle, as above."""
-    env = dict(os.environ, EVR_WIDE_MIN='1', EVR_WIDE='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')      # (EVR_WIDE=1, the default: twin AND 256 x 256 forms)
+    env = dict(os.environ, EVR_WIDE_MIN='1', EVR_WIDE='1', EVR_PROG_WIDE_MIN='1', EVR_TEST_DRIFT_ORACLE_SEQS='0,7')      # (EVR_WIDE=1, the default: twin AND 256 x 256 forms)
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_fullsize.py', '-k', 'drift_100', '-p', 'no:cacheprovider']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-4000:] + r.stderr[-2000:]
