@@ -141,21 +141,32 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const HeadArgs a) {
 //   B (pixels)   the normalised, zero-padded input tile [B][8+5][32+4] sits in LDS as u32 = hi | lo << 16 (split once
 //            per element); a lane gathers 8 elements per slab and two v_perm build the hi and lo operands.
 //   C^T      lane = pixel, registers = channels -> bias, ReLU, PACKED 8-B stores.
-__global__ __launch_bounds__(256, 2) void head_mfma_kernel(const HeadArgs a) {
+// WLDS (round 5): the weight fragments live in LDS (20 KB, staged once per persistent block) and are read per slab instead of sitting in
+// 80 registers: 236 -> ~160 VGPRs, THREE work-groups per CU instead of two.  The kernel is the one convolution of the step that is not
+// power-limited (2.47 GHz, 0.20 matrix-busy, 45 % of the wave cycles parked: profiles/r05_pmc_sq_single_stream.md) -- it lacks waves to
+// hide its per-tile latencies behind, not matrix cycles.
+template <bool WLDS>
+__global__ __launch_bounds__(256, WLDS ? 3 : 2) void head_mfma_kernel(const HeadArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 8, TW = 32, LR = TH + 5, LC = TW + 4, PLANE = LR * LC;
-    extern __shared__ unsigned htile[];   // [B][LR][LC]
+    extern __shared__ __attribute__((aligned(16))) unsigned htile[];   // [B][LR][LC] (5 bins: 9360 B) | WLDS: 20 slabs x 64 lanes x 16 B of weight fragments
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
 
     // weight fragments (slab s, {hi, lo}: 16 B per lane) stay in registers across ALL tiles of this persistent block;
     // the empty asm makes them opaque so hipcc neither sinks the loads into the tile loop nor re-loads them there
     const u32x4_t* wf = (const u32x4_t*)a.wfrag;
-    u32x4_t w_hi[10], w_lo[10];
+    u32x4_t w_hi[WLDS ? 1 : 10], w_lo[WLDS ? 1 : 10];
+    const u32x4_t* wl = (const u32x4_t*)(htile + ((a.B * PLANE + 3) & ~3));
+    if constexpr (WLDS) {
+        u32x4_t* wls = (u32x4_t*)(htile + ((a.B * PLANE + 3) & ~3));
+        for (int i = tid; i < 20 * 64; i += 256) wls[i] = wf[i];
+    } else {
 #pragma unroll
-    for (int s = 0; s < 10; ++s) { w_hi[s] = wf[(2 * s) * 64 + lane]; w_lo[s] = wf[(2 * s + 1) * 64 + lane]; }
+        for (int s = 0; s < 10; ++s) { w_hi[s] = wf[(2 * s) * 64 + lane]; w_lo[s] = wf[(2 * s + 1) * 64 + lane]; }
 #pragma unroll
-    for (int s = 0; s < 10; ++s) { asm volatile("" : "+v"(w_hi[s])); asm volatile("" : "+v"(w_lo[s])); }
+        for (int s = 0; s < 10; ++s) { asm volatile("" : "+v"(w_hi[s])); asm volatile("" : "+v"(w_lo[s])); }
+    }
     f4 bias4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bias4[q] = *(const f4*)(a.bias + 8 * q + 4 * h);
@@ -229,10 +240,12 @@ __global__ __launch_bounds__(256, 2) void head_mfma_kernel(const HeadArgs a) {
                     al[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
                 }
                 const f16x8 a_hi = __builtin_bit_cast(f16x8, ah), a_lo = __builtin_bit_cast(f16x8, al);
-                const f16x8 b_hi = __builtin_bit_cast(f16x8, w_hi[s]), b_lo = __builtin_bit_cast(f16x8, w_lo[s]);
+                const f16x8 b_hi = __builtin_bit_cast(f16x8, WLDS ? wl[(2 * s) * 64 + lane] : w_hi[WLDS ? 0 : s]);
+                const f16x8 b_lo = __builtin_bit_cast(f16x8, WLDS ? wl[(2 * s + 1) * 64 + lane] : w_lo[WLDS ? 0 : s]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc, 0, 0, 0);
+                if constexpr (WLDS) { if (s & 1) __builtin_amdgcn_sched_barrier(0); }      // (two slabs' gathers in flight at most: the register budget of three work-groups per CU)
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] *= a.wfrag_scale;
@@ -314,9 +327,12 @@ int launch_head_conv(const HeadArgs& a, hipStream_t stream) {
         // one box (tools/head_blocks_ab.sh, two rounds): 768 work-groups (the third per CU starts when a first one ends) 421 us, 512 or
         // 1024: 382-384 us; a 168-register build that does fit three spills the weight fragments (730 us); both row passes of a wave
         // unrolled together 390 us.  EVR_HEAD_BLOCKS overrides the grid.
-        static const int head_blocks = [] { const char* e = getenv("EVR_HEAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+        static const int wlds = [] { const char* e = getenv("EVR_HEAD_WLDS"); return e ? atoi(e) : 0; }();      // (A/B: weights in LDS, three work-groups per CU)
+        static const int head_blocks = [] { const char* e = getenv("EVR_HEAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (wlds ? 768 : 512); }();
         const dim3 g((unsigned)(ntiles < head_blocks ? ntiles : head_blocks));
-        hipLaunchKernelGGL(head_mfma_kernel, g, dim3(256), (size_t)a.B * 13 * 36 * sizeof(unsigned), stream, a2);
+        const size_t tile_b = (((size_t)a.B * 13 * 36 + 3) & ~(size_t)3) * sizeof(unsigned);
+        if (wlds) hipLaunchKernelGGL(head_mfma_kernel<true>, g, dim3(256), tile_b + (size_t)20 * 64 * 16, stream, a2);
+        else hipLaunchKernelGGL(head_mfma_kernel<false>, g, dim3(256), tile_b, stream, a2);
         EVR_LAUNCH_CHECK();
         return EVR_OK;
     }
