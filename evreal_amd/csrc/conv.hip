@@ -2318,7 +2318,7 @@ static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream
     }
     {   // 256-pixel tiles once a launch has enough of them to fill the chip (two or three blocks per CU; EVR_PROG_WIDE=0: never)
         static const int pw_on = getenv("EVR_PROG_WIDE") ? atoi(getenv("EVR_PROG_WIDE")) : 1;
-        static const int pw_min = getenv("EVR_PROG_WIDE_MIN") ? atoi(getenv("EVR_PROG_WIDE_MIN")) : 1024;
+        static const int pw_min = getenv("EVR_PROG_WIDE_MIN") ? atoi(getenv("EVR_PROG_WIDE_MIN")) : 600;
         const int total2 = ((M + 255) / 256) * (a.cout / (32 * NB));
         if (pw_on && total2 >= pw_min && ks == 1) {
             hipLaunchKernelGGL((conv_band_prog_wide_kernel<NB>), dim3(total2), dim3(256), 0, stream, d_args, img);
@@ -2434,7 +2434,7 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
         // (profiles/r02_tile_variants.txt) and are gone: with the zero row their 80 KiB no longer leave two blocks per CU.
         // 256-pixel block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
         static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
-        static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 1024;   // >= 4 rounds of 256 blocks; tests lower it
+        static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 600;   // (round 5: 600 tiles, was 1024 -- +2 % at 8 / 16 / 32 sequences, equal at 4 and 64; 300: -1 % at 16 / 32.  Tests lower it)
         const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
                              (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= wide_min;
         if (wide_ok && a.epi == EPI_LSTM) {
