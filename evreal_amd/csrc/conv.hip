@@ -2445,9 +2445,12 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
         }
         // plain 3x3 layers (residual blocks): the twin form once a launch has enough 256 x 128 tiles (not at 64 sequences of
         // 346x260: 726 tiles for 512 slots; from 128 sequences or 640x480 up)
+        // (their own threshold: at 64 sequences the residual convolutions are 726 such tiles -- 1.42 rounds of 512 slots -- and run
+        // 281 us on this form against 258 us on the 128 x 128 tiles; the ConvLSTM threshold above went down to 600 in round 5)
+        static const int wide_min_plain = getenv("EVR_WIDE_MIN_PLAIN") ? atoi(getenv("EVR_WIDE_MIN_PLAIN")) : (wide_min > 1024 ? wide_min : (getenv("EVR_WIDE_MIN") ? wide_min : 1024));
         if (wide && a.tp.ngroups == 1 && a.cout % 128 == 0 && !a.pred_w &&
             (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RESIDUAL_RELU) &&
-            (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min)
+            (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min_plain)
             return launch_wide<false, 1>(a, d_args, stream, img);
         if (a.epi == EPI_LSTM) {
             return launch_band<4, 2, true>(a, d_args, stream, img);
