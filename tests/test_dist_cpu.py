@@ -164,3 +164,44 @@ def test_sequence_costs_come_from_rank_0(tmp_path):
         p.join(60); assert p.exitcode == 0
     assert res[0][1] == res[1][1] == [10 * 32 * 32, 40 * 32 * 32, 18 * 32 * 32]      # windows x padded pixels, from rank 0's files
     assert res[0][2] == res[1][2] and sorted(sum(res[0][2], [])) == [0, 1, 2]
+
+
+def _load_fail_worker(rank, world, port, root, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from evreal_amd import eval as ev
+    os.chdir(root)
+
+    class _Model:      # stands in for a loaded network: the test never reaches a frame loop
+        pass
+
+    def loader(model_name, path):
+        if rank == 1:
+            raise OSError("simulated rank-local checkpoint failure")
+        return _Model()
+    ev.get_model_from_checkpoint_path = loader
+    reached = []
+    ev.sequence_costs = lambda seqs: reached.append('collective') or [1] * len(seqs)      # the first collective of the dataset loop
+    out = ev.eval_method_with_config({'name': 'std'}, 'M', [{'name': 'D', 'sequences': [{'name': 's'}]}], ['mse'])
+    q.put((rank, out, reached))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_checkpoint_load_before_the_dataset_collectives(tmp_path):
+    """a rank whose checkpoint load fails locally must not leave the others waiting in the dataset loop's collectives
+    (sequence_costs' broadcast, the per-dataset all-reduce): the ranks agree on the load first and skip the method everywhere,
+    as the reference skips it on its single rank (eval.py:348-352)."""
+    import json
+    os.makedirs(tmp_path / 'config' / 'method')
+    json.dump({"model_name": "E2VID", "model_path": "nowhere.pth"}, open(tmp_path / 'config' / 'method' / 'M.json', 'w'))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_load_fail_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    assert res[0][1] == [] and res[1][1] == []                 # the method is skipped on BOTH ranks ...
+    assert res[0][2] == [] and res[1][2] == []                 # ... and neither entered the dataset loop
