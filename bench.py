@@ -298,8 +298,11 @@ def cpu_baseline(wl, host_inputs, n_frames, budget_s=25.0, lpips_sd=None, keep_f
     for nt in ([threads] if threads else sorted({min(8, os.cpu_count()), min(32, os.cpu_count())})):
         torch.set_num_threads(nt)
         frame(0)                                   # warm-up at this thread count
-        dt = sum(frame(1 % xy.shape[0]))
-        tried[str(nt)] = round(1.0 / dt, 2)        # frames/s of the probe frame at this thread count (both go on the line)
+        # median of three probe frames (round 5: ONE probe frame picked 32 threads at 18 frames/s on a box whose timed sample then ran
+        # 12 frames/s -- the thread pool's first frames after a resize are not representative)
+        dts = sorted(sum(frame((1 + q) % xy.shape[0])) for q in range(3))
+        dt = dts[1]
+        tried[str(nt)] = round(1.0 / dt, 2)        # frames/s (median probe frame) at this thread count (both go on the line)
         if best_t is None or dt < best_t:
             best, best_t = nt, dt
     torch.set_num_threads(best)
