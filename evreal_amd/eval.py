@@ -238,6 +238,8 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
 def _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequence):
     guard = hasattr(model, 'saturation') and getattr(model, 'arith', 'fp32') != 'fp32'
     model.reset_states()
+    if guard:
+        model.saturation(clear=True)        # counters are cumulative: this sequence starts from zero
     infer_all = eval_config.get('eval_infer_all', False)
     post_norm = method_config.get('post_process_norm', "none")
     norm_in = method_config.get('event_tensor_normalization', False)
