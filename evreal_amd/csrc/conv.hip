@@ -842,6 +842,9 @@ __global__ __launch_bounds__(64 * WM, 2) void conv3x3_band_kernel(const ConvArgs
         const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
         for (int jj = 0; jj < NBW; ++jj) {
+            // (PHASES = 1, four waves: piece jj of a wave lies in 32-column block jj; a block whose phase does not connect tap t is never
+            // multiplied, so its quarter of the weight tile is not fetched -- the counted waits only rely on the band pieces coming last)
+            if constexpr (PHASES == 1 && WM == 4 && NBW == 4) { if ((t / 3 == 0 && (jj >> 1) == 1) || (t % 3 == 0 && (jj & 1) == 1)) continue; }
             lds_ptr_t dst = (lds_ptr_t)&lds[2 * A_F4 + slot * B_F4 + (wmi + jj * WM) * 64];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, live ? (b_off[jj] + kofs) * 4u : OOB_OFFSET, 0, 0, 0);
         }
@@ -1680,6 +1683,9 @@ __global__ __launch_bounds__(256 * WN, 2) void conv3x3_wide_kernel(const ConvArg
         const unsigned kofs = (unsigned)((t * nchunks + cc) * 32);
 #pragma unroll
         for (int jj = 0; jj < NBW; ++jj) {
+            // (twin form, PHASES = 1: a wave's piece jj lies in 32-column block jj -- pieces are 32 rows apart -- and a block whose phase
+            // does not connect tap t is never multiplied: its quarter of the weight tile is not fetched either)
+            if constexpr (PHASES == 1 && WN == 1) { if ((t / 3 == 0 && (jj >> 1) == 1) || (t % 3 == 0 && (jj & 1) == 1)) continue; }
             lds_ptr_t dst = (lds_ptr_t)&lds[NBUF * A_F4 + slot * B_F4 + (wv + jj * NW) * 64];
             // (soffset carries the wave-uniform part: row block jj and the K offset of the step)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, b_off0 * 4u, (kofs + (unsigned)(8 * NW * jj * ktot)) * 4u, 0, 0);
