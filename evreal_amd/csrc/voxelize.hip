@@ -45,9 +45,9 @@
 
 namespace {
 
-constexpr int K1T = 256;            // threads of a split workgroup
+constexpr int K1T = 512;            // threads of a split workgroup
 constexpr int K1W = K1T / 64;       // its waves
-constexpr int SEG = 1024;           // events per segment: 4 per thread, event (wave k, slot j, lane l) = k*256 + j*64 + l
+constexpr int SEG = 2048;           // events per segment: 4 per thread, event (wave k, slot j, lane l) = k*256 + j*64 + l
 constexpr int K2T = 256;            // threads of a range workgroup
 constexpr int K2W = K2T / 64;
 constexpr int NTAG = 512;         // ticket slots of a range workgroup (hashed by pixel)
