@@ -1130,6 +1130,15 @@ static void launch_ksplit_epilogue(const ConvArgs* d_args, float* img, int total
     hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<LSTM, GROUPED>), dim3(total), dim3(256), 0, stream, d_args, img, ks, kws);
 }
 
+// most runs per tile: 4, and 8 for launches of at most 64 tiles (the residual convolutions and dec0 of ONE sequence: 24 / 48 tiles --
+// eight runs still leave slots free).  Measured on one box, three runs each, +-0.1 %: a flat cap of 8 is +1.1 % at one sequence (2183 vs
+// 2159 frames/s) and -1.0 % at four (5 runs for the 92-tile residual convolutions and enc2.rec: the 8-run epilogue kernel holds one block
+// per CU); caps of 5 / 6: -3 % at one sequence; 5-6 runs for 65-102 tiles with a six-run epilogue kernel at two blocks per CU: 2206 vs 2245 at
+// one sequence, equal at four.  EVR_KSPLIT sets the general cap, EVR_KSPLIT_SMALL the one for <= 64 tiles.
+static int ksplit_cap(int total, int ks_max) {
+    static const int ks_small = getenv("EVR_KSPLIT_SMALL") ? atoi(getenv("EVR_KSPLIT_SMALL")) : (getenv("EVR_KSPLIT") ? 0 : 8);
+    return (total <= 64 && ks_small > ks_max) ? ks_small : ks_max;
+}
 // workspace of the split-K launches: ConvArgs::ksplit_ws, KSPLIT_WS_BYTES owned by the handle (model / LPIPS) whose plan this is --
 // allocated with the plan, freed with it, never touched in the launch path (no hipMalloc / synchronisation here: a step can be
 // captured into a hipGraph, and two devices or two handles never share partial sums)
@@ -1152,7 +1161,7 @@ static int launch_band(const ConvArgs& a, const ConvArgs* d_args, hipStream_t st
         if (ks_max > 1 && total <= 192 && nchunks >= 2 && !a.pred_w) {
             ks = 512 / total;
             if (ks > nchunks) ks = nchunks;
-            if (ks > ks_max) ks = ks_max;
+            if (ks > ksplit_cap(total, ks_max)) ks = ksplit_cap(total, ks_max);
             if (ks < 2) ks = 1;
         }
     }
@@ -2318,7 +2327,7 @@ static int launch_band_prog(const ConvArgs& a, const ConvArgs* d_args, hipStream
         if (ks_max > 1 && total <= 192 && nbands >= 4) {
             ks = 512 / total;
             if (ks > nbands / 2) ks = nbands / 2;
-            if (ks > ks_max) ks = ks_max;
+            if (ks > ksplit_cap(total, ks_max)) ks = ksplit_cap(total, ks_max);
             if (ks < 2) ks = 1;
         }
     }
@@ -2441,12 +2450,16 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
         // 256-pixel block tiles when N allows and there are enough of them to fill the chip (EVR_WIDE=0: never)
         static const int wide = getenv("EVR_WIDE") ? atoi(getenv("EVR_WIDE")) : 1;
         static const int wide_min = getenv("EVR_WIDE_MIN") ? atoi(getenv("EVR_WIDE_MIN")) : 600;   // (round 5: 600 tiles, was 1024 -- +2 % at 8 / 16 / 32 sequences, equal at 4 and 64; 300: -1 % at 16 / 32.  Tests lower it)
+        // two 256 x 128 blocks per CU (one band buffer each) while K is short, one 256 x 256 block otherwise: measured
+        // 1486 / 1449 / 1405 us against 1585 / 1489 / 1401 us for 128 / 256 / 512 input channels (EVR_WIDE=2 / 3 force one)
+        const bool twin = (wide == 2) || (wide == 1 && a.c0 + a.c1 <= 256);
+        // (the twin form already pays from ~1.4 rounds of its 512 slots on: per-layer times at 4 / 8 sequences, enc0.rec 144 -> 138 us
+        // with 726 twin tiles, enc1.rec 262 -> 249 us with 728; below one round it loses -- enc1.rec 136 -> 151 us with 364 tiles -- and
+        // the 256 x 256 form loses up to its own threshold: enc2.rec 256 -> 279 us at 8 sequences.  Explicit EVR_WIDE_MIN: one threshold)
+        static const int wide_min_twin = getenv("EVR_WIDE_MIN") ? wide_min : 350;
         const bool wide_ok = wide && a.tp.ngroups == 1 && a.cout % 256 == 0 && !a.pred_w &&
-                             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= wide_min;
+                             (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 256) >= (twin ? wide_min_twin : wide_min);
         if (wide_ok && a.epi == EPI_LSTM) {
-            // two 256 x 128 blocks per CU (one band buffer each) while K is short, one 256 x 256 block otherwise: measured
-            // 1486 / 1449 / 1405 us against 1585 / 1489 / 1401 us for 128 / 256 / 512 input channels (EVR_WIDE=2 / 3 force one)
-            const bool twin = (wide == 2) || (wide == 1 && a.c0 + a.c1 <= 256);
             return twin ? launch_wide<true, 1>(a, d_args, stream, img) : launch_wide<true, 2>(a, d_args, stream, img);
         }
         // plain 3x3 layers (residual blocks): the twin form once a launch has enough 256 x 128 tiles (not at 64 sequences of
@@ -2474,7 +2487,9 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
                 // 256 x 128 tiles, two blocks per CU (the twin form of conv3x3_wide_kernel), once there are enough of them:
                 // half the LDS-DMA bytes per MFMA cycle of the 128 x 128 tiles (EVR_WIDE_DEC=0: never)
                 static const int wide_dec = getenv("EVR_WIDE_DEC") ? atoi(getenv("EVR_WIDE_DEC")) : 1;
-                const bool twin_ok = wide_dec && rule && (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= wide_min &&
+                // (dec2 -- 32 output channels, 18 steps -- gains from 363 such tiles on: 49 -> 39 us at 4 sequences; dec1 at 364 loses, 83 -> 92 us)
+                static const int wide_min_dec32 = getenv("EVR_WIDE_MIN") ? wide_min : 350;
+                const bool twin_ok = wide_dec && rule && (((int64_t)a.n * a.hm * a.wm + 255) / 256) * (a.cout / 128) >= (a.tp.grp_cols == 32 ? wide_min_dec32 : wide_min) &&
                                      (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU) && (!a.pred_w || a.tp.grp_cols == 32);   // (a fused
                 // prediction must close inside one 32-column block: the epilogue runs block by block)
                 if (twin_ok && a.tp.grp_cols == 32) return launch_wide<false, 1, true, 1>(a, d_args, stream, img);
