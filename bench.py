@@ -835,7 +835,7 @@ def main():
         while s0 < s_end:
             u0 = s0 % U
             a = min(AHEAD, s_end - s0, U - u0)
-            h.prefetch_raw(xy, ts, pol, offs_flat[u0 * n_seq:(u0 + a) * n_seq + 1], a, n_window_events=a * n_seq * K_EVENTS)
+            h.prefetch_raw(xy, ts, pol, offs_flat[u0 * n_seq:(u0 + a) * n_seq + 1], a, n_window_events=a * n_seq * K_EVENTS, capacity=AHEAD)
             for s in range(s0, s0 + a):
                 h.step_ahead(ref, out_rows(s))
             s0 += a

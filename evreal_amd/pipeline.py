@@ -162,11 +162,14 @@ class HotPath:
     # Windows do not depend on the recurrence, so the tensorizer may run for several steps at once: ONE launch over
     # A x n_seq windows (its kernels reach a higher fraction of the HBM roof on 512 windows than on 64) fills a
     # ring of voxel grids that the following A steps consume.
-    def prefetch_raw(self, xy, ts, pol, win_offsets, n_steps, n_window_events=None):
-        """win_offsets: int64 [n_steps * n_seq + 1], the windows of the next n_steps steps in step-major order."""
+    def prefetch_raw(self, xy, ts, pol, win_offsets, n_steps, n_window_events=None, capacity=0):
+        """win_offsets: int64 [n_steps * n_seq + 1], the windows of the next n_steps steps in step-major order.
+        capacity: the most steps any later call will ask for -- the ring is allocated once for that many (a shorter first call followed by a
+        longer one would otherwise re-allocate ~1 GB in the middle of a run)."""
         if self._ring is None or self._ring.shape[0] < n_steps:
-            self._ring = torch.empty((n_steps, self.n, self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
-            self._ring_stats = torch.zeros((n_steps, self.n, 3), dtype=torch.float64, device=self.dev)
+            cap = max(n_steps, int(capacity))
+            self._ring = torch.empty((cap, self.n, self.B, self.H, self.W), dtype=torch.float32, device=self.dev)
+            self._ring_stats = torch.zeros((cap, self.n, 3), dtype=torch.float64, device=self.dev)
         assert int(win_offsets.numel()) == n_steps * self.n + 1
         if self._vox_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
