@@ -1023,24 +1023,46 @@ def main():
             for ns in (1, 4, 8, 16, 32):
                 if ns >= n_seq:
                     continue
+                # the headline's own step at ns sequences: inputs laid out for ns (step-major), the tensorizer AHEAD steps at a time, and a timed
+                # window of >= 0.5 s (80 steps of a one-sequence step are 36 ms: pipeline fill, the drain of the gated evaluation stream and
+                # the first look-ahead launch were 3-5 % of that)
                 h2 = mk(ns)
                 sc2 = torch.zeros((ns, 3), dtype=torch.float64, device=device)
-                ofs = [offs[u][:ns + 1].contiguous() for u in range(U)]
-                for s in range(Wm):
-                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2, n_window_events=ns * K_EVENTS)
-                h2.flush()
+                xy2, ts2, pol2, offs2, refs2, _h = build_inputs(rank, ns, U, device, W_, H_, K_EVENTS)
+                flat2 = torch.cat([offs2[:, :-1].reshape(-1), offs2[-1, -1:]]).contiguous()
+
+                def run2(s_begin, s_end):
+                    s0 = s_begin
+                    while s0 < s_end:
+                        u0 = s0 % U
+                        a = min(AHEAD, s_end - s0, U - u0)
+                        if AHEAD == 1:
+                            h2.step_raw(xy2, ts2, pol2, offs2[u0], refs2, sc2, n_window_events=ns * K_EVENTS)
+                        else:
+                            h2.prefetch_raw(xy2, ts2, pol2, flat2[u0 * ns:(u0 + a) * ns + 1], a, n_window_events=a * ns * K_EVENTS, capacity=AHEAD)
+                            for _ in range(a):
+                                h2.step_ahead(refs2, sc2)
+                        s0 += a
+                    h2.flush()
+
+                run2(0, max(Wm, AHEAD))
                 torch.cuda.synchronize()
-                Ks = 80
                 t1 = time.perf_counter()
-                for s in range(Wm, Wm + Ks):
-                    h2.step_raw(xy, ts, pol, ofs[s % U], refs[:ns], sc2, n_window_events=ns * K_EVENTS)
-                h2.flush()
+                run2(0, 2 * AHEAD)
+                torch.cuda.synchronize()
+                est = (time.perf_counter() - t1) / (2 * AHEAD)
+                Ks = int(min(4000, max(80, np.ceil(0.5 / max(est, 1e-5)))))
+                Ks = (Ks + AHEAD - 1) // AHEAD * AHEAD
+                t1 = time.perf_counter()
+                run2(0, Ks)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
-                sb[f"n_seq_{ns}"] = {"value": round(ns * Ks / dt, 1), "ms_per_step": round(1e3 * dt / Ks, 4)}
+                sb[f"n_seq_{ns}"] = {"value": round(ns * Ks / dt, 1), "ms_per_step": round(1e3 * dt / Ks, 4), "steps": Ks}
+                del xy2, ts2, pol2, offs2, refs2, flat2
                 del h2
             sb["note"] = ("the headline advances %d sequences per GPU in lock-step; evreal_amd.eval --batch-sequences S does "
-                          "the same for the sequences of a dataset" % n_seq)
+                          "the same for the sequences of a dataset.  Each entry: the headline's step at that many sequences (tensorizer %d steps "
+                          "at a time), >= 0.5 s of steps" % (n_seq, AHEAD))
             out["small_batch"] = sb
 
     # the ranks part here: what follows is rank 0's own checking (CPU oracle) and the side blocks, outside every timed region
