@@ -519,7 +519,8 @@ def compact_line(out, full_path=None):
             g = lambda a: (ec.get(a) or {})
             o["eval_cli"] = {"off": g('save_images_off').get('value'), "on": g('save_images_on').get('value'),
                              "loop_off": (g('save_images_off').get('frame_loop') or {}).get('value'),
-                             "loop_on": (g('save_images_on').get('frame_loop') or {}).get('value')}
+                             "loop_on": (g('save_images_on').get('frame_loop') or {}).get('value'),
+                             "seq1": g('one_sequence_at_a_time').get('value')}
     o["full"] = full_path
     # never above the limit: drop the optional blocks, least important first
     for k in ('small_batch', 'eval_cli', 'large_batch_128', 'fp8_cross_terms', 'configs', 'sensor_640x480', 'fp32_exact', 'steady_state',
@@ -669,10 +670,11 @@ def run_eval_cli(args, device):
                     'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, os.path.join(tmp, 'e2vid.pth'))
         json.dump({"model_name": "E2VID", "model_path": os.path.join(tmp, 'e2vid.pth'), "event_tensor_normalization": True,
                    "post_process_norm": "robust"}, open(os.path.join(tmp, 'config/method/E2VID.json'), 'w'))
-        for name, save in (('std', True), ('stdnoimg', False)):
+        # 'seq1': the reference's own loop -- one sequence after the other, batch 1 (eval.py:72,360-368)
+        for name, save, bs in (('std', True, n_seq), ('stdnoimg', False, n_seq), ('seq1', False, 1)):
             json.dump({"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "between_frames"}, "keep_ratio": 1.0},
                        "save_images": save, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 1.0, "create_video": False,
-                       "batch_sequences": n_seq}, open(os.path.join(tmp, f'config/eval/{name}.json'), 'w'))
+                       "batch_sequences": bs}, open(os.path.join(tmp, f'config/eval/{name}.json'), 'w'))
         seqs = {}
         for s in range(n_seq):
             # 1 Mev/s and 66.67 frames/s: 15k events between consecutive reference frames
@@ -680,7 +682,7 @@ def run_eval_cli(args, device):
             seqs[f's{s}'] = {}
         json.dump({"root_path": os.path.join(tmp, 'data', 'SYN'), "sequences": seqs}, open(os.path.join(tmp, 'config/dataset/SYN.json'), 'w'))
         os.chdir(tmp)
-        for name in ('stdnoimg', 'std'):
+        for name in ('stdnoimg', 'std', 'seq1'):
             for rep in range(2):                       # first pass warms allocations / the LPIPS model; the second is timed
                 shutil.rmtree(os.path.join(tmp, 'outputs'), ignore_errors=True)
                 torch.cuda.synchronize()
@@ -694,7 +696,7 @@ def run_eval_cli(args, device):
             dm = r[name][0][0]
             nfr = sum(len(open(os.path.join(tmp, 'outputs', name, 'SYN', f's{s}', 'E2VID', 'timestamps.txt')).read().splitlines())
                       for s in range(n_seq))
-            res['save_images_on' if name == 'std' else 'save_images_off'] = {
+            res[{'std': 'save_images_on', 'stdnoimg': 'save_images_off', 'seq1': 'one_sequence_at_a_time'}[name]] = {
                 "value": round(nfr / dt, 1), "unit": "frames/s", "frames": nfr, "seconds": round(dt, 3),
                 "frame_loop": {"value": round(tm['frames'] / loop_s, 1), "seconds": round(loop_s, 3),
                                "note": "the frame loop alone (voxelize .. files written); the rest of `seconds` is per-call and "
@@ -707,7 +709,8 @@ def run_eval_cli(args, device):
         shutil.rmtree(tmp, ignore_errors=True)
     res["what"] = ("evreal_amd.eval.evaluate(['E2VID'], [cfg], ['SYN'], ['mse','ssim','lpips']) end to end (sequence open + upload, "
                    "window tables, frame loop, text files, PNGs), %d sequences x %d frames of %dx%d advanced together "
-                   "(batch_sequences = %d); wall clock of the whole call" % (n_seq, frames, W_, H_, n_seq))
+                   "(batch_sequences = %d); wall clock of the whole call.  one_sequence_at_a_time: the same call with batch_sequences = 1, "
+                   "no PNGs -- the reference's own loop (eval.py:72,360-368)" % (n_seq, frames, W_, H_, n_seq))
     return res
 
 
