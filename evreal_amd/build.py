@@ -31,7 +31,7 @@ PER_FILE = {
 # kernels whose accumulators must stay in registers: hipcc has demoted them to scratch more than once while this code
 # grew (a branchy unrolled epilogue, dynamic indexing of a register array) -- silently, at a 10x slowdown.  These files
 # are compiled with -Rpass-analysis=kernel-resource-usage and the build fails if any of their kernels uses scratch.
-NO_SCRATCH = {'conv.hip', 'conv_misc.hip', 'lpips.hip'}
+NO_SCRATCH = {'conv.hip', 'conv_misc.hip', 'lpips.hip', 'wino.hip'}
 # sources compiled more than once: (object tag, extra flags).  conv.hip carries one split arithmetic per object
 # (csrc/conv.h arith_mode): mode 2 (f16 + MX-fp8, plus the exact-fp32 kernels) and mode 3 (three f16 products, fp32-grade)
 VARIANTS = {'conv.hip': [('', ['-DEVR_ARITH=2']), ('.h3', ['-DEVR_ARITH=3']), ('.m6', ['-DEVR_ARITH=4'])]}

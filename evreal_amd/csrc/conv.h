@@ -109,6 +109,11 @@ struct ConvArgs {
     float* ksplit_ws;         // split-K partial sums (conv.hip launch_band / launch_band_prog): KSPLIT_WS_BYTES of device memory owned by the
                               //   handle whose launches use it (evr_model per shape, evr_lpips per plan) -- launches of ONE handle are ordered
                               //   on one stream, so they can share it; null: never split.  Host-side only.
+    // Winograd F(2x2, 3x3) form of a 3x3 stride-1 convolution in the exact-fp32 mode (wino.hip): transform-domain weights in the
+    // kernel's streaming order, or null; the grid of 2x2 output tiles per image and its multiply-high divisors
+    const float* wgt_wino;
+    int wino_th, wino_tw;
+    unsigned wdiv_t_mul, wdiv_t_sh, wdiv_tw_mul, wdiv_tw_sh;
 };
 // A split launch has at most 512 blocks (one per resident slot) of 64 KB of partial accumulators each
 constexpr size_t KSPLIT_WS_BYTES = (size_t)512 * 4 * 16 * 64 * 16;
@@ -413,6 +418,17 @@ int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm,
 int launch_conv_igemm_mx(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 int launch_conv_igemm_h3(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
 int launch_conv_igemm_m6(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img);
+// Winograd F(2x2, 3x3) path of the exact-fp32 mode (wino.hip; EVR_WINO=0: never): host-side weight transform (w = [n_gemm][9][cin]
+// in prep_conv2d's order; lstm_hidden > 0: ConvLSTM row permutation), the eligibility test of a launch plan, the launch
+void wino_pack_weights(const std::vector<float>& w, int n_gemm, int cin, int lstm_hidden, std::vector<float>& out);
+bool wino_enabled();
+bool wino_eligible(const ConvArgs& a);
+int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream);
+inline void set_wino_grid(ConvArgs& a) {
+    a.wino_th = (a.hin + 1) / 2; a.wino_tw = (a.win + 1) / 2;
+    fastdiv_magic((unsigned)(a.wino_th * a.wino_tw), &a.wdiv_t_mul, &a.wdiv_t_sh);
+    fastdiv_magic((unsigned)a.wino_tw, &a.wdiv_tw_mul, &a.wdiv_tw_sh);
+}
 // picks (wm, nb) for the shape: fills the 256 CUs when M is small
 void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);
 

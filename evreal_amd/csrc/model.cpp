@@ -59,6 +59,7 @@ struct Conv {   // one prepared implicit-GEMM convolution
     // k5 stride-2 convs: space-to-depth weights [n_gemm][9][4*cin] and the step program of the band kernel
     std::vector<float> w2; std::vector<unsigned> prog; int prog_steps = 0;
     float* d_w2 = nullptr; unsigned* d_prog = nullptr;
+    float* d_wino = nullptr;    // exact-fp32 mode, 3x3 stride-1 layers: Winograd-domain weights (wino.hip)
     // per shape
     ConvArgs args[2];
     int wm = 4, nb = 4;
@@ -145,7 +146,8 @@ struct evr_model {
     std::vector<double> prof_ms;
     std::vector<int64_t> prof_n;
 
-    ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); }
+    ~evr_model() { release_shape(); for (auto& c : convs) { if (c.d_w) (void)hipFree(c.d_w); if (c.d_b) (void)hipFree(c.d_b); if (c.d_wino) (void)hipFree(c.d_wino);
+                                            if (c.d_w2) (void)hipFree(c.d_w2); if (c.d_prog) (void)hipFree(c.d_prog); }
                    if (d_ctx_w) (void)hipFree(d_ctx_w); if (d_ctx_b) (void)hipFree(d_ctx_b); if (d_bases) (void)hipFree(d_bases);
                    if (d_head_wfrag) (void)hipFree(d_head_wfrag); if (d_sat) (void)hipFree(d_sat);
                    for (auto& pr : et_ln) { (void)hipFree(pr.first); (void)hipFree(pr.second); }
@@ -374,6 +376,15 @@ int finish_conv(evr_model* m, Conv& c) {
         if ((rc = upload(c.w2, &c.d_w2))) return rc;
         EVR_HIP(hipMalloc((void**)&c.d_prog, c.prog.size() * sizeof(unsigned)));
         EVR_HIP(hipMemcpy(c.d_prog, c.prog.data(), c.prog.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+    // exact-fp32 mode: the 3x3 stride-1 layers whose shape wino.hip covers (ConvLSTM gates, residual convolutions) get their
+    // Winograd-domain weights too -- G g G^T in fp64 -- and run F(2x2, 3x3): 2.25x fewer fp32 MFMAs (EVR_WINO=0: direct form only)
+    if (c.x3 == 0 && c.kc == 32 && wino_enabled() && c.k == 3 && c.stride == 1 && !c.transposed && c.tp.ngroups == 1 && c.cin0 % 8 == 0 &&
+        (c.cin1 == 0 || c.cin1 == c.cin0) && c.n_gemm % 64 == 0 && c.n_valid == c.n_gemm &&
+        ((c.epi == EPI_LSTM && c.hidden % 16 == 0) || c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU || c.epi == EPI_RESIDUAL_RELU)) {
+        std::vector<float> u;
+        wino_pack_weights(c.w, c.n_gemm, c.cin0 + c.cin1, c.epi == EPI_LSTM ? c.hidden : 0, u);
+        if ((rc = upload(u, &c.d_wino))) return rc;
     }
     if (c.x3) c.mx_e = pack_weights_for(c.x3, c.w);
     // mode 3 accumulates products scaled by 2^(e_w + H2_ACT_EXP): the accumulators start at the bias in that scale (exact:
@@ -874,6 +885,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.acc_scale = (c.x3 == 3) ? std::ldexp(1.0f, -(c.mx_e + H2_ACT_EXP)) : (c.x3 == 4 ? std::ldexp(1.0f, -c.mx_e) : 1.0f);
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
+        a.wgt_wino = c.d_wino; set_wino_grid(a);
         a.sat = m->d_sat ? m->d_sat + ci : nullptr;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;

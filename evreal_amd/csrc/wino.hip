@@ -1,0 +1,369 @@
+// Winograd F(2x2, 3x3) form of the 3x3 stride-1 'same' convolutions in exact fp32 -- the ConvLSTM gate convolutions
+// (model/submodules.py:227-245, 65 % of E2VID's FLOPs) and the residual blocks' convolutions (:169-184) of the library's
+// exact-fp32 mode (EVR_FP32=1, the saturation re-run twin): 16 multiplies per 2x2 output tile and (cin, cout) pair instead
+// of 36, i.e. 2.25x fewer v_mfma_f32_32x32x2_f32 -- the one instruction that mode is bound by (0.81 matrix-busy in round 5).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs   (Lavin & Gray 2016)
+//
+//   GEMM view   16 independent GEMMs (one per transform-domain position) with M = n*th*tw tiles of 2x2 output pixels
+//               (flattened), N = output channels, K = input channels (cat(x, h) for the ConvLSTM)
+//   weights     U = G g G^T computed in fp64 on the host at model creation (wino_pack_weights), stored in the exact order
+//               the kernel's LDS image wants: [N/64][K/8][pos 16][wc 2][kp 2][row 32][4 k] -- a block's K chunk is ONE
+//               contiguous 32 KB run, fetched by LDS-DMA, and a wave's A fragment is a lane-linear ds_read_b128
+//   block       256 threads = 4 waves = 2 (tile halves) x 2 (column halves): 64 tiles x 64 columns; a wave owns 32 tiles x
+//               32 columns x 16 positions = 16 accumulators of 16 registers = the 256 AGPRs of a one-wave-per-SIMD kernel
+//   input       per K chunk (8 channels) every thread owns one (tile, channel pair): 16 8-byte loads of its 4x4 patch (zero
+//               padding and ragged M from the buffer descriptor's range check), B^T d B in registers (32 packed adds), 16
+//               8-byte LDS stores into the V image [pos][wt][kp][tile 32][4 k]; the loads run two chunks ahead of the MFMAs
+//   ConvLSTM    the wave's 32 columns are the 4 gates of 8 hidden channels, rows ordered so that a lane (= one tile) holds
+//               all four gates of 4 channels: output transform and cell update are a register epilogue
+//   grid        1-D, XCD-aware remap, column block fastest (the blocks that share input tiles run together)
+#include "conv.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace evr {
+
+// G g G^T for every (row, input channel) of w = [n_gemm][9][cin] (prep_conv2d's layout: tap = ky*3 + kx), in fp64, laid out
+// as the kernel streams it.  lstm_hidden > 0: the rows of w are the ConvLSTM permutation (c/32)*128 + gate*32 + c%32.
+void wino_pack_weights(const std::vector<float>& w, int n_gemm, int cin, int lstm_hidden, std::vector<float>& out) {
+    static const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const int ncb = n_gemm / 64, nch = cin / 8;
+    out.assign((size_t)n_gemm * cin * 16, 0.f);
+    for (int cb = 0; cb < ncb; ++cb)
+        for (int wc = 0; wc < 2; ++wc)
+            for (int rho = 0; rho < 32; ++rho) {
+                int src;
+                if (lstm_hidden > 0) {
+                    const int gate = rho >> 3, ch = cb * 16 + wc * 8 + (rho & 7);
+                    src = (ch / 32) * 128 + gate * 32 + (ch % 32);
+                } else {
+                    src = cb * 64 + wc * 32 + rho;
+                }
+                for (int k = 0; k < cin; ++k) {
+                    double g[3][3];
+                    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)w[((size_t)src * 9 + t) * cin + k];
+                    double tmp[4][3];
+                    for (int xi = 0; xi < 4; ++xi)
+                        for (int kx = 0; kx < 3; ++kx) tmp[xi][kx] = G[xi][0] * g[0][kx] + G[xi][1] * g[1][kx] + G[xi][2] * g[2][kx];
+                    const int c = k / 8, kp = (k % 8) / 4, kk = k % 4;
+                    for (int xi = 0; xi < 4; ++xi)
+                        for (int nu = 0; nu < 4; ++nu) {
+                            const double u = tmp[xi][0] * G[nu][0] + tmp[xi][1] * G[nu][1] + tmp[xi][2] * G[nu][2];
+                            const int pos = xi * 4 + nu;
+                            out[((((((size_t)cb * nch + c) * 16 + pos) * 2 + wc) * 2 + kp) * 32 + rho) * 4 + kk] = (float)u;
+                        }
+                }
+            }
+}
+
+bool wino_enabled() {
+    static const bool on = getenv("EVR_WINO") ? atoi(getenv("EVR_WINO")) != 0 : true;
+    return on;
+}
+
+// host-side test of a launch plan (model.cpp sets wgt_wino only for layers that pass the shape part of this)
+bool wino_eligible(const ConvArgs& a) {
+    if (!a.wgt_wino || a.x3 != 0 || a.pred_w || a.tp.ngroups != 1 || a.tp.ntaps != 9 || a.stride != 1 || a.os != 1) return false;
+    if (a.hout != a.hm || a.wout != a.wm || a.hm != a.hin || a.wm != a.win) return false;
+    if (a.c0 % 8 || (a.in_mode == IN_CAT && a.c1 != a.c0) || a.cout % 64 || a.n_valid != a.cout) return false;
+    if (((a.c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) / 8) % 2) return false;      // (the chunk loop is unrolled by its two LDS buffers)
+    if (a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed) return false;
+    if (a.epi == EPI_LSTM) return a.hidden % 16 == 0 && a.cout == 4 * a.hidden;
+    return (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RESIDUAL_RELU) && a.cout_total == a.cout;
+}
+
+namespace wino {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned sh) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> sh); }
+// Gate activations: FAST = v_exp_f32 / v_rcp_f32 forms (absolute error ~2e-7, the split kernels' forms), else libm-grade
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    else return 1.0f / (1.0f + expf(-x));
+}
+template <bool FAST> __device__ __forceinline__ float tanh_t(float x) {
+    if constexpr (FAST) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+    else return tanhf(x);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+#endif
+
+constexpr int UV_F4 = 2048;      // float4 per 32-KB image: [pos 16][half 2][lane 64]
+
+template <bool LSTM, bool FAST>
+__global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    // four separate LDS objects: hipcc's waitcnt insertion then knows that an LDS-DMA into one U buffer does not alias the fragment
+    // reads of the other (with one array it puts s_waitcnt vmcnt(0) in front of every chunk's first ds_read, i.e. waits for the
+    // weight image it has just requested)
+    __shared__ __attribute__((aligned(16))) float4 ldsU0[UV_F4], ldsU1[UV_F4], ldsV0[UV_F4], ldsV1[UV_F4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wv & 1, wc = wv >> 1;
+    const int H = a.hin, W = a.win, tw = a.wino_tw, tpi = a.wino_th * tw;
+    const int Mt = a.n * tpi;
+    const int ncb = a.cout >> 6;
+    int lin;
+    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
+        const int total = gridDim.x, bid = blockIdx.x;
+        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
+        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    }
+    const int cb = lin % ncb, mt = lin / ncb;
+    const int c0 = a.c0;
+    const int nch = (c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) >> 3;      // (even: checked at launch)
+    const int nch0 = c0 >> 3;
+    const unsigned in_bytes = (unsigned)a.n * (unsigned)H * (unsigned)W * (unsigned)c0 * 4u;
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt_wino, (unsigned)a.cout * (unsigned)(nch * 8) * 64u);
+
+    // ---- input-transform role: thread = (tile tt of the block's 64, channel pair cp of the chunk's 8 channels)
+    const int tt = tid >> 2, cp = tid & 3;
+    unsigned poff[16];
+    {
+        const int m = mt * 64 + tt;
+        const bool tvalid = m < Mt;
+        const int mm = tvalid ? m : 0;
+        const int img = fdiv(mm, a.wdiv_t_mul, a.wdiv_t_sh), rem = mm - img * tpi;
+        const int ty = fdiv(rem, a.wdiv_tw_mul, a.wdiv_tw_sh), tx = rem - ty * tw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
+                const bool ok = tvalid && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                poff[r * 4 + c] = ok ? ((unsigned)((img * H + y) * W + x) * (unsigned)c0 + (unsigned)(cp * 2)) * 4u : OOB_OFFSET;
+            }
+    }
+    // V image: [pos][wt][kp][tile 32][4 k] floats; this thread's 8-B slot at pos 0
+    const int vslot = (((tt >> 5) * 2 + (cp >> 1)) * 32 + (tt & 31)) * 4 + (cp & 1) * 2;
+
+    f2 S[16];      // the staged 4x4 patch of one chunk (two channels), row-major
+    f2 T[16];      // its column pass
+    const float* const in0p = a.in0; const float* const in1p = a.in1 ? a.in1 : a.in0;      // (kept in SGPRs: no scalar load per chunk)
+    auto patch_rsrc = [&](int c) {
+        const bool second = c >= nch0;
+        const float* src = (second ? in1p : in0p) + (size_t)((second ? c - nch0 : c) * 8);
+        return make_rsrc(src, in_bytes);
+    };
+    // B^T d B in two passes: rows of d (over r) per patch column c, then columns per transform row xi -> the V image
+    auto col_pass = [&](int c) {
+        T[0 * 4 + c] = S[0 * 4 + c] - S[2 * 4 + c];
+        T[1 * 4 + c] = S[1 * 4 + c] + S[2 * 4 + c];
+        T[2 * 4 + c] = S[2 * 4 + c] - S[1 * 4 + c];
+        T[3 * 4 + c] = S[1 * 4 + c] - S[3 * 4 + c];
+    };
+    auto row_pass_store = [&](int xi, float4* vimg4) {
+        float* vimg = (float*)vimg4 + vslot;
+        const f2 v0 = T[xi * 4 + 0] - T[xi * 4 + 2];
+        const f2 v1 = T[xi * 4 + 1] + T[xi * 4 + 2];
+        const f2 v2 = T[xi * 4 + 2] - T[xi * 4 + 1];
+        const f2 v3 = T[xi * 4 + 1] - T[xi * 4 + 3];
+        *(f2*)(vimg + (xi * 4 + 0) * 512) = v0;
+        *(f2*)(vimg + (xi * 4 + 1) * 512) = v1;
+        *(f2*)(vimg + (xi * 4 + 2) * 512) = v2;
+        *(f2*)(vimg + (xi * 4 + 3) * 512) = v3;
+    };
+    // the block's 32-KB weight image of chunk c: 32 lane-linear 1-KB pieces, 8 per wave (piece j of this wave)
+    const unsigned u_voff = (unsigned)(lane * 16 + wv * 8192);
+    auto issue_u = [&](int c, int j, float4* ubuf) {
+        const unsigned soff = (unsigned)((cb * nch + c) * 32768);
+        lds_ptr_t dst = (lds_ptr_t)&ubuf[(wv * 8 + j) * 64];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, u_voff + (unsigned)(j * 1024), soff, 0, 0);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
+
+    // One K chunk: 64 MFMAs (16 positions x 4) on the images of buffer B, and -- spread over the positions so that it issues in
+    // the MFMAs' shadow -- the next chunk's weight DMA (two pieces at each of positions 0-3), its input transform (column pass at
+    // 0-3, row pass + V stores at 4-7) and the patch loads of the chunk after it (four at each of positions 4-7, right behind
+    // the column pass that frees the staging registers: they have 12 positions ~ 3000 cycles to land).
+    // MODE 2: both follow; 1: only the next chunk follows (no patch loads); 0: the last chunk
+    auto step = [&](auto bufc, auto modec, int c) {
+        constexpr int B = decltype(bufc)::value, MODE = decltype(modec)::value;
+        float4* ucur = B ? ldsU1 : ldsU0; float4* unext = B ? ldsU0 : ldsU1;
+        float4* vcur = B ? ldsV1 : ldsV0; float4* vnext = B ? ldsV0 : ldsV1;
+        // U[c] (LDS-DMA) must have landed; the 16 patch loads requested behind it (memory operations complete in order) may stay in
+        // flight -- the step before the last one requests none
+        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // V[c] and U[c] are whole; every wave has left the other buffers
+        asm volatile("" ::: "memory");
+        const float4* lu = ucur + wc * 64 + lane;
+        const float4* lv = vcur + wt * 64 + lane;
+        __amdgpu_buffer_rsrc_t rsp = rsw;
+        if constexpr (MODE == 2) rsp = patch_rsrc(c + 2);
+        float4 u = lu[0], v = lv[0];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            float4 un = u, vn = v;
+            if (p < 15) { un = lu[(p + 1) * 128]; vn = lv[(p + 1) * 128]; }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, acc[p], 0, 0, 0);
+            if constexpr (MODE >= 1) {
+                if (p < 4) { issue_u(c + 1, 2 * p, unext); issue_u(c + 1, 2 * p + 1, unext); col_pass(p); }
+                else if (p < 8) row_pass_store(p - 4, vnext);
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, v.y, acc[p], 0, 0, 0);
+            if constexpr (MODE == 2) {
+                if (p >= 4 && p < 8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        S[(p - 4) * 4 + i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 4) * 4 + i], 0, 0));
+                }
+            }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, v.z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, v.w, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            u = un; v = vn;
+        }
+    };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+
+    // prologue: U[0] requested, patch 0 transformed into V0, patch 1 staged
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_u(0, j, ldsU0);
+    {
+        const __amdgpu_buffer_rsrc_t rs = patch_rsrc(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, poff[i], 0, 0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) col_pass(c);
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) row_pass_store(xi, ldsV0);
+        const __amdgpu_buffer_rsrc_t rs1 = patch_rsrc(1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs1, poff[i], 0, 0));
+    }
+    int c = 0;
+    for (; c + 3 < nch; c += 2) { step(I0{}, I2{}, c); step(I1{}, I2{}, c + 1); }
+    step(I0{}, I1{}, c);
+    step(I1{}, I0{}, c + 1);
+
+    // ---- epilogue: lane = tile (lane & 31), register j of an accumulator = row 8*(j>>2) + 4*(lane>>5) + (j&3) of the wave's 32
+    const int hl = lane >> 5;
+    const int me = mt * 64 + wt * 32 + (lane & 31);
+    const bool evalid = me < Mt;
+    const int mme = evalid ? me : 0;
+    const int eimg = fdiv(mme, a.wdiv_t_mul, a.wdiv_t_sh), erem = mme - eimg * tpi;
+    const int ety = fdiv(erem, a.wdiv_tw_mul, a.wdiv_tw_sh), etx = erem - ety * tw;
+    bool pok[4]; unsigned ppix[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int oy = 2 * ety + (p >> 1), ox = 2 * etx + (p & 1);
+        pok[p] = evalid && oy < H && ox < W;
+        ppix[p] = pok[p] ? (unsigned)((eimg * H + oy) * W + ox) : 0u;
+    }
+    // A^T m A for register j: y[py*2 + px]
+    float Y[4][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float m0 = acc[xi * 4 + 0][j], m1 = acc[xi * 4 + 1][j], m2 = acc[xi * 4 + 2][j], m3 = acc[xi * 4 + 3][j];
+            s0[xi] = (m0 + m1) + m2;
+            s1[xi] = (m1 - m2) - m3;
+        }
+        Y[0][j] = (s0[0] + s0[1]) + s0[2];
+        Y[2][j] = (s0[1] - s0[2]) - s0[3];
+        Y[1][j] = (s1[0] + s1[1]) + s1[2];
+        Y[3][j] = (s1[1] - s1[2]) - s1[3];
+    }
+    if constexpr (LSTM) {
+        // the wave's 32 rows = 4 gates (in, remember, out, cell: submodules.py:231) x 8 hidden channels; this lane: 4 channels
+        const int C = a.hidden;
+        const int ch = cb * 16 + wc * 8 + 4 * hl;
+        const int brow = (ch >> 5) * 128 + (ch & 31);
+        f4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *(const f4*)(a.bias + brow + q * 32);
+        f4 cprev[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) cprev[p] = *(const f4*)(a.state + ppix[p] * (unsigned)C + (unsigned)ch);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f4 cn, hn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gi = sigmoid_t<FAST>(Y[p][0 + i] + bq[0][i]);
+                const float gf = sigmoid_t<FAST>(Y[p][4 + i] + bq[1][i]);
+                const float go = sigmoid_t<FAST>(Y[p][8 + i] + bq[2][i]);
+                const float gc = tanh_t<FAST>(Y[p][12 + i] + bq[3][i]);
+                cn[i] = __fadd_rn(__fmul_rn(gf, cprev[p][i]), __fmul_rn(gi, gc));      // submodules.py:242
+                hn[i] = go * tanh_t<FAST>(cn[i]);                                       // submodules.py:243
+            }
+            if (pok[p]) {
+                *(f4*)(a.state + ppix[p] * (unsigned)C + (unsigned)ch) = cn;
+                *(f4*)(a.out + ppix[p] * (unsigned)C + (unsigned)ch) = hn;
+            }
+        }
+    } else {
+        const int epi = a.epi;
+        const bool res = (epi == EPI_RESIDUAL_RELU), relu = (epi != EPI_BIAS);
+        const unsigned ct = (unsigned)a.cout_total;
+        const int cbase = cb * 64 + wc * 32 + 4 * hl;
+        f4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *(const f4*)(a.bias + cbase + 8 * q);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned row = ppix[p] * ct;
+            f4 rv[4], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rv[q] = res ? *(const f4*)(a.residual + row + (unsigned)(cbase + 8 * q)) : f4{0.f, 0.f, 0.f, 0.f};
+                sv[q] = a.post_add ? *(const f4*)(a.post_add + row + (unsigned)(cbase + 8 * q)) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = Y[p][4 * q + i] + bq[q][i];
+                    t += rv[q][i];
+                    t = relu ? fmaxf(t, 0.f) : t;
+                    v[i] = t + sv[q][i];
+                }
+                if (pok[p]) *(f4*)(a.out + row + (unsigned)(cbase + 8 * q)) = v;
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace wino
+
+int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream) {
+    EVR_REQUIRE(wino_eligible(a), "conv_wino: the plan is not a 3x3 stride-1 fp32 convolution this kernel covers");
+    EVR_REQUIRE(a.wino_th == (a.hin + 1) / 2 && a.wino_tw == (a.win + 1) / 2 && a.wdiv_t_sh < 32 && a.wdiv_tw_sh < 32, "conv_wino: plan without tile grid");
+    EVR_REQUIRE((int64_t)a.n * a.hin * a.win * a.c0 * 4 < 0xFFFFFF00LL, "conv_wino: input tensor exceeds the buffer-descriptor range");
+    const int64_t Mt = (int64_t)a.n * a.wino_th * a.wino_tw;
+    const int64_t total = ((Mt + 63) / 64) * (a.cout / 64);
+    EVR_REQUIRE(total < (1LL << 31), "conv_wino: grid too large");
+    static const bool fast_act = getenv("EVR_WINO_FASTACT") ? atoi(getenv("EVR_WINO_FASTACT")) != 0 : false;
+    if (a.epi == EPI_LSTM) {
+        if (fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
+        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
+    } else {
+        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
+    }
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+}  // namespace evr

@@ -94,6 +94,26 @@ def test_drift_100_frames_346x260_8_sequences():
     print(f'100-frame drift, 8 sequences: worst per-pixel error {worst:.2e}')
 
 
+def test_exact_fp32_twin_winograd_346x260():
+    """The library's exact-fp32 twin (what a saturated group of sequences is re-run on) computes its ConvLSTM gate and residual
+    convolutions as Winograd F(2x2, 3x3) since round 6 (csrc/wino.hip): 346x260 puts ODD grids under it (132x176, 66x88, 33x44 -- the
+    last tile row of 33 rows has one valid output row), 3 sequences make ragged tile blocks.  20 recurrent frames against the oracle at
+    north_star's 1e-4; the states at the end.  (tests/test_gpu_modes.py runs the golden suite on this form and on EVR_WINO=0.)"""
+    from evreal_amd import weights
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    m, o = _pair(dict(weights.E2VID_KWARGS), seed=23)
+    twin = m.exact_twin()
+    assert twin.arith == 'fp32'
+    global IMG_ATOL
+    keep, IMG_ATOL = IMG_ATOL, 1e-4
+    try:
+        worst = _run(twin, o, 260, 346, 3, frames=20, n_seq=3, n_events=15000, seed0=70000, check_states=True)
+    finally:
+        IMG_ATOL = keep
+    print(f'exact-fp32 twin (Winograd {os.environ.get("EVR_WINO", "on")}), 20 frames x 3 sequences: worst per-pixel error {worst:.2e}')
+    assert worst < 2e-5, worst      # measured 1e-6-class; a wrong tile or weight position is 1e-1
+
+
 def test_one_sequence_split_k_100_frames_346x260():
     """The reference's own operating point -- ONE sequence, batch 1 (eval.py:72) -- runs the deep layers (12 tiles of 128 pixels at
     33 x 44) through the split-K forms of the band kernels (conv.hip launch_band / launch_band_prog: up to four blocks per tile, partial
