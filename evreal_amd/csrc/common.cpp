@@ -21,7 +21,8 @@ const char* last_error() { return g_err; }
 extern "C" const char* evr_last_error(void) { return evr::last_error(); }
 // 1001 (round 4): evr_percentile_normalize requires its workspace (NULL is rejected); evr_model_arith reports the effective mode
 // 1002 (round 5): evr_model_desc::reserved[2] = arithmetic mode + 1 of THIS model (0: EVR_ARITH); evr_model_saturation_async
-extern "C" int evr_version(void) { return 1002; }
+// 1003 (round 6): evr_model_release_shape; evr_png_pool_* (native PNG writers, hostcodec.cpp)
+extern "C" int evr_version(void) { return 1003; }
 extern "C" int evr_device_info(int device, int* n_cu, int* clock_mhz, char* name_out, size_t name_len) {
     hipDeviceProp_t p;
     EVR_HIP(hipGetDeviceProperties(&p, device));

@@ -1118,14 +1118,15 @@ __global__ __launch_bounds__(256, (KSMAX > 4) ? 1 : 2) void conv_ksplit_epi4_ker
 }
 
 // the epilogue launch of a split-K convolution (ks runs per tile)
+constexpr int KSPLIT_RUNS_MAX = 8;      // what conv_ksplit_epi4_kernel<..., 8> sums; ksplit_cap clamps EVR_KSPLIT / EVR_KSPLIT_SMALL to it
 template <bool LSTM, bool GROUPED>
 static void launch_ksplit_epilogue(const ConvArgs* d_args, float* img, int total, int ks, const float* kws, hipStream_t stream) {
     static const int wide = getenv("EVR_KSPLIT_EPI4") ? atoi(getenv("EVR_KSPLIT_EPI4")) : 1;      // (A/B: 0 = one block per tile)
     constexpr bool can4 = !(LSTM && ARITH == 4);      // (P6 tensors are written as whole 16-channel groups: the ConvLSTM quad form has no writer)
     if constexpr (can4) if (wide) {
-        if (ks <= 4) hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 4>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws);
-        else hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 8>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws);
-        return;
+        if (ks <= 4) { hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 4>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws); return; }
+        if (ks <= KSPLIT_RUNS_MAX) { hipLaunchKernelGGL((conv_ksplit_epi4_kernel<LSTM, GROUPED, 8>), dim3(total * 4), dim3(256), 0, stream, d_args, img, ks, kws); return; }
+        // (more runs than the wide form sums -- ksplit_cap never lets that happen -- fall through to the any-count epilogue)
     }
     hipLaunchKernelGGL((conv_ksplit_epilogue_kernel<LSTM, GROUPED>), dim3(total), dim3(256), 0, stream, d_args, img, ks, kws);
 }
@@ -1135,9 +1136,12 @@ static void launch_ksplit_epilogue(const ConvArgs* d_args, float* img, int total
 // 2159 frames/s) and -1.0 % at four (5 runs for the 92-tile residual convolutions and enc2.rec: the 8-run epilogue kernel holds one block
 // per CU); caps of 5 / 6: -3 % at one sequence; 5-6 runs for 65-102 tiles with a six-run epilogue kernel at two blocks per CU: 2206 vs 2245 at
 // one sequence, equal at four.  EVR_KSPLIT sets the general cap, EVR_KSPLIT_SMALL the one for <= 64 tiles.
+// Both switches are clamped to KSPLIT_RUNS_MAX = 8: conv_ksplit_epi4_kernel<..., 8> sums at most eight partial sets (with
+// EVR_KSPLIT=16 the main kernel wrote sixteen and the epilogue silently summed the first eight).
 static int ksplit_cap(int total, int ks_max) {
     static const int ks_small = getenv("EVR_KSPLIT_SMALL") ? atoi(getenv("EVR_KSPLIT_SMALL")) : (getenv("EVR_KSPLIT") ? 0 : 8);
-    return (total <= 64 && ks_small > ks_max) ? ks_small : ks_max;
+    const int cap = (total <= 64 && ks_small > ks_max) ? ks_small : ks_max;
+    return cap > KSPLIT_RUNS_MAX ? KSPLIT_RUNS_MAX : cap;
 }
 // workspace of the split-K launches: ConvArgs::ksplit_ws, KSPLIT_WS_BYTES owned by the handle (model / LPIPS) whose plan this is --
 // allocated with the plan, freed with it, never touched in the launch path (no hipMalloc / synchronisation here: a step can be

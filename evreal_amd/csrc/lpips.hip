@@ -497,9 +497,15 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
     }
     {   // split-K partial sums of conv3..conv5 at small batches (conv.h KSPLIT_WS_BYTES): this handle's own -- it runs on the evaluation
         // stream beside a model's launches
+        // (only when a conv of this plan can split -- a split arithmetic and <= 192 tiles of 128 pixels -- and a failed allocation
+        // degrades to "never split" instead of failing the plan: ADVICE r5)
+        bool may_split = false;
+        for (int i = 1; i < 4; ++i) if (m->args[i].x3 && (int64_t)n2 * m->args[i].hm * m->args[i].wm <= 192LL * 128) may_split = true;
         float* kws = nullptr;
-        EVR_HIP(hipMalloc((void**)&kws, KSPLIT_WS_BYTES));
-        m->allocs.push_back((void*)kws);
+        if (may_split) {
+            if (hipMalloc((void**)&kws, KSPLIT_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); kws = nullptr; }
+            else m->allocs.push_back((void*)kws);
+        }
         for (int i = 0; i < 4; ++i) m->args[i].ksplit_ws = kws;
     }
     EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));

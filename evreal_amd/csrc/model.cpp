@@ -1551,6 +1551,13 @@ extern "C" int evr_model_destroy(evr_model* m) {
     return EVR_OK;
 }
 
+extern "C" int evr_model_release_shape(evr_model* m) {
+    EVR_REQUIRE(m, "evr_model_release_shape: null model");
+    m->release_shape();
+    m->H = m->W = 0; m->frame = 0;
+    return EVR_OK;
+}
+
 extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     EVR_REQUIRE(m && n_seq >= 1 && H >= 1 && W >= 1, "evr_model_reset_states: bad arguments");
@@ -1595,18 +1602,26 @@ extern "C" int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)m->desc.num_bins * m->desc.kernel_size * m->desc.kernel_size * m->desc.base_num_channels;
     m->flops += 2.0 * n_seq * m->hp * m->wp * (double)(fire_padded ? m->desc.base_num_channels : m->pred_c);
     {   // split-K partial sums of this model's under-filled launches (conv.h KSPLIT_WS_BYTES): owned by the shape -- one device, one
-        // stream at a time -- freed with it, never zeroed (every split launch writes what its epilogue kernel reads)
+        // stream at a time -- freed with it, never zeroed (every split launch writes what its epilogue kernel reads).  Only the split
+        // arithmetics have kernels that split (the exact-fp32 twin never does), and only launches of <= 192 tiles of 128 pixels do;
+        // a failed allocation degrades to "never split" (the launchers treat a null workspace that way) instead of failing the plan
+        bool may_split = false;
+        for (auto& c : m->convs)
+            if (c.x3 && (int64_t)c.args[0].n * c.args[0].hm * c.args[0].wm <= 192LL * 128) may_split = true;
         float* kws = nullptr;
-        EVR_HIP(hipMalloc((void**)&kws, KSPLIT_WS_BYTES));
-        m->shape_consts.push_back(kws);
+        if (may_split) {
+            if (hipMalloc((void**)&kws, KSPLIT_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); kws = nullptr; }
+            else m->shape_consts.push_back(kws);
+        }
         for (auto& c : m->convs) { c.args[0].ksplit_ws = kws; c.args[1].ksplit_ws = kws; }
     }
-    // upload the launch plans
+    // upload the launch plans (a failure here leaves no half-built shape behind: the next reset re-plans)
     std::vector<ConvArgs> all;
     for (auto& c : m->convs) { c.arg_slot = (int)all.size(); all.push_back(c.args[0]); all.push_back(c.args[1]); }
-    EVR_HIP(hipMalloc((void**)&m->d_args, all.size() * sizeof(ConvArgs)));
-    EVR_HIP(hipMemcpyAsync(m->d_args, all.data(), all.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, stream));
-    EVR_HIP(hipStreamSynchronize(stream));
+    hipError_t he = hipMalloc((void**)&m->d_args, all.size() * sizeof(ConvArgs));
+    if (he == hipSuccess) he = hipMemcpyAsync(m->d_args, all.data(), all.size() * sizeof(ConvArgs), hipMemcpyHostToDevice, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    if (he != hipSuccess) { m->release_shape(); return hip_fail(he, "upload of the launch plans", __FILE__, __LINE__); }
     return EVR_OK;
 }
 

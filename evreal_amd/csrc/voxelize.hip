@@ -502,7 +502,9 @@ bool make_plan(int64_t n_events_total, int n_windows, int B, int H, int W, VoxPl
 
 // internal second stream of the chunked form (voxelize_impl), one per device, created on first use and kept for the process
 constexpr int MAX_CHUNKS = 16;
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr; hipEvent_t done[MAX_CHUNKS] = {}; };
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr; hipEvent_t done[MAX_CHUNKS] = {};
+                    std::mutex mu; };      // (one enqueue at a time per device, whichever form of the call -- ADVICE r5: a `static` mutex inside the
+                                           //  templated caller gave the raw and the fp32 instantiation one each over the SAME stream and events)
 SideStream* side_stream(int dev) {
     static SideStream pool[64];
     static std::atomic<int> state[64];      // 0 none, 1 being created, 2 ready, 3 failed
@@ -608,8 +610,7 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
         launch_range(0, n_windows, 1);
         EVR_LAUNCH_CHECK();
     } else {
-        static std::mutex mu;      // the side stream and its events are per device, shared by every caller: one enqueue at a time
-        std::lock_guard<std::mutex> lock(mu);
+        std::lock_guard<std::mutex> lock(ss->mu);      // the side stream and its events are per device, shared by every caller
         // the side stream joins behind the caller's earlier work (a previous call's range launch may still read this workspace)
         EVR_HIP(hipEventRecord(ss->fork, stream));
         EVR_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));

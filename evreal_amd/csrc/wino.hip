@@ -69,6 +69,7 @@ bool wino_eligible(const ConvArgs& a) {
     if (a.c0 % 8 || (a.in_mode == IN_CAT && a.c1 != a.c0) || a.cout % 64 || a.n_valid != a.cout) return false;
     if (((a.c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) / 8) % 2) return false;      // (the chunk loop is unrolled by its two LDS buffers)
     if (a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed) return false;
+    if ((int64_t)a.n * a.hin * a.win * (a.epi == EPI_LSTM ? a.hidden : a.cout_total) * 4 > 0xBFFF0000LL) return false;      // (EPI_OOB, wino.hip)
     if (a.epi == EPI_LSTM) return a.hidden % 16 == 0 && a.cout == 4 * a.hidden;
     return (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RESIDUAL_RELU) && a.cout_total == a.cout;
 }
@@ -79,9 +80,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned sh) { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> sh); }
-// Gate activations: FAST = v_exp_f32 / v_rcp_f32 forms (absolute error ~2e-7, the split kernels' forms), else libm-grade
+// Gate activations: FAST (the default here) = v_exp_f32 / v_rcp_f32 forms, absolute error ~2e-7 -- a fifth of what the fp32 summation
+// order of a 4608-term convolution leaves (1e-6); EVR_WINO_FASTACT=0: libm-grade (3200 instead of 350 instructions per tile and lane)
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
     if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
     else return 1.0f / (1.0f + expf(-x));
@@ -94,6 +97,10 @@ template <bool FAST> __device__ __forceinline__ float tanh_t(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
+// the epilogue ADDS up to 96 bytes to a pixel's offset (channel runs of one lane): its marker must not wrap past 2^32 -- 0xFFFFFFF0 + 32
+// is byte 16 of the tensor, and the dropped store of a pixel that does not exist became a store into pixel 0.  Output tensors beyond
+// 3 GiB stay on the direct form (wino_eligible)
+constexpr unsigned EPI_OOB = 0xC0000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
@@ -102,7 +109,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 constexpr int UV_F4 = 2048;      // float4 per 32-KB image: [pos 16][half 2][lane 64]
 
 template <bool LSTM, bool FAST>
-__global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap) {
+__global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap, int total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     // four separate LDS objects: hipcc's waitcnt insertion then knows that an LDS-DMA into one U buffer does not alias the fragment
@@ -115,37 +122,49 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     const int H = a.hin, W = a.win, tw = a.wino_tw, tpi = a.wino_th * tw;
     const int Mt = a.n * tpi;
     const int ncb = a.cout >> 6;
-    int lin;
-    {   // XCD-aware bijective remap of the 1-D grid (block b runs on XCD b % 8)
-        const int total = gridDim.x, bid = blockIdx.x;
-        const int q = total >> 3, rr = total & 7, xcd = bid & 7, idx = bid >> 3;
-        lin = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    // PERSISTENT blocks (one per CU: 128 KB of LDS, 512 registers per lane): block b runs on XCD b % 8; every XCD owns a contiguous
+    // range of the (tile block, column block) items, column block fastest, and its blocks walk it with the stride of their count --
+    // at any time the CUs of an XCD work on neighbouring tile blocks x all column blocks (shared input lines in the XCD's L2).
+    // A new work-group per item cost ~10 us of launch, cold-start latency and drain per 27-us item at 128 input channels.
+    int item, item_end, stride;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+        const int q = total >> 3, r = total & 7;
+        const int start = xcd * q + (xcd < r ? xcd : r);
+        item_end = start + q + (xcd < r ? 1 : 0);
+        stride = (nblk - xcd + 7) >> 3;
+        item = start + (bid >> 3);
     }
-    const int cb = lin % ncb, mt = lin / ncb;
+    if (item >= item_end) return;
     const int c0 = a.c0;
     const int nch = (c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) >> 3;      // (even: checked at launch)
     const int nch0 = c0 >> 3;
     const unsigned in_bytes = (unsigned)a.n * (unsigned)H * (unsigned)W * (unsigned)c0 * 4u;
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt_wino, (unsigned)a.cout * (unsigned)(nch * 8) * 64u);
+    const unsigned wdt_mul = a.wdiv_t_mul, wdt_sh = a.wdiv_t_sh, wdw_mul = a.wdiv_tw_mul, wdw_sh = a.wdiv_tw_sh;
 
     // ---- input-transform role: thread = (tile tt of the block's 64, channel pair cp of the chunk's 8 channels)
     const int tt = tid >> 2, cp = tid & 3;
     unsigned poff[16];
-    {
+    const unsigned pixb = (unsigned)c0 * 4u, rowb = (unsigned)W * pixb;
+    auto set_patch_offsets = [&](int mt) {
         const int m = mt * 64 + tt;
         const bool tvalid = m < Mt;
         const int mm = tvalid ? m : 0;
-        const int img = fdiv(mm, a.wdiv_t_mul, a.wdiv_t_sh), rem = mm - img * tpi;
-        const int ty = fdiv(rem, a.wdiv_tw_mul, a.wdiv_tw_sh), tx = rem - ty * tw;
+        const int img = fdiv(mm, wdt_mul, wdt_sh), rem = mm - img * tpi;
+        const int ty = fdiv(rem, wdw_mul, wdw_sh), tx = rem - ty * tw;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        // (one multiply chain, then adds: with a product per pixel hipcc guards each of the 16 offsets with its own branch)
+        const unsigned base = (unsigned)((img * H + y0) * W + x0) * pixb + (unsigned)(cp * 8);      // (wraps for y0 / x0 = -1: never used then)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
-                const bool ok = tvalid && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                poff[r * 4 + c] = ok ? ((unsigned)((img * H + y) * W + x) * (unsigned)c0 + (unsigned)(cp * 2)) * 4u : OOB_OFFSET;
+                const bool ok = tvalid && (unsigned)(y0 + r) < (unsigned)H && (unsigned)(x0 + c) < (unsigned)W;
+                const unsigned o = base + (unsigned)r * rowb + (unsigned)c * pixb;
+                poff[r * 4 + c] = ok ? o : OOB_OFFSET;
             }
-    }
+    };
     // V image: [pos][wt][kp][tile 32][4 k] floats; this thread's 8-B slot at pos 0
     const int vslot = (((tt >> 5) * 2 + (cp >> 1)) * 32 + (tt & 31)) * 4 + (cp & 1) * 2;
 
@@ -175,32 +194,74 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         *(f2*)(vimg + (xi * 4 + 2) * 512) = v2;
         *(f2*)(vimg + (xi * 4 + 3) * 512) = v3;
     };
-    // the block's 32-KB weight image of chunk c: 32 lane-linear 1-KB pieces, 8 per wave (piece j of this wave)
+    // the 32-KB weight image of (column block cbx, chunk c): 32 lane-linear 1-KB pieces, 8 per wave (piece j of this wave)
     const unsigned u_voff = (unsigned)(lane * 16 + wv * 8192);
-    auto issue_u = [&](int c, int j, float4* ubuf) {
-        const unsigned soff = (unsigned)((cb * nch + c) * 32768);
+    auto issue_u = [&](int cbx, int c, int j, float4* ubuf) {
+        const unsigned soff = (unsigned)((cbx * nch + c) * 32768);
         lds_ptr_t dst = (lds_ptr_t)&ubuf[(wv * 8 + j) * 64];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, u_voff + (unsigned)(j * 1024), soff, 0, 0);
     };
 
     f32x16 acc[16];
+    int cb = item % ncb, mt = item / ncb;      // the item being computed
+    int cbn = cb, mtn = mt; bool has_next = false;      // the item after it (prefetched by the last chunk's step)
+
+    // epilogue operands requested by the last chunk's step, a whole step before they are used.  Every epilogue access is a buffer
+    // operation with a 32-bit byte offset: pixels that do not exist (ragged last tile block, the odd last row / column of the grid)
+    // carry EPI_OOB -- loads return 0, stores are dropped by the range check -- so there is no branch and no 64-bit address
+    const int hl = lane >> 5;
+    unsigned eoff[4];  // byte offset of the lane's first channel at the tile's 4 output pixels (py * 2 + px)
+    f4 eb[4];          // bias runs of the lane's 4 x 4 rows
+    f4 ecp[4];         // ConvLSTM: cell state of the lane's 4 channels at those pixels
+    const unsigned out_bytes = (unsigned)a.n * (unsigned)H * (unsigned)W * (unsigned)(LSTM ? a.hidden : a.cout_total) * 4u;
+    auto epi_prefetch = [&]() {
+        const int me = mt * 64 + wt * 32 + (lane & 31);
+        const bool evalid = me < Mt;
+        const int mme = evalid ? me : 0;
+        const int eimg = fdiv(mme, wdt_mul, wdt_sh), erem = mme - eimg * tpi;
+        const int ety = fdiv(erem, wdw_mul, wdw_sh), etx = erem - ety * tw;
+        const unsigned cpp = (unsigned)(LSTM ? a.hidden : a.cout_total) * 4u;
+        const unsigned chan0 = LSTM ? (unsigned)(cb * 16 + wc * 8 + 4 * hl) : (unsigned)(cb * 64 + wc * 32 + 4 * hl);
+        const unsigned ebase = (unsigned)((eimg * H + 2 * ety) * W + 2 * etx) * cpp + chan0 * 4u;
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = evalid && 2 * ety + (p >> 1) < H && 2 * etx + (p & 1) < W;
+            const unsigned o = ebase + (unsigned)(p >> 1) * (unsigned)W * cpp + (unsigned)(p & 1) * cpp;
+            eoff[p] = ok ? o : EPI_OOB;
+        }
+        const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.bias, (unsigned)a.cout * 4u);
+        if constexpr (LSTM) {
+            const unsigned brow = ((chan0 >> 5) * 128u + (chan0 & 31u)) * 4u;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
+            for (int q = 0; q < 4; ++q) eb[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsb, brow + 128u * q, 0, 0));
+            const __amdgpu_buffer_rsrc_t rss = make_rsrc(a.state, out_bytes);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ecp[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rss, eoff[p], 0, 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) eb[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsb, chan0 * 4u + 32u * q, 0, 0));
+        }
+    };
 
     // One K chunk: 64 MFMAs (16 positions x 4) on the images of buffer B, and -- spread over the positions so that it issues in
     // the MFMAs' shadow -- the next chunk's weight DMA (two pieces at each of positions 0-3), its input transform (column pass at
     // 0-3, row pass + V stores at 4-7) and the patch loads of the chunk after it (four at each of positions 4-7, right behind
     // the column pass that frees the staging registers: they have 12 positions ~ 3000 cycles to land).
-    // MODE 2: both follow; 1: only the next chunk follows (no patch loads); 0: the last chunk
-    auto step = [&](auto bufc, auto modec, int c) {
+    // MODE 2: both follow; 1: only the next chunk follows (no patch loads); 0: the item's last chunk -- it requests the epilogue's
+    // operands and, when the block has a further item, that item's first weight image and patch (the buffers of parity 0 are free
+    // from this step's barrier on), so that the next item's cold start hides under this item's epilogue.
+    // FIRST: an item's first chunk.  Its weight image was requested BEFORE the chunk-0 patch this thread has already consumed
+    // (loads complete in order), so only the block-wide barrier is needed; the explicit count of the other steps would be wrong
+    // behind an epilogue's stores.
+    auto step = [&](auto bufc, auto modec, auto firstc, int c) {
         constexpr int B = decltype(bufc)::value, MODE = decltype(modec)::value;
+        constexpr bool FIRST = decltype(firstc)::value != 0;
         float4* ucur = B ? ldsU1 : ldsU0; float4* unext = B ? ldsU0 : ldsU1;
         float4* vcur = B ? ldsV1 : ldsV0; float4* vnext = B ? ldsV0 : ldsV1;
         // U[c] (LDS-DMA) must have landed; the 16 patch loads requested behind it (memory operations complete in order) may stay in
         // flight -- the step before the last one requests none
-        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (FIRST) asm volatile("" ::: "memory");
+        else if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // V[c] and U[c] are whole; every wave has left the other buffers
         asm volatile("" ::: "memory");
@@ -208,15 +269,29 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         const float4* lv = vcur + wt * 64 + lane;
         __amdgpu_buffer_rsrc_t rsp = rsw;
         if constexpr (MODE == 2) rsp = patch_rsrc(c + 2);
+        if constexpr (MODE == 0) rsp = patch_rsrc(0);
         float4 u = lu[0], v = lv[0];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             float4 un = u, vn = v;
             if (p < 15) { un = lu[(p + 1) * 128]; vn = lv[(p + 1) * 128]; }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, acc[p], 0, 0, 0);
+            if constexpr (FIRST) {
+                // (the accumulators of a new item start at zero: the first MFMA of every position takes a zero C operand)
+                f32x16 z;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] = 0.f;
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, z, 0, 0, 0);
+            } else {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, acc[p], 0, 0, 0);
+            }
             if constexpr (MODE >= 1) {
-                if (p < 4) { issue_u(c + 1, 2 * p, unext); issue_u(c + 1, 2 * p + 1, unext); col_pass(p); }
+                if (p < 4) { issue_u(cb, c + 1, 2 * p, unext); issue_u(cb, c + 1, 2 * p + 1, unext); col_pass(p); }
                 else if (p < 8) row_pass_store(p - 4, vnext);
+            }
+            if constexpr (MODE == 0) {
+                if (p == 0) epi_prefetch();
+                if (p == 1 && has_next) set_patch_offsets(mtn);
+                if (p >= 2 && p < 6 && has_next) { issue_u(cbn, 0, 2 * (p - 2), unext); issue_u(cbn, 0, 2 * (p - 2) + 1, unext); }
             }
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, v.y, acc[p], 0, 0, 0);
             if constexpr (MODE == 2) {
@@ -224,6 +299,13 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         S[(p - 4) * 4 + i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 4) * 4 + i], 0, 0));
+                }
+            }
+            if constexpr (MODE == 0) {
+                if (p >= 6 && p < 10 && has_next) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        S[(p - 6) * 4 + i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 6) * 4 + i], 0, 0));
                 }
             }
             acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, v.z, acc[p], 0, 0, 0);
@@ -234,114 +316,139 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
 
-    // prologue: U[0] requested, patch 0 transformed into V0, patch 1 staged
+    // A^T m A of accumulator register j: y[py * 2 + px]
+    auto otrans = [&](auto jc, float (&y)[4]) {
+        constexpr int j = decltype(jc)::value;
+        float s0[4], s1[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) issue_u(0, j, ldsU0);
+        for (int xi = 0; xi < 4; ++xi) {
+            // (read where they are used: as plain values hipcc copies all 256 accumulator registers out of the AGPRs right behind
+            // each position's last MFMA of the last step -- 256 live VGPRs, 388 B of scratch per lane)
+            float m0, m1, m2, m3;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m0) : "a"(acc[xi * 4 + 0][j]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m1) : "a"(acc[xi * 4 + 1][j]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m2) : "a"(acc[xi * 4 + 2][j]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m3) : "a"(acc[xi * 4 + 3][j]));
+            s0[xi] = (m0 + m1) + m2;
+            s1[xi] = (m1 - m2) - m3;
+        }
+        y[0] = (s0[0] + s0[1]) + s0[2];
+        y[2] = (s0[1] - s0[2]) - s0[3];
+        y[1] = (s1[0] + s1[1]) + s1[2];
+        y[3] = (s1[1] - s1[2]) - s1[3];
+        __builtin_amdgcn_sched_barrier(0);      // (one register's 16 reads and 24 adds at a time: otherwise the adds sink and 128 values are live)
+    };
+
+    // prologue of the block's first item: U[0] requested, patch 0 transformed into V0, patch 1 staged
+    set_patch_offsets(mt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_u(cb, 0, j, ldsU0);
     {
         const __amdgpu_buffer_rsrc_t rs = patch_rsrc(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) S[i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, poff[i], 0, 0));
+    }
+    for (;;) {
+        // (re-entered per item: S holds the item's chunk-0 patch -- requested by the prologue above or by the previous item's last step)
 #pragma unroll
         for (int c = 0; c < 4; ++c) col_pass(c);
+        {
+            const __amdgpu_buffer_rsrc_t rs1 = patch_rsrc(1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs1, poff[i], 0, 0));
+        }
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) row_pass_store(xi, ldsV0);
-        const __amdgpu_buffer_rsrc_t rs1 = patch_rsrc(1);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs1, poff[i], 0, 0));
-    }
-    int c = 0;
-    for (; c + 3 < nch; c += 2) { step(I0{}, I2{}, c); step(I1{}, I2{}, c + 1); }
-    step(I0{}, I1{}, c);
-    step(I1{}, I0{}, c + 1);
+        {
+            const int nxt = item + stride;
+            has_next = nxt < item_end;
+            cbn = has_next ? nxt % ncb : cb; mtn = has_next ? nxt / ncb : mt;
+        }
+        step(I0{}, I2{}, I1{}, 0);
+        step(I1{}, I2{}, I0{}, 1);
+        int c = 2;
+        for (; c + 3 < nch; c += 2) { step(I0{}, I2{}, I0{}, c); step(I1{}, I2{}, I0{}, c + 1); }
+        if (c + 2 < nch) { step(I0{}, I2{}, I0{}, c); step(I1{}, I2{}, I0{}, c + 1); c += 2; }      // (not taken: nch - 2 is even)
+        step(I0{}, I1{}, I0{}, c);
+        step(I1{}, I0{}, I0{}, c + 1);
 
-    // ---- epilogue: lane = tile (lane & 31), register j of an accumulator = row 8*(j>>2) + 4*(lane>>5) + (j&3) of the wave's 32
-    const int hl = lane >> 5;
-    const int me = mt * 64 + wt * 32 + (lane & 31);
-    const bool evalid = me < Mt;
-    const int mme = evalid ? me : 0;
-    const int eimg = fdiv(mme, a.wdiv_t_mul, a.wdiv_t_sh), erem = mme - eimg * tpi;
-    const int ety = fdiv(erem, a.wdiv_tw_mul, a.wdiv_tw_sh), etx = erem - ety * tw;
-    bool pok[4]; unsigned ppix[4];
+        // ---- epilogue: lane = tile (lane & 31), register j of an accumulator = row 8*(j>>2) + 4*(lane>>5) + (j&3) of the wave's 32
+        if constexpr (LSTM) {
+            // the wave's 32 rows = 4 gates (in, remember, out, cell: submodules.py:231) x 8 hidden channels; this lane: 4 channels,
+            // finished two at a time (8-byte stores: the 4 x 4 transpose of whole 16-byte runs costs 16 registers this loop does not have)
+            const __amdgpu_buffer_rsrc_t rss = make_rsrc(a.state, out_bytes), rso = make_rsrc(a.out, out_bytes);
+            auto chan2 = [&](auto ic) {
+                constexpr int i0 = decltype(ic)::value;
+                f2 cn[4], hn[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int oy = 2 * ety + (p >> 1), ox = 2 * etx + (p & 1);
-        pok[p] = evalid && oy < H && ox < W;
-        ppix[p] = pok[p] ? (unsigned)((eimg * H + oy) * W + ox) : 0u;
-    }
-    // A^T m A for register j: y[py*2 + px]
-    float Y[4][16];
+                for (int ii = 0; ii < 2; ++ii) {
+                    float yi[4], yf[4], yo[4], yc[4];
+                    if (ii == 0) {
+                        otrans(std::integral_constant<int, 0 + i0>{}, yi); otrans(std::integral_constant<int, 4 + i0>{}, yf);
+                        otrans(std::integral_constant<int, 8 + i0>{}, yo); otrans(std::integral_constant<int, 12 + i0>{}, yc);
+                    } else {
+                        otrans(std::integral_constant<int, 1 + i0>{}, yi); otrans(std::integral_constant<int, 5 + i0>{}, yf);
+                        otrans(std::integral_constant<int, 9 + i0>{}, yo); otrans(std::integral_constant<int, 13 + i0>{}, yc);
+                    }
+                    const int i = i0 + ii;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            const float m0 = acc[xi * 4 + 0][j], m1 = acc[xi * 4 + 1][j], m2 = acc[xi * 4 + 2][j], m3 = acc[xi * 4 + 3][j];
-            s0[xi] = (m0 + m1) + m2;
-            s1[xi] = (m1 - m2) - m3;
-        }
-        Y[0][j] = (s0[0] + s0[1]) + s0[2];
-        Y[2][j] = (s0[1] - s0[2]) - s0[3];
-        Y[1][j] = (s1[0] + s1[1]) + s1[2];
-        Y[3][j] = (s1[1] - s1[2]) - s1[3];
-    }
-    if constexpr (LSTM) {
-        // the wave's 32 rows = 4 gates (in, remember, out, cell: submodules.py:231) x 8 hidden channels; this lane: 4 channels
-        const int C = a.hidden;
-        const int ch = cb * 16 + wc * 8 + 4 * hl;
-        const int brow = (ch >> 5) * 128 + (ch & 31);
-        f4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *(const f4*)(a.bias + brow + q * 32);
-        f4 cprev[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) cprev[p] = *(const f4*)(a.state + ppix[p] * (unsigned)C + (unsigned)ch);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            f4 cn, hn;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float gi = sigmoid_t<FAST>(Y[p][0 + i] + bq[0][i]);
-                const float gf = sigmoid_t<FAST>(Y[p][4 + i] + bq[1][i]);
-                const float go = sigmoid_t<FAST>(Y[p][8 + i] + bq[2][i]);
-                const float gc = tanh_t<FAST>(Y[p][12 + i] + bq[3][i]);
-                cn[i] = __fadd_rn(__fmul_rn(gf, cprev[p][i]), __fmul_rn(gi, gc));      // submodules.py:242
-                hn[i] = go * tanh_t<FAST>(cn[i]);                                       // submodules.py:243
-            }
-            if (pok[p]) {
-                *(f4*)(a.state + ppix[p] * (unsigned)C + (unsigned)ch) = cn;
-                *(f4*)(a.out + ppix[p] * (unsigned)C + (unsigned)ch) = hn;
-            }
-        }
-    } else {
-        const int epi = a.epi;
-        const bool res = (epi == EPI_RESIDUAL_RELU), relu = (epi != EPI_BIAS);
-        const unsigned ct = (unsigned)a.cout_total;
-        const int cbase = cb * 64 + wc * 32 + 4 * hl;
-        f4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *(const f4*)(a.bias + cbase + 8 * q);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned row = ppix[p] * ct;
-            f4 rv[4], sv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                rv[q] = res ? *(const f4*)(a.residual + row + (unsigned)(cbase + 8 * q)) : f4{0.f, 0.f, 0.f, 0.f};
-                sv[q] = a.post_add ? *(const f4*)(a.post_add + row + (unsigned)(cbase + 8 * q)) : f4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f4 v;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = Y[p][4 * q + i] + bq[q][i];
-                    t += rv[q][i];
-                    t = relu ? fmaxf(t, 0.f) : t;
-                    v[i] = t + sv[q][i];
+                    for (int p = 0; p < 4; ++p) {
+                        const float gi = sigmoid_t<FAST>(yi[p] + eb[0][i]);
+                        const float gf = sigmoid_t<FAST>(yf[p] + eb[1][i]);
+                        const float go = sigmoid_t<FAST>(yo[p] + eb[2][i]);
+                        const float gc = tanh_t<FAST>(yc[p] + eb[3][i]);
+                        const float cv = __fadd_rn(__fmul_rn(gf, ecp[p][i]), __fmul_rn(gi, gc));      // submodules.py:242
+                        cn[p][ii] = cv;
+                        hn[p][ii] = go * tanh_t<FAST>(cv);                                          // submodules.py:243
+                    }
                 }
-                if (pok[p]) *(f4*)(a.out + row + (unsigned)(cbase + 8 * q)) = v;
-            }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, cn[p]), rss, eoff[p] + 4u * i0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, hn[p]), rso, eoff[p] + 4u * i0, 0, 0);
+                }
+            };
+            // (one channel pair at a time: left alone, hipcc hoists all 256 accumulator reads and spills)
+            chan2(I0{}); __builtin_amdgcn_sched_barrier(0);
+            chan2(I2{}); __builtin_amdgcn_sched_barrier(0);
+        } else {
+            const int epi = a.epi;
+            const bool res = (epi == EPI_RESIDUAL_RELU), relu = (epi != EPI_BIAS);
+            const bool padd = a.post_add != nullptr;
+            const __amdgpu_buffer_rsrc_t rso = make_rsrc(a.out, out_bytes);
+            const __amdgpu_buffer_rsrc_t rsr = make_rsrc(res ? a.residual : a.out, res ? out_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rsp = make_rsrc(padd ? a.post_add : a.out, padd ? out_bytes : 0u);      // (0 records: every load returns 0)
+            auto group = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                f4 rv[4], sv[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    rv[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsr, eoff[p] + 32u * q, 0, 0));
+                    sv[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsp, eoff[p] + 32u * q, 0, 0));
+                }
+                float y0[4], y1[4], y2[4], y3[4];
+                otrans(std::integral_constant<int, 4 * q + 0>{}, y0);
+                otrans(std::integral_constant<int, 4 * q + 1>{}, y1);
+                otrans(std::integral_constant<int, 4 * q + 2>{}, y2);
+                otrans(std::integral_constant<int, 4 * q + 3>{}, y3);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f4 v = {y0[p], y1[p], y2[p], y3[p]};
+                    v += eb[q];
+                    v += rv[p];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu ? fmaxf(v[i], 0.f) : v[i];
+                    v += sv[p];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rso, eoff[p] + 32u * q, 0, 0);
+                }
+            };
+            group(I0{}); __builtin_amdgcn_sched_barrier(0);
+            group(I1{}); __builtin_amdgcn_sched_barrier(0);
+            group(I2{}); __builtin_amdgcn_sched_barrier(0);
+            group(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
         }
+        if (!has_next) break;
+        item += stride; cb = cbn; mt = mtn;
     }
 #endif
 }
@@ -354,13 +461,16 @@ int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stre
     EVR_REQUIRE((int64_t)a.n * a.hin * a.win * a.c0 * 4 < 0xFFFFFF00LL, "conv_wino: input tensor exceeds the buffer-descriptor range");
     const int64_t Mt = (int64_t)a.n * a.wino_th * a.wino_tw;
     const int64_t total = ((Mt + 63) / 64) * (a.cout / 64);
-    EVR_REQUIRE(total < (1LL << 31), "conv_wino: grid too large");
-    static const bool fast_act = getenv("EVR_WINO_FASTACT") ? atoi(getenv("EVR_WINO_FASTACT")) != 0 : false;
+    EVR_REQUIRE(total < (1LL << 31), "conv_wino: too many work items");
+    // persistent blocks, one per CU (EVR_WINO_BLOCKS overrides the count); libm-grade gate activations with EVR_WINO_FASTACT=0
+    static const int nblocks = getenv("EVR_WINO_BLOCKS") ? atoi(getenv("EVR_WINO_BLOCKS")) : 256;
+    static const bool fast_act = getenv("EVR_WINO_FASTACT") ? atoi(getenv("EVR_WINO_FASTACT")) != 0 : true;
+    const unsigned grid = (unsigned)(total < nblocks ? total : nblocks);
     if (a.epi == EPI_LSTM) {
-        if (fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
-        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
+        if (fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
     } else {
-        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, stream, d_args);
+        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
     }
     EVR_LAUNCH_CHECK();
     return EVR_OK;

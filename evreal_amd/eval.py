@@ -135,7 +135,12 @@ def get_model_from_checkpoint_path(model_name, checkpoint_path):
         _MODEL_CACHE[key] = model
         while len(_MODEL_CACHE) > 4:
             _, old = _MODEL_CACHE.popitem(last=False)
-            old.destroy()       # its HBM (weights, activations and state of the largest batch it ran) goes back now, not at some later GC
+            # Its HBM (weights, activations and state of the largest batch it ran) goes back NOW when the cache held the only
+            # reference; a caller that still holds the model (the reference's get_model_from_checkpoint_path hands out models
+            # the caller owns: eight methods loaded up front outlive a four-entry cache) keeps a working object -- it is freed by
+            # __del__ when the caller lets go.  refcount 2 = `old` + the argument of getrefcount.
+            if sys.getrefcount(old) <= 2 and hasattr(old, 'destroy'):
+                old.destroy()
     else:
         _MODEL_CACHE.move_to_end(key)
     return model
@@ -202,6 +207,17 @@ def _plan_items(ds, tb, sequence, infer_all):
     return todo, bad, idx
 
 
+def _range_guard_policy(eval_config):
+    """What a non-zero range counter of a split arithmetic does (eval config key `range_guard`, env EVREAL_RANGE_GUARD):
+    'rerun' (default) -- the pass is abandoned and the whole group of sequences re-run on the exact-fp32 twin, so results never
+    depend on the activation range; that twin is ~2.3x slower (2.4k vs 5.7k frames/s at 64 sequences) and its activations are
+    allocated after the first model's are released.  'warn' -- keep the first pass and print the counters (in the opt-in
+    `mx` / `mx6` modes a non-zero counter means some values kept f16-only precision, 2^-12 relative, not that they were clamped:
+    a user of those modes may prefer the fast result).  'off' -- no polling."""
+    v = str(eval_config.get('range_guard', os.environ.get('EVREAL_RANGE_GUARD', 'rerun'))).lower()
+    return v if v in ('rerun', 'warn', 'off') else 'rerun'
+
+
 class _Saturated(Exception):
     """Activations of the running chunk left the split arithmetic's exact range (evr_model_saturation): nothing of it is booked."""
 
@@ -217,6 +233,10 @@ def _rerun_exact(model, trackers, names):
         t.discard()
     print(f"[evreal_amd.eval] {n} activation runs of {names} left the exact range of the '{model.arith}' split format (most in layer "
           f"'{layer}'): re-running in exact fp32 on the GPU (the library's fp32 kernels); no score, image or line of the first pass is kept")
+    # the first model's activations / states for these S sequences go back before the twin allocates its own (both
+    # resident at once risked running out of HBM at large batch_sequences); its weights stay for the next group
+    if hasattr(model, 'release_shape'):
+        model.release_shape()
     return model.exact_twin()
 
 
@@ -236,7 +256,8 @@ def eval_method_on_sequence(dataset_name, eval_config, method_name, model, metho
 
 
 def _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequence):
-    guard = hasattr(model, 'saturation') and getattr(model, 'arith', 'fp32') != 'fp32'
+    policy = _range_guard_policy(eval_config)
+    guard = policy != 'off' and hasattr(model, 'saturation') and getattr(model, 'arith', 'fp32') != 'fp32'
     model.reset_states()
     if guard:
         model.saturation(clear=True)        # counters are cumulative: this sequence starts from zero
@@ -256,7 +277,10 @@ def _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequenc
             normalize_event_tensor(grid, stats)
         bgr = [model(grid[j:j + 1])['image'][0] for j in range(n)]
         if guard and model.saturation()[0]:        # (synchronises; this loop copies every frame to the host anyway)
-            raise _Saturated()
+            if policy == 'rerun':
+                raise _Saturated()
+            model.model.warn_if_saturated(sequence['name']) if hasattr(model, 'model') else model.warn_if_saturated(sequence['name'])
+            guard = False
         tracker.update_batch_color(items, torch.stack(bgr), [float(v) for v in tb['voxel_timestamp'][items]])
         for i in items:
             cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
@@ -340,7 +364,9 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
                           all(ds.has_images for ds in dss)) for _ in range(2)]
     main = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(device=dev)
-    guard = hasattr(model, 'saturation_async') and getattr(model, 'arith', 'fp32') != 'fp32'
+    policy = _range_guard_policy(eval_config)
+    guard = policy != 'off' and hasattr(model, 'saturation_async') and getattr(model, 'arith', 'fp32') != 'fp32'
+    warned = [False]
     if guard:
         model._ensure(S, H, W)              # (the counters exist from the first reset on)
         model.saturation(clear=True)        # counters are cumulative: start this group from zero
@@ -381,7 +407,11 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
     def book(b):
         b.ev_done.synchronize()
         if guard and bool(b.h_sat.any()):
-            raise _Saturated(trackers)          # before anything of this chunk is written
+            if policy == 'rerun':
+                raise _Saturated(trackers)          # before anything of this chunk is written
+            if not warned[0]:
+                warned[0] = True
+                model.warn_if_saturated(', '.join(q['name'] for q in sequences) + " (range_guard: 'warn' -- results of the first pass are kept)")
         n = b.n
         sc = b.h_scores[:n * S].numpy().reshape(n, S, 2) if b.h_scores is not None else None
         lp = b.h_lp[:n * S].numpy().reshape(n, S) if b.h_lp is not None else None

@@ -55,6 +55,7 @@ SYMBOLS = {
                                  ctypes.POINTER(c_void_p)]),
     'evr_model_destroy': (c_int, [c_void_p]),
     'evr_model_reset_states': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    'evr_model_release_shape': (c_int, [c_void_p]),
     'evr_model_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint, c_void_p]),
     'evr_model_read_tensor': (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     'evr_model_flops_per_step': (c_double, [c_void_p]),

@@ -89,6 +89,13 @@ class _HipModel:
         if twin is not None:
             twin.destroy()
 
+    def release_shape(self):
+        """Return the activations / recurrent state of the last shape to the allocator (weights stay resident; the next call plans
+        again).  The caller has synchronised the streams that ran the model."""
+        if self.handle is not None:
+            _lib.check(self.lib.evr_model_release_shape(self.handle), 'evr_model_release_shape')
+        self._shape, self._needs_reset = None, True
+
     def exact_twin(self):
         """The same network on the library's exact-fp32 HIP kernels (fp32 MFMA, PLAIN tensors: the reference's arithmetic,
         model/submodules.py:227-245, and no range limit) -- what a sequence is re-run on when its activations left the split

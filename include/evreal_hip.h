@@ -38,7 +38,7 @@ enum evr_status {
 
 /* Message for the last failure on this thread ("" if none). */
 const char* evr_last_error(void);
-/* ABI version (major*1000 + minor).  1002 (round 5): evr_model_desc.reserved[2] (per-model arithmetic), evr_model_saturation_async.
+/* ABI version (major*1000 + minor).  1003 (round 6): evr_model_release_shape, evr_png_* (native PNG writer pool).  1002 (round 5): evr_model_desc.reserved[2] (per-model arithmetic), evr_model_saturation_async.
  * 1001 (round 4): evr_percentile_normalize rejects a NULL workspace (size it with
  * evr_percentile_normalize_workspace_bytes); evr_model_arith reports the mode the convolutions actually run (FireNet's 16-channel
  * layers: h3 whatever EVR_ARITH says). */
@@ -172,6 +172,10 @@ int evr_model_destroy(evr_model* m);
 /* (Re)allocate activations/state for n_seq sequences of H x W frames and zero the recurrent
  * state (model.reset_states(), eval.py:197). */
 int evr_model_reset_states(evr_model* m, int n_seq, int H, int W, evr_stream_t stream);
+/* Give the shape-dependent device memory (activations, recurrent state, launch plans) back without destroying the model: weights
+ * stay resident and the next evr_model_reset_states plans again.  The caller has synchronised every stream that ran the model.
+ * (ABI 1003: the drop-in frees a saturated model's buffers before its exact-fp32 twin allocates its own.) */
+int evr_model_release_shape(evr_model* m);
 /* One frame for each of the n_seq sequences: vox [n_seq, B, H, W] (unpadded) -> img
  * [n_seq, 1, H, W] (cropped).  Zero padding to a multiple of 2^pad_multiple_log2 and the centre
  * crop happen inside (utils/util.py:41-59).  flags: bit 0 = apply event-tensor normalization
