@@ -114,6 +114,7 @@ struct ConvArgs {
     const float* wgt_wino;
     int wino_th, wino_tw;
     unsigned wdiv_t_mul, wdiv_t_sh, wdiv_tw_mul, wdiv_tw_sh;
+    int wino_order;           // 1: items of a launch ordered 8 tile blocks x 4 column blocks per XCD round (wino.hip); 0: column block fastest
 };
 // A split launch has at most 512 blocks (one per resident slot) of 64 KB of partial accumulators each
 constexpr size_t KSPLIT_WS_BYTES = (size_t)512 * 4 * 16 * 64 * 16;
@@ -428,6 +429,7 @@ inline void set_wino_grid(ConvArgs& a) {
     a.wino_th = (a.hin + 1) / 2; a.wino_tw = (a.win + 1) / 2;
     fastdiv_magic((unsigned)(a.wino_th * a.wino_tw), &a.wdiv_t_mul, &a.wdiv_t_sh);
     fastdiv_magic((unsigned)a.wino_tw, &a.wdiv_tw_mul, &a.wdiv_tw_sh);
+    a.wino_order = getenv("EVR_WINO_ORDER") ? atoi(getenv("EVR_WINO_ORDER")) : 1;
 }
 // picks (wm, nb) for the shape: fills the 256 CUs when M is small
 void pick_conv_tile(const ConvArgs& a, int kc, int* wm, int* nb);

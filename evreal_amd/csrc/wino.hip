@@ -94,6 +94,10 @@ template <bool FAST> __device__ __forceinline__ float tanh_t(float x) {
     else return tanhf(x);
 }
 
+// two channels per instruction (hipcc splits the <2 x float> adds of the input transform into scalar v_add_f32 pairs)
+__device__ __forceinline__ f2 pk_add(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned OOB_OFFSET = 0xFFFFFFF0u;   // >= num_records of every descriptor -> the load returns 0
@@ -108,7 +112,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 constexpr int UV_F4 = 2048;      // float4 per 32-KB image: [pos 16][half 2][lane 64]
 
-template <bool LSTM, bool FAST>
+// VAR (timing experiments, EVR_WINO_VAR; bit 0 -- the MFMAs of two positions interleaved so that no two consecutive ones share an
+// accumulator -- measured no different and is gone): bit 1 = no side work at all (no DMA, transform or patch loads after the first chunk: results are garbage); bit 2 = side work on
+// cache-hot addresses (always chunk 0's weights and patch: garbage) -- separates the side work's issue cost from its memory latency;
+// bits 3 / 4 / 5 = no weight DMA / no patch loads / no transform and V stores after an item's first chunk
+template <bool LSTM, bool FAST, int VAR = 0>
 __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap, int total) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -177,23 +185,21 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         return make_rsrc(src, in_bytes);
     };
     // B^T d B in two passes: rows of d (over r) per patch column c, then columns per transform row xi -> the V image
-    auto col_pass = [&](int c) {
-        T[0 * 4 + c] = S[0 * 4 + c] - S[2 * 4 + c];
-        T[1 * 4 + c] = S[1 * 4 + c] + S[2 * 4 + c];
-        T[2 * 4 + c] = S[2 * 4 + c] - S[1 * 4 + c];
-        T[3 * 4 + c] = S[1 * 4 + c] - S[3 * 4 + c];
-    };
-    auto row_pass_store = [&](int xi, float4* vimg4) {
+    // (each pass in two halves, so that a step can spread them over the gaps between its MFMAs)
+    auto col_pass_a = [&](int c) { T[0 * 4 + c] = pk_sub(S[0 * 4 + c], S[2 * 4 + c]); T[1 * 4 + c] = pk_add(S[1 * 4 + c], S[2 * 4 + c]); };
+    auto col_pass_b = [&](int c) { T[2 * 4 + c] = pk_sub(S[2 * 4 + c], S[1 * 4 + c]); T[3 * 4 + c] = pk_sub(S[1 * 4 + c], S[3 * 4 + c]); };
+    auto col_pass = [&](int c) { col_pass_a(c); col_pass_b(c); };
+    f2 R[4];       // one transform row on its way to LDS
+    auto row_pass_a = [&](int xi) { R[0] = pk_sub(T[xi * 4 + 0], T[xi * 4 + 2]); R[1] = pk_add(T[xi * 4 + 1], T[xi * 4 + 2]); };
+    auto row_pass_b = [&](int xi) { R[2] = pk_sub(T[xi * 4 + 2], T[xi * 4 + 1]); R[3] = pk_sub(T[xi * 4 + 1], T[xi * 4 + 3]); };
+    auto row_store = [&](int xi, float4* vimg4) {
         float* vimg = (float*)vimg4 + vslot;
-        const f2 v0 = T[xi * 4 + 0] - T[xi * 4 + 2];
-        const f2 v1 = T[xi * 4 + 1] + T[xi * 4 + 2];
-        const f2 v2 = T[xi * 4 + 2] - T[xi * 4 + 1];
-        const f2 v3 = T[xi * 4 + 1] - T[xi * 4 + 3];
-        *(f2*)(vimg + (xi * 4 + 0) * 512) = v0;
-        *(f2*)(vimg + (xi * 4 + 1) * 512) = v1;
-        *(f2*)(vimg + (xi * 4 + 2) * 512) = v2;
-        *(f2*)(vimg + (xi * 4 + 3) * 512) = v3;
+        *(f2*)(vimg + (xi * 4 + 0) * 512) = R[0];
+        *(f2*)(vimg + (xi * 4 + 1) * 512) = R[1];
+        *(f2*)(vimg + (xi * 4 + 2) * 512) = R[2];
+        *(f2*)(vimg + (xi * 4 + 3) * 512) = R[3];
     };
+    auto row_pass_store = [&](int xi, float4* vimg4) { row_pass_a(xi); row_pass_b(xi); row_store(xi, vimg4); };
     // the 32-KB weight image of (column block cbx, chunk c): 32 lane-linear 1-KB pieces, 8 per wave (piece j of this wave)
     const unsigned u_voff = (unsigned)(lane * 16 + wv * 8192);
     auto issue_u = [&](int cbx, int c, int j, float4* ubuf) {
@@ -203,7 +209,20 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     };
 
     f32x16 acc[16];
-    int cb = item % ncb, mt = item / ncb;      // the item being computed
+    // item -> (column block, tile block).  Items are ordered so that 32 consecutive ones -- what the 32 CUs of an XCD hold at a time --
+    // are 8 tile blocks x 4 column blocks (EVR_WINO_ORDER=0 / ncb % 4 != 0: 2 x 16, column block fastest): a weight image is then
+    // shared by 8 CUs and an input patch by 4, instead of 2 and 16 -- 2.6x fewer bytes from the Infinity Cache per launch
+    const int ntb = (Mt + 63) >> 6;
+    const bool order2d = a.wino_order != 0 && (ncb & 3) == 0;
+    auto decode = [&](int it, int& cbo, int& mto) {
+        if (!order2d) { cbo = it % ncb; mto = it / ncb; return; }
+        const int per = 8 * ncb, grp = it / per, rem = it - grp * per;
+        const int gt = (ntb - 8 * grp) < 8 ? (ntb - 8 * grp) : 8;
+        const int cq = rem / (4 * gt), rem2 = rem - cq * 4 * gt;
+        cbo = cq * 4 + (rem2 & 3); mto = grp * 8 + (rem2 >> 2);
+    };
+    int cb, mt;      // the item being computed
+    decode(item, cb, mt);
     int cbn = cb, mtn = mt; bool has_next = false;      // the item after it (prefetched by the last chunk's step)
 
     // epilogue operands requested by the last chunk's step, a whole step before they are used.  Every epilogue access is a buffer
@@ -258,58 +277,68 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         constexpr bool FIRST = decltype(firstc)::value != 0;
         float4* ucur = B ? ldsU1 : ldsU0; float4* unext = B ? ldsU0 : ldsU1;
         float4* vcur = B ? ldsV1 : ldsV0; float4* vnext = B ? ldsV0 : ldsV1;
-        // U[c] (LDS-DMA) must have landed; the 16 patch loads requested behind it (memory operations complete in order) may stay in
-        // flight -- the step before the last one requests none
+        // U[c] (LDS-DMA) must have landed; the patch loads requested behind its last piece (memory operations complete in order) may
+        // stay in flight -- the step before the last one requests none
         if constexpr (FIRST) asm volatile("" ::: "memory");
-        else if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (MODE == 0 || (VAR & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // V[c] and U[c] are whole; every wave has left the other buffers
         asm volatile("" ::: "memory");
         const float4* lu = ucur + wc * 64 + lane;
         const float4* lv = vcur + wt * 64 + lane;
         __amdgpu_buffer_rsrc_t rsp = rsw;
-        if constexpr (MODE == 2) rsp = patch_rsrc(c + 2);
+        if constexpr (MODE == 2) rsp = patch_rsrc((VAR & 4) ? 0 : c + 2);
         if constexpr (MODE == 0) rsp = patch_rsrc(0);
+        constexpr bool SIDE = !(VAR & 2);
+        // Side work of (position p, gap g): gap g is the shadow of the position's MFMA g (64 cycles of the matrix pipe; a wave issues
+        // in order, so what sits between two MFMAs runs beside the first and delays the second once it is longer than that -- with
+        // the same work bunched behind the first two MFMAs of positions 0-7 a step took 4930 instead of 4096 cycles).
+        //   chunk c + 1: weight DMA pieces 2p, 2p + 1 at (p < 4, gaps 1 and 3); column pass of patch column p - 4 at (4 <= p < 8, gaps 2
+        //   and 3); row pass of transform row p - 12 at (p >= 12, gaps 1 and 2) and its V stores at gap 3
+        //   chunk c + 2: patch load (p - 8) * 4 + g at (8 <= p < 12, gap g) -- behind every DMA piece, so the wait at the top of the
+        //   next step can leave all 16 in flight; they are read 12 positions (~3000 cycles) later
+        //   last chunk of an item: epilogue operands at (0, 1), the next item's offsets at (1, 1), its first weight image at
+        //   (2 <= p < 10, gap 1), its first patch at (10 <= p < 14, gap g)
+        auto side = [&](int p, int g) {
+            if constexpr (!SIDE) { if constexpr (MODE == 0) { if (p == 0 && g == 1) epi_prefetch(); } return; }
+            if constexpr (MODE >= 1) {
+                if constexpr (!(VAR & 8)) { if (p < 4 && (g & 1)) issue_u(cb, (VAR & 4) ? 0 : c + 1, 2 * p + (g >> 1), unext); }
+                if constexpr (!(VAR & 32)) {
+                    if (p >= 4 && p < 8) { if (g == 2) col_pass_a(p - 4); if (g == 3) col_pass_b(p - 4); }
+                    if (p >= 12) { if (g == 1) row_pass_a(p - 12); if (g == 2) row_pass_b(p - 12); if (g == 3) row_store(p - 12, vnext); }
+                }
+            }
+            if constexpr (MODE == 2 && !(VAR & 16)) {
+                if (p >= 8 && p < 12) S[(p - 8) * 4 + g] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 8) * 4 + g], 0, 0));
+            }
+            if constexpr (MODE == 0) {
+                if (p == 0 && g == 1) epi_prefetch();
+                if (p == 1 && g == 1 && has_next) set_patch_offsets(mtn);
+                if (p >= 2 && p < 10 && g == 1 && has_next) issue_u(cbn, 0, p - 2, unext);
+                if (p >= 10 && p < 14 && has_next) S[(p - 10) * 4 + g] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 10) * 4 + g], 0, 0));
+            }
+        };
+        auto mma = [&](int p, float x, float y, bool first) {
+            if (FIRST && first) {      // (the accumulators of a new item start at zero: the first MFMA of every position takes a zero C operand)
+                f32x16 z;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) z[j] = 0.f;
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, z, 0, 0, 0);
+            } else acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[p], 0, 0, 0);
+        };
         float4 u = lu[0], v = lv[0];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             float4 un = u, vn = v;
+            mma(p, u.x, v.x, true);
             if (p < 15) { un = lu[(p + 1) * 128]; vn = lv[(p + 1) * 128]; }
-            if constexpr (FIRST) {
-                // (the accumulators of a new item start at zero: the first MFMA of every position takes a zero C operand)
-                f32x16 z;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) z[j] = 0.f;
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, z, 0, 0, 0);
-            } else {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, v.x, acc[p], 0, 0, 0);
-            }
-            if constexpr (MODE >= 1) {
-                if (p < 4) { issue_u(cb, c + 1, 2 * p, unext); issue_u(cb, c + 1, 2 * p + 1, unext); col_pass(p); }
-                else if (p < 8) row_pass_store(p - 4, vnext);
-            }
-            if constexpr (MODE == 0) {
-                if (p == 0) epi_prefetch();
-                if (p == 1 && has_next) set_patch_offsets(mtn);
-                if (p >= 2 && p < 6 && has_next) { issue_u(cbn, 0, 2 * (p - 2), unext); issue_u(cbn, 0, 2 * (p - 2) + 1, unext); }
-            }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, v.y, acc[p], 0, 0, 0);
-            if constexpr (MODE == 2) {
-                if (p >= 4 && p < 8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        S[(p - 4) * 4 + i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 4) * 4 + i], 0, 0));
-                }
-            }
-            if constexpr (MODE == 0) {
-                if (p >= 6 && p < 10 && has_next) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        S[(p - 6) * 4 + i] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsp, poff[(p - 6) * 4 + i], 0, 0));
-                }
-            }
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, v.z, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, v.w, acc[p], 0, 0, 0);
+            side(p, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(p, u.y, v.y, false); side(p, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(p, u.z, v.z, false); side(p, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(p, u.w, v.w, false); side(p, 3);
             __builtin_amdgcn_sched_barrier(0);
             u = un; v = vn;
         }
@@ -362,7 +391,8 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         {
             const int nxt = item + stride;
             has_next = nxt < item_end;
-            cbn = has_next ? nxt % ncb : cb; mtn = has_next ? nxt / ncb : mt;
+            cbn = cb; mtn = mt;
+            if (has_next) decode(nxt, cbn, mtn);
         }
         step(I0{}, I2{}, I1{}, 0);
         step(I1{}, I2{}, I0{}, 1);
@@ -466,9 +496,12 @@ int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stre
     static const int nblocks = getenv("EVR_WINO_BLOCKS") ? atoi(getenv("EVR_WINO_BLOCKS")) : 256;
     static const bool fast_act = getenv("EVR_WINO_FASTACT") ? atoi(getenv("EVR_WINO_FASTACT")) != 0 : true;
     const unsigned grid = (unsigned)(total < nblocks ? total : nblocks);
+    static const int var = getenv("EVR_WINO_VAR") ? atoi(getenv("EVR_WINO_VAR")) : 0;
     if (a.epi == EPI_LSTM) {
-        if (fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
-        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        if (!fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        else if (var == 2) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 2>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        else if (var == 4) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 4>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
     } else {
         hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
     }
