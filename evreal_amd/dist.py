@@ -4,10 +4,19 @@ accumulates (eval.py:259-266).  Backend "nccl" is RCCL on ROCm; "gloo" is used b
 import torch
 
 
+import os
+
+
+def force_collectives():
+    """EVR_FORCE_DIST=1: issue the collectives on a one-rank process group too -- how the RCCL path is exercised on a one-GPU box
+    (tests/test_gpu_dist.py, bench.py: `rccl_ranks: 1`); a sum over one rank is the identity."""
+    return bool(os.environ.get('EVR_FORCE_DIST'))
+
+
 def reduce_metric_sums(sums, dist=None):
     """sums: float64 tensor [n_rows, n_metrics+1] = per-dataset (sum of seq_mean*n_seq per metric ..., sum n_seq).
     Returns the all-reduced numpy array (identity without a process group)."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives()):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     return sums.cpu().numpy()
 

@@ -26,7 +26,7 @@ from tabulate import tabulate
 from . import model as model_arch
 from .config import get_dataset_configs, get_eval_configs, get_method_config
 from .dataset import MemMapDataset
-from .dist import assign_sequences, reduce_metric_sums
+from .dist import assign_sequences, force_collectives, reduce_metric_sums
 from .eval_metrics import EvalMetricsTracker, MetricTracker
 from .lib import EvrError
 from .prepost import normalize_event_tensor, post_process_normalization
@@ -480,7 +480,7 @@ def sequence_costs(seqs):
     give ranks different plans: sequences evaluated twice or not at all); a sequence whose reader fails weighs 1 and
     fails again, loudly, on the rank that owns it."""
     d = _dist()
-    if d is None or d.get_world_size() <= 1 or len(seqs) <= 1:
+    if d is None or (d.get_world_size() <= 1 and not force_collectives()) or len(seqs) <= 1:
         return [1] * len(seqs)          # one rank takes everything: nothing to balance
     box = [None]
     if d.get_rank() == 0:
@@ -539,7 +539,8 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
         print(f"Exception while getting method {method_name} from checkpoint path {method_config['model_path']}")
         print(e); print(traceback.format_exc())
         model = None
-    if world > 1:
+    collectives = dist is not None and (world > 1 or force_collectives())      # (EVR_FORCE_DIST=1: also on one rank -- the RCCL path on a one-GPU box)
+    if collectives:
         # the dataset loop below holds collectives (sequence_costs' broadcast, the per-dataset all-reduce): a rank whose checkpoint
         # load failed locally must not leave the others waiting in them -- agree first, then skip the method everywhere
         ok = torch.tensor([0.0 if model is None else 1.0], device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
@@ -598,7 +599,7 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
             print(f"Exception while evaluating method {method_name} on {dataset['name']} dataset:")
             print(e); print(traceback.format_exc())
         finally:
-            if world > 1:
+            if collectives:
                 dataset_metrics = fold_dataset_metrics(dataset_metrics, metrics, dist)
             method_metrics.append(dataset_metrics)
     return method_metrics
