@@ -102,7 +102,7 @@ def build(force=False, verbose=True):
                 os.remove(obj)
                 raise
     if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-lz', '-lpthread', '-o', LIB]      # (zlib: the PNG writers of hostcodec.cpp)
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -218,6 +218,9 @@ def _range_guard_policy(eval_config):
     return v if v in ('rerun', 'warn', 'off') else 'rerun'
 
 
+_DEFER_PNG = [False]      # True while eval_method_with_config's dataset loop runs: it waits for the native PNG writers once per dataset
+
+
 class _Saturated(Exception):
     """Activations of the running chunk left the split arithmetic's exact range (evr_model_saturation): nothing of it is booked."""
 
@@ -285,7 +288,7 @@ def _eval_color_sequence(ds, tracker, eval_config, model, method_config, sequenc
         for i in items:
             cnt, dt = int(tb['event_count'][i]), float(tb['dt'][i])
             tracker.save_custom_metric(i, "event_rate", 0 if (cnt <= 1 or dt == 0) else cnt / dt)
-    tracker.finalize(idx)
+    tracker.finalize(idx, wait_png=not _DEFER_PNG[0])
     ds.raise_if_dropped()       # once per sequence: out-of-sensor events the kernel dropped (the reference raises)
     if bad is not None:
         raise ValueError("WARNING: Event indices {},{} out of bounds 0,{}".format(
@@ -426,7 +429,7 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
                 if 'mse' in pre: scores['mse'] = sc[:k, j, 0].copy()
                 if 'ssim' in pre: scores['ssim'] = sc[:k, j, 1].copy()
                 if 'lpips' in pre and lp is not None: scores['lpips'] = lp[:k, j].copy()
-            u8 = b.h_u8[:k, j].numpy().copy() if b.h_u8 is not None else None
+            u8 = b.h_u8[:k, j] if b.h_u8 is not None else None      # (a strided view of the pinned buffer: the native writers copy it inside the call)
             if ds.has_images:
                 refs = b.refs[:k, j] if b.refs is not None else ds.frames(tb['frame_index'][it])[:, 0]
                 ref_ts = [float(v) for v in tb['frame_timestamp'][it]]
@@ -457,7 +460,7 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
     t1 = _time.perf_counter()
     out = []
     for j in range(S):
-        trackers[j].finalize(plans[j][2])
+        trackers[j].finalize(plans[j][2], wait_png=not _DEFER_PNG[0])      # (inside evaluate() the dataset loop waits for the PNG writers once)
         out.append((trackers[j].get_num_quan_evaluations(), trackers[j].get_mean_scores()))
     _t['finalize'] = _time.perf_counter() - t1
     TIMINGS.append(dict(_t, frames=sum(len(p[0]) for p in plans), sequences=S))
@@ -493,6 +496,35 @@ def sequence_costs(seqs):
         box[0] = costs
     d.broadcast_object_list(box, src=0)
     return list(box[0])
+
+
+class _SequencePrefetcher:
+    """One helper thread that opens the sequences the main loop will need next (eval_method_with_config)."""
+
+    def __init__(self):
+        self._thread = None
+
+    @staticmethod
+    def _work(seqs):
+        for q in seqs:
+            try:
+                ds = open_sequence(q)
+                ds.table()
+                ds.host_events(keep=True)
+            except Exception:
+                return          # the main flow meets the same failure at the same sequence and reports it
+
+    def start(self, seqs):
+        import threading
+        seqs = [q for q in seqs if 'dataset' not in q]
+        if seqs:
+            self._thread = threading.Thread(target=self._work, args=(seqs,), daemon=True)
+            self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
 
 
 def fold_dataset_metrics(dataset_metrics, metric_names, dist, device=None):
@@ -557,7 +589,14 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
             mine = [seqs[i] for i in assign_sequences(sequence_costs(seqs), world)[rank]]
             S = int(eval_config.get('batch_sequences', os.environ.get('EVREAL_BATCH_SEQUENCES', DEFAULT_BATCH_SEQUENCES)))
             k = 0
+            # the NEXT group's host-side set-up (memmap open, window tables, the validated host copy of the events) runs on a helper
+            # thread while the GPU is inside the current group: at one sequence per group -- the reference's own loop -- that set-up
+            # was 8 % of a 160-frame sequence.  Exceptions are swallowed there and raised again, in order, by the main flow below.
+            prefetcher = _SequencePrefetcher() if os.environ.get('EVREAL_PREFETCH', '1') != '0' else None
+            _DEFER_PNG[0] = True
             while k < len(mine):
+                if prefetcher is not None:
+                    prefetcher.wait()
                 # a batch = up to S consecutive sequences of one sensor size; it ends at a sequence whose loader would
                 # raise (the reference stops the dataset there).  S = 1 (default) is the reference's own loop.
                 group = [mine[k]]
@@ -582,6 +621,8 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
                         if not bool(open_sequence(nxt).table()['valid'].all()):
                             break
                 k += len(group)
+                if prefetcher is not None and not eval_config.get('color', False):
+                    prefetcher.start(mine[k:k + max(S, 1)])
                 for sequence in group:
                     open_sequence(sequence)
                     print(f"[rank {rank}] Evaluating {method_name} with {eval_config['name']} config on "
@@ -599,6 +640,15 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
             print(f"Exception while evaluating method {method_name} on {dataset['name']} dataset:")
             print(e); print(traceback.format_exc())
         finally:
+            _DEFER_PNG[0] = False
+            try:
+                _t_png = __import__('time').perf_counter()
+                EvalMetricsTracker.wait_all_pngs()      # the frames the sequence loops left with the native writers: on disk before the dataset is reported
+                if os.environ.get('EVR_EVAL_TIMING'):
+                    print(f'[evreal_amd.eval] waited {__import__("time").perf_counter() - _t_png:.3f} s for the PNG writers at the end of {dataset["name"]}', file=sys.stderr)
+            except Exception as e:
+                print(f"Exception while writing the images of method {method_name} on {dataset['name']} dataset:")
+                print(e)
             if collectives:
                 dataset_metrics = fold_dataset_metrics(dataset_metrics, metrics, dist)
             method_metrics.append(dataset_metrics)

@@ -370,21 +370,47 @@ class EvalMetricsTracker:
         quantitative metric in colour mode (utils/eval_metrics.py:272)."""
         self._append(join(self.output_dir, 'timestamps.txt'), zip(indices, img_ts), '{} {:.15f}\n')
         if self.save_images:
-            rgb = bgr_u8.flip(-1).cpu().numpy()          # cv2.imwrite stores BGR arrays as RGB files
-            for i, a in zip(indices, rgb):
-                self._submit_png(join(self.output_dir, 'frame_{:010d}.png'.format(i)), a, 'RGB')
+            rgb = bgr_u8.flip(-1).contiguous().cpu()     # cv2.imwrite stores BGR arrays as RGB files
+            if self._use_pil():
+                for i, a in zip(indices, rgb.numpy()):
+                    self._submit_png(join(self.output_dir, 'frame_{:010d}.png'.format(i)), a, 'RGB')
+            else:
+                self._submit_native(self.output_dir, indices, rgb, 3)
 
-    # PNG encoding (zlib, ~3 ms per 346x260 frame on one core) leaves the frame loop: a small shared thread pool
-    # encodes and writes while the GPU goes on (PIL releases the GIL in the compressor); same PIL calls, so the
-    # files are byte-identical to the synchronous ones.  finalize() waits for this tracker's files (SURVEY 8f-2).
+    # PNG encoding leaves the frame loop (SURVEY 8f-2).  Round 6: a pool of NATIVE writer threads inside the library
+    # (csrc/hostcodec.cpp: filter 0 + one zlib stream of level EVREAL_PNG_LEVEL, default 1; no GIL, ~0.3 ms per 346x260 frame and
+    # core) takes whole chunks of frames per call; the files decode to exactly round(clip(img) * 255) (eval_utils.py:80-84).
+    # EVREAL_PNG_THREADS=<n> sizes the pool (0: every call waits for its files -- synchronous, as the reference);
+    # EVREAL_PNG_WRITER=pil keeps round 5's pool of PIL writers (~3 ms per frame and core, zlib level 6: smaller files).
+    # finalize() waits for the files (and raises a writer's failure there).
     _pool = None
+    _native = None
+
+    @classmethod
+    def _png_threads(cls):
+        return int(os.environ.get('EVREAL_PNG_THREADS', '') or min(16, max(4, (os.cpu_count() or 4) // 2)))
 
     @classmethod
     def _writer_pool(cls):
         if cls._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            cls._pool = ThreadPoolExecutor(max_workers=int(os.environ.get('EVREAL_PNG_THREADS', '') or min(16, max(4, (os.cpu_count() or 4) // 2))))
+            cls._pool = ThreadPoolExecutor(max_workers=max(1, cls._png_threads()))
         return cls._pool
+
+    @classmethod
+    def _native_pool(cls):
+        if cls._native is None:
+            import ctypes
+            from . import lib as _lib
+            h = ctypes.c_void_p()
+            _lib.check(_lib.load().evr_png_pool_create(max(1, cls._png_threads()), int(os.environ.get('EVREAL_PNG_LEVEL', '1')), ctypes.byref(h)),
+                       'evr_png_pool_create')
+            cls._native = h
+        return cls._native
+
+    @staticmethod
+    def _use_pil():
+        return os.environ.get('EVREAL_PNG_WRITER', 'native') == 'pil'
 
     def _submit_png(self, path, array, mode):
         def job():
@@ -395,14 +421,44 @@ class EvalMetricsTracker:
         else:
             self._pending.append(self._writer_pool().submit(job))
 
+    def _submit_native(self, folder, indices, frames, channels):
+        """frames: uint8 host array/tensor [n, H, W] or [n, H, W, 3]; frame 0 contiguous, frames a constant stride apart."""
+        import ctypes
+        from . import lib as _lib
+        t = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
+        n, H, W = int(t.shape[0]), int(t.shape[1]), int(t.shape[2])
+        if n == 0:
+            return
+        if not t[0].is_contiguous() or (n > 1 and t.stride(0) < H * W * channels):
+            t = t.contiguous()
+        idx = (ctypes.c_int64 * n)(*[int(i) for i in indices])
+        _lib.check(_lib.load().evr_png_pool_submit(self._native_pool(), os.fsencode(folder), idx, n, ctypes.c_void_p(t.data_ptr()), H, W, channels,
+                                                  int(t.stride(0)) if n > 1 else 0), 'evr_png_pool_submit')
+        self._native_pending = True
+        if os.environ.get('EVREAL_PNG_THREADS', '') == '0':
+            self._wait_native()
+
+    def _wait_native(self, ignore_errors=False):
+        if getattr(self, '_native_pending', False) and type(self)._native is not None:
+            from . import lib as _lib
+            self._native_pending = False
+            rc = _lib.load().evr_png_pool_wait(type(self)._native, None)
+            if rc and not ignore_errors:
+                _lib.check(rc, 'evr_png_pool_wait')
+
     def _save_pngs(self, folder, indices, imgs, u8=None):
         if u8 is None:
-            u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu().numpy()     # eval_utils.py:83
-        for i, a in zip(indices, u8):
-            self._submit_png(join(folder, 'frame_{:010d}.png'.format(i)), a, 'L')
+            u8 = torch.round(torch.clamp(imgs, 0.0, 1.0) * 255).to(torch.uint8).cpu()               # eval_utils.py:83
+        if self._use_pil():
+            for i, a in zip(indices, u8.numpy() if isinstance(u8, torch.Tensor) else u8):
+                self._submit_png(join(folder, 'frame_{:010d}.png'.format(i)), np.ascontiguousarray(a), 'L')
+        else:
+            self._submit_native(folder, indices, u8, 1)
 
-    def finalize(self, idx):
-        """eval_metrics.py:225-228: flush the queued metrics; then wait for this tracker's files."""
+    def finalize(self, idx, wait_png=True):
+        """eval_metrics.py:225-228: flush the queued metrics; then wait for this tracker's files.  wait_png=False (the drop-in's
+        sequence loops): the native writers keep working on this tracker's last frames while the next sequence starts; the caller
+        owes a wait_all_pngs() before it reports the dataset (evreal_amd.eval does it per dataset) -- 3 ms per 160-frame sequence."""
         for m in self.metrics:
             if getattr(m, 'on_gpu', False):
                 m.updated = 0
@@ -416,7 +472,16 @@ class EvalMetricsTracker:
         for f in self._pending:
             f.result()                                       # re-raises a writer's exception here
         self._pending = []
+        if wait_png:
+            self._wait_native()                              # ... and a native writer's failure here
         self._close_files()
+
+    @classmethod
+    def wait_all_pngs(cls):
+        """Every frame handed to the native writers so far is on disk when this returns; raises the first write failure."""
+        if cls._native is not None:
+            from . import lib as _lib
+            _lib.check(_lib.load().evr_png_pool_wait(cls._native, None), 'evr_png_pool_wait')
 
     def discard(self):
         """Abandon this tracker (its sequence is re-run from the start with a fresh one, which truncates the same files): wait for
@@ -427,6 +492,7 @@ class EvalMetricsTracker:
             except Exception:
                 pass
         self._pending = []
+        self._wait_native(ignore_errors=True)
         self._close_files()
 
     def get_num_quan_evaluations(self):

@@ -93,6 +93,10 @@ SYMBOLS = {
     'evr_p6_pack_device': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'evr_h2_act_exponent': (c_int, []),
     'evr_fastdiv_magic': (c_int, [ctypes.c_uint, c_void_p, c_void_p]),
+    'evr_png_pool_create': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'evr_png_pool_submit': (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64]),
+    'evr_png_pool_wait': (c_int, [c_void_p, ctypes.POINTER(c_int64)]),
+    'evr_png_pool_destroy': (c_int, [c_void_p]),
 }
 
 _lib = None

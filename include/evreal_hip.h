@@ -312,6 +312,18 @@ int evr_p6_unpack(const float* src, float* dst, int64_t n);
 int evr_p6_pack_device(const float* src, float* dst, int64_t n, evr_stream_t stream);
 int evr_fastdiv_magic(unsigned d, unsigned* mul, unsigned* shift);
 
+/* ---- native PNG writers (round 6, ABI 1003) -----------------------------------------------------------------------------------
+ * Replaces the reference's per-frame cv2.imwrite (utils/eval_utils.py:80-84; `save_images` is on in config/eval/std.json:9): a pool
+ * of host threads encodes 8-bit gray / RGB PNGs (filter 0, one zlib stream of the given level; 0 = stored) and writes them as
+ * <folder>/frame_%010d.png.  `frames_host` ([n,H,W] or [n,H,W,3] uint8, host memory) is copied before submit returns; wait blocks
+ * until everything submitted is on disk and fails (message: the first failure) if a file could not be written. */
+typedef struct evr_png_pool evr_png_pool;
+int evr_png_pool_create(int n_threads, int zlib_level, evr_png_pool** out);
+int evr_png_pool_submit(evr_png_pool* pool, const char* folder, const int64_t* indices, int n, const unsigned char* frames_host,
+                        int H, int W, int channels, int64_t frame_stride /* bytes between frames; 0 = dense */);
+int evr_png_pool_wait(evr_png_pool* pool, int64_t* n_written);
+int evr_png_pool_destroy(evr_png_pool* pool);
+
 #ifdef __cplusplus
 }
 #endif

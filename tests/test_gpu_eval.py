@@ -213,7 +213,9 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
         return orig(self, folder, indices, imgs, u8)
     monkeypatch.setattr(em.EvalMetricsTracker, '_save_pngs', spy)
     digests = {}
-    for mode in ('async', 'sync'):
+    # async / sync: the library's native writer pool (round 6), and the same encoder with a wait behind every call; pil: round 5's
+    # pool of PIL writers (EVREAL_PNG_WRITER=pil) -- another container around the same pixels
+    for mode in ('async', 'sync', 'pil'):
         root = tmp_path / mode
         os.makedirs(root)
         model_path = str(root / 'firenet.pth')
@@ -224,6 +226,9 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
         monkeypatch.chdir(root)
         if mode == 'sync':
             monkeypatch.setenv('EVREAL_PNG_THREADS', '0')
+        if mode == 'pil':
+            monkeypatch.delenv('EVREAL_PNG_THREADS')
+            monkeypatch.setenv('EVREAL_PNG_WRITER', 'pil')
         ev.evaluate(['FireNet'], ['k3k'], ['SYN'], ['mse'])
         out = {}
         for d, _, files in os.walk(root / 'outputs'):
@@ -243,6 +248,7 @@ def test_png_writers_async_equals_sync(tmp_path, monkeypatch):
         digests[mode] = out
         seen.clear()
     assert digests['async'] and digests['async'] == digests['sync']
+    assert set(digests['pil']) == {k.replace('async', 'pil', 1) for k in digests['async']} or len(digests['pil']) == len(digests['async'])
 
 
 def test_dataset_reader_matches_reference_tables(tmp_path):
