@@ -244,12 +244,18 @@ __global__ __launch_bounds__(K1T) void vox_split_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-template <bool RAW>
+// SCAN (round 6, timing experiment only -- EVR_VOX_SCANPROBE=1 / 2): VERDICT r5 proposed ONE kernel per (window, range) that scans the
+// window's events itself (a wave-ballot range filter over the 4-byte coordinate words) instead of reading the records a split kernel
+// sorted.  The probe adds exactly that scan to this kernel -- every work-group loads all coordinate words of its window, tests them
+// against its rows and ballots; the result only lands in a spare LDS word -- so that (probe range kernel) bounds the fused kernel's
+// time from below at one launch: it would still need this kernel's zero / ticket / flush phases and, per in-range event, a gather
+// of {coordinates, timestamp, polarity} instead of one 8-byte record.  Numbers: DESIGN.md section 4.1.
+template <bool RAW, int SCAN = 0>
 __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     const int64_t* __restrict__ win_begin, const int64_t* __restrict__ win_end, const int64_t* __restrict__ rec_base,
     const float4* __restrict__ rec, const int* __restrict__ table, float* __restrict__ out,
     double* __restrict__ partials, VoxHeader* hdr, int n_windows, int G, int rows, int Rp, int B, int H, int W, int vec_out, int xcd_map,
-    unsigned rq_magic, int w0, int publish) {
+    unsigned rq_magic, int w0, int publish, const int16_t* __restrict__ scan_xy = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (n_windows: END of this launch's chunk [w0, n_windows); publish: the call's LAST range launch -- every split launch of the call
     // has finished by then, voxelize_impl orders them with events)
@@ -290,6 +296,31 @@ __global__ __launch_bounds__(K2T, 3) void vox_range_kernel(
     volatile unsigned* tag = (volatile unsigned*)tags;
     volatile int* vmore = (volatile int*)more;
     int round = 0;                            // ticket rounds so far (selects the flag; uniform)
+    if constexpr (SCAN != 0) {
+        // wave k scans the k-th quarter of the window in 64-event strides, 16 loads in flight per lane (SCAN == 2: the y halves only)
+        const int64_t a0 = win_begin[w];
+        const int per = (n + K2W - 1) / K2W;
+        const int lo = k * per, hi = min(n, lo + per);
+        int cnt = 0;
+        for (int e0 = lo; e0 < hi; e0 += 64 * 16) {
+            unsigned wd[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int e = e0 + j * 64 + lane;
+                const int64_t i = a0 + (e < hi ? e : hi - 1);
+                if (SCAN == 2) wd[j] = (unsigned)((const uint16_t*)scan_xy)[2 * i + 1] << 16;
+                else wd[j] = ((const unsigned*)scan_xy)[i];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int e = e0 + j * 64 + lane;
+                const int yy = (int)(wd[j] >> 16), xx = (int)(wd[j] & 0xFFFFu);
+                const bool in = e < hi && (unsigned)(yy - y0) < (unsigned)nrows && xx < W;
+                cnt += __popcll(__ballot(in));
+            }
+        }
+        if (lane == 0) vmore[4] = cnt;        // (a spare word: keeps the scan alive, read by nobody)
+    }
 
     for (int sg0 = 0; sg0 < nseg; sg0 += MAXSEG) {
         const int ns = min(MAXSEG, nseg - sg0);
@@ -560,6 +591,10 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     if (dev < 0 || dev >= 64 || !(attr_done[dev].load(std::memory_order_relaxed) & bit)) {
         EVR_HIP(hipFuncSetAttribute((const void*)vox_split_kernel<RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EVR_HIP(hipFuncSetAttribute((const void*)vox_range_kernel<RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (RAW) {
+            EVR_HIP(hipFuncSetAttribute((const void*)vox_range_kernel<RAW, RAW ? 1 : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            EVR_HIP(hipFuncSetAttribute((const void*)vox_range_kernel<RAW, RAW ? 2 : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         if (dev >= 0 && dev < 64) attr_done[dev].fetch_or(bit, std::memory_order_relaxed);
     }
     // split workgroups per window: enough for the average window in one pass, at most 32 (longer windows loop)
@@ -601,6 +636,14 @@ int voxelize_impl(const EventSrc& src, const int64_t* win_begin, const int64_t* 
     auto launch_range = [&](int w0, int w1, int publish) {
         const int nw = w1 - w0;
         const int64_t blocks = xcd_map ? (int64_t)((nw + 7) / 8) * 8 * pl.G : (int64_t)nw * pl.G;
+        static const int scan_probe = getenv("EVR_VOX_SCANPROBE") ? atoi(getenv("EVR_VOX_SCANPROBE")) : 0;
+        if (RAW && scan_probe == 1)
+            hipLaunchKernelGGL((vox_range_kernel<RAW, RAW ? 1 : 0>), dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
+                               rec, table, out, partials, hdr, w1, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic, w0, publish, src.xy);
+        else if (RAW && scan_probe == 2)
+            hipLaunchKernelGGL((vox_range_kernel<RAW, RAW ? 2 : 0>), dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
+                               rec, table, out, partials, hdr, w1, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic, w0, publish, src.xy);
+        else
         hipLaunchKernelGGL(vox_range_kernel<RAW>, dim3((unsigned)blocks), dim3(K2T), pl.lds2, stream, win_begin, win_end, rec_base,
                            rec, table, out, partials, hdr, w1, pl.G, pl.rows, pl.Rp, B, H, W, vec_out, xcd_map, rq_magic, w0, publish);
     };
