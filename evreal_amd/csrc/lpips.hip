@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64) void lpips_final_kernel(const double* __restric
 constexpr int SCORE_BLOCKS_MAX = 256;
 static int score_blocks(int n) { int b = 2048 / (n > 0 ? n : 1); return b < 32 ? 32 : (b > SCORE_BLOCKS_MAX ? SCORE_BLOCKS_MAX : b); }
 
-struct Layer { int cin, cout, k, pad; int x3 = 0; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr; };
+struct Layer { int cin, cout, k, pad; int x3 = 0; int mx_e = 0; std::vector<float> w, b; float* d_w = nullptr; float* d_b = nullptr; float* d_lin = nullptr;
+               float* d_wino = nullptr; };      // (exact-fp32 mode, 3x3 layers: Winograd-domain weights, wino.hip)
 
 }  // namespace
 
@@ -332,7 +333,7 @@ struct evr_lpips {
         if (d_wg) (void)hipFree(d_wg); if (d_wb) (void)hipFree(d_wb); if (d_b1) (void)hipFree(d_b1); if (d_b1in) (void)hipFree(d_b1in);
         if (d_wfrag1) (void)hipFree(d_wfrag1); if (d_wbsum) (void)hipFree(d_wbsum);
         for (auto& p : d_lin) if (p) (void)hipFree(p);
-        for (auto& l : L) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); }
+        for (auto& l : L) { if (l.d_w) (void)hipFree(l.d_w); if (l.d_b) (void)hipFree(l.d_b); if (l.d_wino) (void)hipFree(l.d_wino); }
     }
 };
 
@@ -432,6 +433,12 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
                 L.w[((size_t)co * taps + t) * cin[l] + ci] = w->data_host[((size_t)co * cin[l] + ci) * taps + t];
             L.x3 = arith_mode();          // conv2..conv5 run on the same implicit-GEMM family as the networks, in their mode
             if (L.x3 == 4) L.x3 = 2;      // (P6 tensors have no 4-channel writer -- the max pools, conv1's epilogue: LPIPS keeps the fp8 form)
+            // exact-fp32 mode: conv3..conv5 (3x3 stride 1) also get their Winograd-domain weights (model.cpp finish_conv; EVR_WINO=0: never)
+            if (L.x3 == 0 && L.k == 3 && wino_enabled() && L.cin % 16 == 0 && L.cout % 64 == 0) {
+                std::vector<float> u;
+                wino_pack_weights(L.w, L.cout, L.cin, 0, u);
+                if ((rc = up(u, &L.d_wino))) break;
+            }
             if (L.x3) L.mx_e = pack_weights_for(L.x3, L.w);
             if (L.x3 == 3) for (float& bv : L.b) bv = std::ldexp(bv, L.mx_e + H2_ACT_EXP);      // (model.cpp finish_conv)
             if ((rc = up(L.w, &L.d_w))) break;
@@ -483,6 +490,7 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         for (int ky = 0; ky < L.k; ++ky) for (int kx = 0; kx < L.k; ++kx) a.tp.set_tap(ky * L.k + kx, ky - L.pad, kx - L.pad, 1);
         a.wgt = L.d_w; a.bias = L.d_b; a.cout = L.cout; a.n_valid = L.cout; a.out = m->feat[i + 1]; a.cout_total = L.cout;
         a.epi = EPI_BIAS_RELU; a.x3 = L.x3;
+        a.wgt_wino = L.d_wino; set_wino_grid(a);
         {   // conv2 (5x5) on the band kernel with 8 KB of LDS padding (two blocks per CU instead of three); EVR_LPIPS_BAND5=<KB> sets the
             // padding, EVR_LPIPS_BAND5=-1 keeps the implicit GEMM (the default until the evaluation stream moved behind the residual
             // blocks: beside the ConvLSTM layers its LDS footprint cost more than the kernel gained; now +0.7 .. 1.0 %, profiles/r03_env_ab.txt)
