@@ -140,6 +140,20 @@ def test_one_sequence_without_split_k():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_split_k_run_count_is_clamped_to_what_the_epilogue_sums():
+    """EVR_KSPLIT / EVR_KSPLIT_SMALL are user switches with no documented upper bound, and the wide split-K epilogue sums at
+    most 8 partial sets: with 16 the main kernel used to write sixteen and the epilogue silently summed eight.  conv.hip ksplit_cap now
+    clamps both to 8: the one-sequence run (every deep layer splits) must still match the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVR_KSPLIT='16', EVR_KSPLIT_SMALL='16', EVR_TEST_SPLITK_FRAMES='12')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_gpu_fullsize.py::test_one_sequence_split_k_100_frames_346x260'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_recurrence_at_the_64_sequence_dispatch():
     """The recurrence at the dispatch bench.py times: 64 sequences advanced together (the 256 x 128 / 256 x 256-tile ConvLSTM kernels, the
     twin-form decoders with the fused prediction epilogue), sequence 37 replayed through the CPU oracle at every frame; final ConvLSTM
