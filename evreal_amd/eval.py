@@ -499,7 +499,11 @@ def sequence_costs(seqs):
 
 
 class _SequencePrefetcher:
-    """One helper thread that opens the sequences the main loop will need next (eval_method_with_config)."""
+    """One helper thread that prepares the sequences the main loop will need next (eval_method_with_config): memmap open, window
+    tables, the validated host copy of the events.  (Uploading the next sequence's device copy from this thread as well -- a copy
+    stream beside the running sequence -- measured SLOWER in round 6: one sequence at a time 2096 -> 1.96-1.98 k frames/s, with PNGs
+    1980 -> 1.1-1.7 k; allocations and pageable copies issued beside a full kernel queue wait for it.  The upload stays between the
+    sequences, 3 ms each.)"""
 
     def __init__(self):
         self._thread = None
@@ -525,6 +529,22 @@ class _SequencePrefetcher:
         if self._thread is not None:
             self._thread.join()
             self._thread = None
+
+
+def _open_group_hosts(seqs):
+    """The first sequences of a dataset: their host-side set-up (31 MB of events each, read and validated) on a few threads at once
+    -- numpy releases the GIL in the copies and reductions; failures are left for the main flow to meet in order."""
+    import threading
+    def one(q):
+        try:
+            ds = open_sequence(q); ds.table(); ds.host_events(keep=True)
+        except Exception:
+            pass
+    ts = [threading.Thread(target=one, args=(q,), daemon=True) for q in seqs[1:] if 'dataset' not in q]
+    for t in ts: t.start()
+    if seqs and 'dataset' not in seqs[0]:
+        one(seqs[0])
+    for t in ts: t.join()
 
 
 def fold_dataset_metrics(dataset_metrics, metric_names, dist, device=None):
@@ -594,6 +614,8 @@ def eval_method_with_config(eval_config, method_name, datasets, metrics):
             # was 8 % of a 160-frame sequence.  Exceptions are swallowed there and raised again, in order, by the main flow below.
             prefetcher = _SequencePrefetcher() if os.environ.get('EVREAL_PREFETCH', '1') != '0' else None
             _DEFER_PNG[0] = True
+            if prefetcher is not None and S > 1 and not eval_config.get('color', False):
+                _open_group_hosts(mine[:S])
             while k < len(mine):
                 if prefetcher is not None:
                     prefetcher.wait()
