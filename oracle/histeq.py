@@ -1,8 +1,10 @@
 """Oracle: the tracker's histogram-equalisation modes (utils/eval_metrics.py:326-350).  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED.  The reference calls scikit-image (exposure.equalize_hist, filters.rank.equalize, img_as_ubyte /
-img_as_float32) and OpenCV (createCLAHE); neither is in the reference tree nor installed here, and requirements.txt
-pins no versions.  This restates their published algorithms on numpy:
+'global' and 'local': PARITY PINNED (round 6) to scikit-image 0.18.3 (/opt/conda/bin/python3.9 of this image; fixture
+tests/golden/thirdparty_histeq.npz, tests/test_thirdparty_pins.py): equalize_global within one float32 ulp (6e-8), equalize_local
+exact.  'clahe': PARITY UNPINNED (OpenCV is nowhere in the image).  The reference calls scikit-image (exposure.equalize_hist,
+filters.rank.equalize, img_as_ubyte / img_as_float32) and OpenCV (createCLAHE); requirements.txt pins no versions.  This restates
+their published algorithms on numpy:
   equalize_global  skimage/exposure/exposure.py: histogram(image, 256) over [min, max] (np.histogram), bin centres,
                    cdf = cumsum / total (float32), np.interp(image, centres, cdf) -> float32
   to_u8 / to_f32   skimage/util/dtype.py: rint(x * 255) clipped; u8 * float32(1/255)

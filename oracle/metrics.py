@@ -1,10 +1,14 @@
 """Oracle: per-frame metrics and score aggregation.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for mse()/ssim(): the arithmetic lives in scikit-image, which is neither
-in the reference tree nor installed (requirements.txt lists it without a version).  These
-follow the published algorithm (Wang et al. 2004) as implemented by scikit-image >= 0.19
-(skimage/metrics/simple_metrics.py, _structural_similarity.py) with exactly the kwargs the
-reference passes at utils/eval_metrics.py:83 and :96.
+PARITY PINNED (round 6) for mse()/ssim() against the real scikit-image: the arithmetic lives in scikit-image, which is not in the
+reference tree (requirements.txt lists it without a version) and not installable for the system interpreter -- but this image
+carries an Anaconda python3.9 with scikit-image 0.18.3 (/opt/conda/bin/python3.9), and tests/golden/thirdparty_metrics.json holds
+ITS mean_squared_error / structural_similarity for the seeded pairs of tests/thirdparty_refs.py (written by
+`/opt/conda/bin/python3.9 tests/golden/make_thirdparty_golden.py`): mse() agrees bit for bit, ssim() to 5e-8 (0.18 filters in
+float64, >= 0.19 -- whose float32 semantics this file follows -- in float32).  tests/test_thirdparty_pins.py holds oracle and HIP
+kernel to the fixture and, wherever skimage imports, to the live package.  The statement below follows the published algorithm
+(Wang et al. 2004) as implemented by scikit-image (skimage/metrics/simple_metrics.py, _structural_similarity.py) with exactly the
+kwargs the reference passes at utils/eval_metrics.py:83 and :96.
 
   mse   mean((ref-img)^2): fp32 difference and square, mean accumulated in fp64.
   ssim  gaussian_weights=True, sigma=1.5, use_sample_covariance=False, data_range=1.0:

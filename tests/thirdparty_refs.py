@@ -95,7 +95,10 @@ def thirdparty_histeq(img, mode):
     if mode == 'local':
         from skimage.filters import rank
         from skimage.morphology import disk
-        return img_as_float32(rank.equalize(img_as_ubyte(img), footprint=disk(55)))
+        try:
+            return img_as_float32(rank.equalize(img_as_ubyte(img), footprint=disk(55)))
+        except TypeError:      # scikit-image < 0.19 calls the same argument `selem` (the reference's spelling needs >= 0.19)
+            return img_as_float32(rank.equalize(img_as_ubyte(img), selem=disk(55)))
     if mode == 'clahe':
         import cv2
         clahe = cv2.createCLAHE(clipLimit=2.0, tileGridSize=(8, 8))
