@@ -331,7 +331,13 @@ class MemMapDataset:
     def frames(self, frame_indices, out=None):
         """Reference frames [n,1,H,W] fp32 in [0,1] (dataset.py:80-85: images[i][:,:,0] / 255)."""
         images = self.upload_images()
-        idx = torch.from_numpy(np.asarray(frame_indices, dtype=np.int64)).to(self.device)
+        # (a DEVICE index tensor is used as it is: the frame loop uploads a sequence's frame indices once -- a host list here is a
+        # synchronous copy in stream order, i.e. a host <-> GPU rendezvous per call: behind the evaluation stream's wait for a
+        # chunk's network steps it cost the drop-in its whole run-ahead, 5 ms per chunk of 8 frames)
+        if isinstance(frame_indices, torch.Tensor) and frame_indices.is_cuda:
+            idx = frame_indices
+        else:
+            idx = torch.from_numpy(np.asarray(frame_indices, dtype=np.int64)).to(self.device)
         # tensor / tensor: a true IEEE division (torch's CUDA kernel turns `/ python_scalar` into `* (1/255)`,
         # which differs from the reference's CPU result in the last bit)
         if self._255 is None:

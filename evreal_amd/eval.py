@@ -356,6 +356,9 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
     batch = SequenceBatch(dss)
     H, W, dev = batch.H, batch.W, batch.device
     plans = [_plan_items(ds, tb, q, infer_all) for ds, tb, q in zip(dss, tbs, sequences)]
+    # the reference-frame index of every planned item, resident: the chunk loop slices it on the device (see MemMapDataset.frames)
+    fidx = [torch.from_numpy(np.asarray(tb['frame_index'][np.asarray(p[0], dtype=np.int64)], dtype=np.int64)).to(dev) if (ds.has_images and len(p[0])) else None
+            for ds, tb, p in zip(dss, tbs, plans)]
     model.reset_states()
     steps = max((len(p[0]) for p in plans), default=0)
     # what the frame loop computes for whole chunks (every tracker of a dataset is configured alike)
@@ -394,7 +397,7 @@ def _eval_method_on_sequences(dataset_name, eval_config, method_name, model, met
             if b.refs is not None:
                 for j, (ds, it) in enumerate(zip(dss, items)):
                     if it:
-                        b.refs[:len(it), j] = ds.frames(tbs[j]['frame_index'][it])[:, 0]
+                        b.refs[:len(it), j] = ds.frames(fidx[j][c0:c0 + len(it)])[:, 0]
                 rf = b.refs[:n].view(n * S, H, W)
                 if b.scores is not None:
                     b.scores[:n * S].copy_(gpu_metrics(im, rf, mse='mse' in pre, ssim='ssim' in pre, clip=True))

@@ -16,7 +16,7 @@ os.makedirs(os.path.join(tmp, 'pretrained'))
 torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in weights.synth_lpips_state_dict(seed=0).items()}, os.path.join(tmp, 'pretrained', 'lpips_alex.pth'))
 torch.save({'model': {k: v for k, v in kw.items() if k != 'final_activation'}, 'state_dict': {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, os.path.join(tmp, 'e2vid.pth'))
 json.dump({"model_name": "E2VID", "model_path": os.path.join(tmp, 'e2vid.pth'), "event_tensor_normalization": True, "post_process_norm": "robust"}, open(os.path.join(tmp, 'config/method/E2VID.json'), 'w'))
-json.dump({"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "between_frames"}, "keep_ratio": 1.0}, "save_images": False, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 1.0, "create_video": False, "batch_sequences": n_seq}, open(os.path.join(tmp, 'config/eval/std.json'), 'w'))
+json.dump({"dataset_kwargs": {"num_bins": 5, "voxel_method": {"method": "between_frames"}, "keep_ratio": 1.0}, "save_images": False, "histeq": "none", "eval_infer_all": False, "ts_tol_ms": 1.0, "create_video": False, "batch_sequences": int(os.environ.get("EVR_PROFILE_BS", n_seq))}, open(os.path.join(tmp, 'config/eval/std.json'), 'w'))
 seqs = {}
 for s in range(n_seq):
     synth.write_sequence(os.path.join(tmp, 'data', 'SYN', f's{s}'), 100 + s, (frames + 1) * 15000, 1.0e6, W_, H_, 1.0e6 / 15000)
@@ -36,5 +36,5 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print(f'--- pass {rep}: {dt:.3f} s, TIMINGS {ev.TIMINGS[-1]}', file=out)
     if rep == 2:
-        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45); print(s.getvalue(), file=out)
+        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(70); print(s.getvalue(), file=out)
 shutil.rmtree(tmp, ignore_errors=True)
