@@ -320,14 +320,25 @@ struct evr_lpips {
     float* d_wfrag1 = nullptr; float* d_wbsum = nullptr;     // matrix-core form of conv1 (split mode)
     float* d_lin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     Layer L[4];
-    // shape-dependent
-    int n = 0, H = 0, W = 0;
+    // shape-dependent.  Buffers are sized for `cap` image pairs at H x W and only ever grow; what depends on the pair count n of a call
+    // (the four ConvArgs with their tile choice) lives in a small cache of plans.  Round 6: the drop-in's chunks change n at every
+    // sequence boundary (a short last chunk, then a full one), and the old one-plan form answered each change with a stream
+    // synchronise + hipFree + hipMalloc of everything -- 16 device-wide stalls in an eight-sequence run.
+    int n = 0, H = 0, W = 0, cap = 0;
     int h[5], w[5];              // feature map sizes of relu1..relu5
     std::vector<void*> allocs;
     float* feat[5] = {}; float* pool1 = nullptr; float* pool2 = nullptr;
-    ConvArgs args[4]; ConvArgs* d_args = nullptr; int wm[4], nb[4];
+    struct Plan { int n = 0; unsigned stamp = 0; ConvArgs args[4]; int wm[4], nb[4]; };
+    static constexpr int NPLANS = 8;
+    Plan plans[NPLANS]; unsigned clock = 0; Plan* cur = nullptr;
+    ConvArgs* d_args = nullptr;      // [NPLANS][4]
+    float* kws = nullptr; bool kws_tried = false;
     double* partials = nullptr; int* d_hw = nullptr;
-    void release() { for (void* p : allocs) (void)hipFree(p); allocs.clear(); n = 0; d_args = nullptr; }
+    void release() {
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear(); n = 0; cap = 0; d_args = nullptr; cur = nullptr; kws = nullptr; kws_tried = false;
+        for (auto& pl : plans) pl.n = 0;
+    }
     ~evr_lpips() {
         release();
         if (d_wg) (void)hipFree(d_wg); if (d_wb) (void)hipFree(d_wb); if (d_b1) (void)hipFree(d_b1); if (d_b1in) (void)hipFree(d_b1in);
@@ -458,31 +469,50 @@ extern "C" int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lp
 
 extern "C" int evr_lpips_destroy(evr_lpips* m) { delete m; return EVR_OK; }
 
-static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
+// (re)allocate the feature buffers for `cap` image pairs of H x W: the only place that synchronises
+static int lpips_buffers(evr_lpips* m, int cap, int H, int W, hipStream_t stream) {
     EVR_HIP(hipStreamSynchronize(stream));
     m->release();
-    m->n = n; m->H = H; m->W = W;
-    const int n2 = 2 * n;
+    m->cap = cap; m->H = H; m->W = W;
+    const int n2 = 2 * cap;
     m->h[0] = (H + 4 - 11) / 4 + 1; m->w[0] = (W + 4 - 11) / 4 + 1;
     const int hp1 = (m->h[0] - 3) / 2 + 1, wp1 = (m->w[0] - 3) / 2 + 1;
     m->h[1] = hp1; m->w[1] = wp1;
     const int hp2 = (hp1 - 3) / 2 + 1, wp2 = (wp1 - 3) / 2 + 1;
     for (int l = 2; l < 5; ++l) { m->h[l] = hp2; m->w[l] = wp2; }
+    if (!(hp2 >= 1 && wp2 >= 1)) { m->cap = 0; m->H = m->W = 0; }
     EVR_REQUIRE(hp2 >= 1 && wp2 >= 1, "evr_lpips: image %dx%d too small for AlexNet", W, H);
     const int C[5] = {64, 192, 384, 256, 256};
     int rc;
     for (int l = 0; l < 5; ++l) if ((rc = dalloc(m, &m->feat[l], (size_t)n2 * m->h[l] * m->w[l] * C[l]))) return rc;
     if ((rc = dalloc(m, &m->pool1, (size_t)n2 * hp1 * wp1 * 64))) return rc;
     if ((rc = dalloc(m, &m->pool2, (size_t)n2 * hp2 * wp2 * 192))) return rc;
-    if ((rc = dalloc(m, &m->partials, (size_t)5 * n * SCORE_BLOCKS_MAX))) return rc;
+    if ((rc = dalloc(m, &m->partials, (size_t)5 * cap * SCORE_BLOCKS_MAX))) return rc;
     if ((rc = dalloc(m, &m->d_hw, 8))) return rc;
+    if ((rc = dalloc(m, &m->d_args, (size_t)evr_lpips::NPLANS * 4))) return rc;
     int hw[5]; for (int l = 0; l < 5; ++l) hw[l] = m->h[l] * m->w[l];
     EVR_HIP(hipMemcpy(m->d_hw, hw, sizeof(hw), hipMemcpyHostToDevice));
+    return EVR_OK;
+}
+
+// the plan of n image pairs inside the current buffers: cached, or built into the least recently used slot (its ConvArgs go to the
+// device in stream order, behind whatever launch still reads the slot's previous contents)
+static int lpips_plan(evr_lpips* m, int n, hipStream_t stream) {
+    evr_lpips::Plan* pl = nullptr;
+    for (auto& c : m->plans) if (c.n == n) pl = &c;
+    if (pl) { pl->stamp = ++m->clock; m->cur = pl; m->n = n; return EVR_OK; }
+    for (auto& c : m->plans) {
+        if (c.n == 0) { pl = &c; break; }
+        if (!pl || c.stamp < pl->stamp) pl = &c;
+    }
+    pl->n = 0;
+    const int n2 = 2 * n;
+    const int hp1 = m->h[1], wp1 = m->w[1], hp2 = m->h[2], wp2 = m->w[2];
     const float* ins[4] = {m->pool1, m->pool2, m->feat[2], m->feat[3]};
     const int hin[4] = {hp1, hp2, hp2, hp2}, win[4] = {wp1, wp2, wp2, wp2};
     for (int i = 0; i < 4; ++i) {
         Layer& L = m->L[i];
-        ConvArgs& a = m->args[i];
+        ConvArgs& a = pl->args[i];
         memset(&a, 0, sizeof(a));
         a.in0 = ins[i]; a.c0 = L.cin; a.in_mode = IN_SINGLE; a.n = n2; a.hin = hin[i]; a.win = win[i];
         a.hm = hin[i]; a.wm = win[i]; a.stride = 1; a.os = 1; a.hout = hin[i]; a.wout = win[i];
@@ -501,24 +531,23 @@ static int lpips_plan(evr_lpips* m, int n, int H, int W, hipStream_t stream) {
         a.acc_scale = (L.x3 == 3) ? std::ldexp(1.0f, -(L.mx_e + H2_ACT_EXP)) : 1.0f;
         a.in_packed = a.out_packed = L.x3 ? 1 : 0;      // pool1 / pool2 / feat1..feat4 are PACKED (H2 in mode 3) in the split modes
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - L.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
-        pick_conv_tile(a, 32, &m->wm[i], &m->nb[i]);
+        pick_conv_tile(a, 32, &pl->wm[i], &pl->nb[i]);
     }
     {   // split-K partial sums of conv3..conv5 at small batches (conv.h KSPLIT_WS_BYTES): this handle's own -- it runs on the evaluation
         // stream beside a model's launches
         // (only when a conv of this plan can split -- a split arithmetic and <= 192 tiles of 128 pixels -- and a failed allocation
         // degrades to "never split" instead of failing the plan: ADVICE r5)
         bool may_split = false;
-        for (int i = 1; i < 4; ++i) if (m->args[i].x3 && (int64_t)n2 * m->args[i].hm * m->args[i].wm <= 192LL * 128) may_split = true;
-        float* kws = nullptr;
-        if (may_split) {
-            if (hipMalloc((void**)&kws, KSPLIT_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); kws = nullptr; }
-            else m->allocs.push_back((void*)kws);
+        for (int i = 1; i < 4; ++i) if (pl->args[i].x3 && (int64_t)n2 * pl->args[i].hm * pl->args[i].wm <= 192LL * 128) may_split = true;
+        if (may_split && !m->kws && !m->kws_tried) {
+            m->kws_tried = true;
+            if (hipMalloc((void**)&m->kws, KSPLIT_WS_BYTES) != hipSuccess) { (void)hipGetLastError(); m->kws = nullptr; }
+            else m->allocs.push_back((void*)m->kws);
         }
-        for (int i = 0; i < 4; ++i) m->args[i].ksplit_ws = kws;
+        for (int i = 0; i < 4; ++i) pl->args[i].ksplit_ws = may_split ? m->kws : nullptr;
     }
-    EVR_HIP(hipMalloc((void**)&m->d_args, 4 * sizeof(ConvArgs)));
-    m->allocs.push_back((void*)m->d_args);
-    EVR_HIP(hipMemcpy(m->d_args, m->args, 4 * sizeof(ConvArgs), hipMemcpyHostToDevice));
+    EVR_HIP(hipMemcpyAsync(m->d_args + 4 * (pl - m->plans), pl->args, 4 * sizeof(ConvArgs), hipMemcpyHostToDevice, stream));
+    pl->n = n; pl->stamp = ++m->clock; m->cur = pl; m->n = n;
     return EVR_OK;
 }
 
@@ -527,7 +556,10 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     hipStream_t stream = (hipStream_t)stream_;
     EVR_REQUIRE(m && img && ref && out && n >= 1 && H >= 1 && W >= 1, "evr_lpips_forward: bad argument");
     int rc;
-    if (m->n != n || m->H != H || m->W != W) if ((rc = lpips_plan(m, n, H, W, stream))) return rc;
+    if (m->H != H || m->W != W || n > m->cap) if ((rc = lpips_buffers(m, n, H, W, stream))) return rc;
+    if (!m->cur || m->cur->n != n) if ((rc = lpips_plan(m, n, stream))) return rc;
+    const evr_lpips::Plan& P = *m->cur;
+    ConvArgs* const d_args = m->d_args + 4 * (m->cur - m->plans);
     const int n2 = 2 * n;
     Conv1Args c1{};
     c1.img = img; c1.ref = ref; c1.n = n; c1.H = H; c1.W = W; c1.h1 = m->h[0]; c1.w1 = m->w[0]; c1.clip = clip;
@@ -572,13 +604,13 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     };
     if (score_split && (rc = score(0, 1))) return rc;
     if ((rc = pool(m->feat[0], m->pool1, m->h[0], m->w[0], 64, m->h[1], m->w[1], 0))) return rc;
-    if ((rc = launch_conv_igemm(m->args[0], m->d_args + 0, 32, m->wm[0], m->nb[0], stream))) return rc;
+    if ((rc = launch_conv_igemm(P.args[0], d_args + 0, 32, P.wm[0], P.nb[0], stream))) return rc;
     if (score_split && (rc = score(1, 1))) return rc;
     if ((rc = pool(m->feat[1], m->pool2, m->h[1], m->w[1], 192, m->h[2], m->w[2], pk))) return rc;
     // (relu3 .. relu5 are 69 MB together at 64 frames -- they outlive their convolutions in the Infinity Cache -- so ONE launch scores
     // the three of them behind conv5 (grid.z = layer): two launches fewer on the evaluation stream; EVR_LPIPS_SCORE_SPLIT=2: one each)
     for (int i = 1; i < 4; ++i) {
-        if ((rc = launch_conv_igemm(m->args[i], m->d_args + i, 32, m->wm[i], m->nb[i], stream))) return rc;
+        if ((rc = launch_conv_igemm(P.args[i], d_args + i, 32, P.wm[i], P.nb[i], stream))) return rc;
         if (score_split == 2 && (rc = score(i + 1, 1))) return rc;
     }
     if (score_split == 1 && (rc = score(2, 3))) return rc;

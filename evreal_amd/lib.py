@@ -138,8 +138,11 @@ def require_gpu():
 
 def stream_ptr(stream=None):
     import torch
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return c_void_p(s.cuda_stream)
+    if stream is not None:
+        return c_void_p(stream.cuda_stream)
+    # (the raw handle of the current stream without building a torch.cuda.Stream object: ~7 us -> <1 us per call, and a one-sequence
+    # step makes six of these calls in ~410 us)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def ptr(t):

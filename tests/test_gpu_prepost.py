@@ -96,6 +96,38 @@ def test_lpips_vs_oracle(shape):
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-7)
 
 
+def test_lpips_handle_serves_changing_pair_counts():
+    """The drop-in's chunks change the number of scored frames at every sequence boundary.  One handle keeps buffers for the largest
+    count seen and a small cache of per-count plans (lpips.hip, round 6): every count -- smaller than the capacity, growing it,
+    evicting the oldest of the eight cached plans, returning to an evicted one -- must give exactly what a fresh handle gives."""
+    from evreal_amd import weights
+    from evreal_amd.lpips import LPIPS
+    from oracle import lpips as ol
+    sd = weights.synth_lpips_state_dict(seed=3)
+    H, W = 97, 131
+    rng = np.random.default_rng(5)
+    ref = rng.random((12, H, W), dtype=np.float32)
+    img = np.clip(ref + 0.1 * rng.standard_normal(ref.shape), 0, 1).astype(np.float32)
+    d_img, d_ref = torch.from_numpy(img).cuda(), torch.from_numpy(ref).cuda()
+    want = LPIPS(sd)(d_img, d_ref).cpu().numpy()                      # a fresh handle, 12 pairs at once
+    np.testing.assert_allclose(want[:2], ol.lpips(sd, img[:2], ref[:2]), rtol=2e-4, atol=1e-7)
+    fresh = {}
+    m = LPIPS(sd)
+    for n in [3, 5, 2, 3, 12, 1, 4, 6, 7, 8, 9, 10, 11, 3, 12, 5, 1]:      # 12 distinct counts through 8 plan slots
+        o = int(rng.integers(0, 12 - n + 1))
+        got = m(d_img[o:o + n], d_ref[o:o + n]).cpu().numpy()
+        if n not in fresh:
+            fresh[n] = LPIPS(sd)
+        np.testing.assert_array_equal(got, fresh[n](d_img[o:o + n], d_ref[o:o + n]).cpu().numpy(), err_msg=f'n={n}')
+        np.testing.assert_allclose(got, want[o:o + n], rtol=1e-6, atol=1e-9, err_msg=f'n={n}')
+    m2 = LPIPS(sd)      # a different image size on a used handle re-allocates
+    a = m2(d_img[:2], d_ref[:2]).cpu().numpy()
+    b = m2(d_img[:2, :64, :80].contiguous(), d_ref[:2, :64, :80].contiguous()).cpu().numpy()
+    c = m2(d_img[:2], d_ref[:2]).cpu().numpy()
+    np.testing.assert_array_equal(a, c)
+    np.testing.assert_allclose(b, ol.lpips(sd, img[:2, :64, :80], ref[:2, :64, :80]), rtol=2e-4, atol=1e-7)
+
+
 def test_lpips_with_user_supplied_weights():
     """When the real AlexNet-v0.1 LPIPS weights are available (EVREAL_LPIPS_WEIGHTS = a torch.save'd pyiqa / lpips state_dict, the
     file evreal_amd.eval picks up), the HIP path and the oracle are compared on THEM -- trained filters instead of the synthetic
