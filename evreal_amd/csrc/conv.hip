@@ -295,7 +295,41 @@ __device__ __forceinline__ void epi_prefetch(const ConvArgs& a, int n0, int h, f
     }
 }
 
-template <int NB, bool LSTM, bool GROUPED, bool FAST>
+// ConvGRU operands of conv3x3_c16_rows_kernel (one 32-column block, hidden == 16), requested a step ahead and parked RAW in `pre`
+// (epi_finish<..., GRUPRE = true> decodes them): h_prev of the lane's two real runs in slots 2, 3 -- for EPI_GRU_ZR those are the
+// reset-gate runs q = 2, 3 themselves, for EPI_GRU_OUT the runs q = 0, 1, whose update gate z sits in slots 0, 1
+__device__ __forceinline__ void gru_prefetch16(const ConvArgs& a, int h, f32x16& pre, const EpiCtx& ec) {
+    const unsigned row = (unsigned)(ec.mvalid ? ec.m : 0) * 16u;
+    const bool zr = a.epi == EPI_GRU_ZR;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ch = 8 * q + 4 * h;
+        f4 hp;
+        if (a.state_packed) {
+            const float* qp = a.state + pk_off(row, ch);
+            hp = f4{qp[0], qp[1], 0.f, 0.f};
+            if constexpr (FMT == 2) { hp[2] = qp[8]; hp[3] = qp[9]; } else hp[2] = a.state[pk_lo_off(row, ch)];
+        } else hp = *(const f4*)(a.state + row + (unsigned)ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[4 * (q + 2) + j] = hp[j];
+        if (!zr) {
+            const f4 z = *(const f4*)(a.aux0 + row + (unsigned)ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre[4 * q + j] = z[j];
+        }
+    }
+}
+__device__ __forceinline__ f4 gru_parked_h(const ConvArgs& a, const f32x16& pre, int slot) {
+    f4 pv = {pre[4 * slot], pre[4 * slot + 1], pre[4 * slot + 2], pre[4 * slot + 3]};
+    if (a.state_packed) {
+        const uint2 phi = {__float_as_uint(pv[0]), __float_as_uint(pv[1])};
+        if constexpr (FMT == 2) { const uint2 plo = {__float_as_uint(pv[2]), __float_as_uint(pv[3])}; pv = unpack4_h2(phi, plo); }
+        else if constexpr (FMT != 3) pv = unpack4(phi, __float_as_uint(pv[2]));
+    }
+    return pv;
+}
+
+template <int NB, bool LSTM, bool GROUPED, bool FAST, bool GRUPRE = false>
 __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, int n0, int h, f32x16 (&acc)[NB],
                                            f32x16 (&pre)[LSTM ? 1 : NB], float* __restrict__ img_out) {
     const int epi = a.epi;
@@ -366,7 +400,8 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                             for (int j = 0; j < 4; ++j) z[j] = sigmoid_t<FAST>(v[j]);
                             *(f4*)(a.aux0 + opx * (unsigned)C + n4) = z;                      // update gate z
                         } else if (n4 < 2 * C) {
-                            const f4 hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
+                            f4 hp;
+                            if constexpr (GRUPRE) hp = gru_parked_h(a, pre[nb], q); else hp = ld4(a.state, opx * (unsigned)C, n4 - C, a.state_packed);
                             f4 hr;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) hr[j] = hp[j] * sigmoid_t<FAST>(v[j]);
@@ -374,7 +409,9 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const EpiCtx& ec, 
                         }
                     } else if (n4 < C) {
                         const unsigned o = opx * (unsigned)C + (unsigned)n4;
-                        const f4 z = *(const f4*)(a.aux0 + o), hp = ld4(a.state, opx * (unsigned)C, n4, a.state_packed);
+                        f4 z, hp;
+                        if constexpr (GRUPRE) { z = f4{pre[nb][4 * q], pre[nb][4 * q + 1], pre[nb][4 * q + 2], pre[nb][4 * q + 3]}; hp = gru_parked_h(a, pre[nb], q + 2); }
+                        else { z = *(const f4*)(a.aux0 + o); hp = ld4(a.state, opx * (unsigned)C, n4, a.state_packed); }
                         f4 hn;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)   // submodules.py:285: prev*(1-update) + out*update
@@ -1595,6 +1632,259 @@ static int launch_c16(const ConvArgs& a, const ConvArgs* d_args, hipStream_t str
     return EVR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same layers, walked ROW BY ROW (round 6; profiles/r06_firenet_rows.txt).  conv3x3_c16_kernel above takes 128 LINEAR pixels per
+// tile and fetches three shifted 130-pixel bands for it, reading every input row three times through L2.  Here a block owns a
+// 128-column STRIP of one image and walks down a segment of its rows, RPB rows per step: the bands of row y are the image rows y-1, y,
+// y+1 of the strip, so a step needs only RPB NEW bands -- every input byte is fetched once (plus a 2-row halo per segment) -- and the
+// horizontal / vertical borders are the DMA's own zero fill (no tap masks).  The bands live in a ring of NBUF = 2 RPB + 2 slots per
+// source: RPB + 2 under the multiplies, RPB being filled for the next step.  A step is: barrier; request the next step's rows; the
+// multiplies (fragments read one tap ahead); ONE wait -- for those rows, the step's epilogue operands and the previous step's stores,
+// all requested at least a multiply phase earlier; the epilogue's stores; the NEXT step's operand requests (residual / ConvGRU state:
+// gru_prefetch16).  No round trip is waited for on its own.  4 RPB waves: RPB image rows x four 32-pixel column blocks.  Per pixel the
+// MFMA sequence -- sources, then rows, then columns, (lo_w hi_x, hi_w lo_x, hi_w hi_x) each -- is the one of the tile kernel:
+// bit-identical results (tests/test_gpu_fullsize.py).
+// Measured (64 x 240x192, single stream): residual convolutions 157 -> 154 us, ConvGRU z|r 265-273 -> 247 us, candidate + update
+// 265-308 -> 293 us; FireNet step 25.9 -> 27.4 k frames/s.  All three forms move 3.2-3.8 TB/s of their algorithmic bytes, half of them
+// writes: what is left is the memory system's mixed read/write rate, not the schedule (a deeper ring, more blocks, other step heights:
+// equal or worse).
+// NSRC / HALFW (sources; only weight rows 0..15 kept, as in the tile kernel) are template parameters so that every tap's LDS offset is
+// an immediate of its ds_read: as kernel arguments they cost 36 address registers, hoisted out of the step loop.
+// (Rows requested TWO steps ahead -- a ring of 3 RPB + 2 slots, the end-of-step wait leaving the newest requests in flight -- measured
+// no better on the one-source layers, the only ones with LDS for it: 165 vs 164 us, 25.8 vs 26.3 k frames/s.  Removed.)
+template <int NB, int RPB, int NSRC, bool HALFW>
+__global__ __launch_bounds__(256 * RPB, (RPB == 1 ? 3 : 2)) void conv3x3_c16_rows_kernel(const ConvArgs* __restrict__ ap, float* __restrict__ img_out,
+                                                                                       int rseg, int nseg, int nstrips) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvArgs& a = *ap;
+    constexpr int NC = 4 * RPB, SP = 4, TM = 128, NBUF = 2 * RPB + 2;
+    constexpr int A_ROWS = TM + 2, A_PIECES = (A_ROWS + 15) / 16, A_F4 = A_ROWS * SP;
+    extern __shared__ __attribute__((aligned(16))) float4 lds[];   // [source 0 ring | source 1 ring | weights (9 or 18 tiles) | a zero row | bias]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.win, H = a.hin;
+    const int hw = H * W;
+    const int M = a.n * hw;
+    constexpr int nsrc = NSRC, ntc = 9 * nsrc, ktot = ntc * 16;
+    const unsigned in_pix = (unsigned)M;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in0, in_pix * 16u * 4u);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in1 ? a.in1 : a.in0, in_pix * 16u * 4u);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt, (unsigned)a.cout * ktot * 4u);
+    const int r = lane & 31, hh = lane >> 5;
+    constexpr int wrows = HALFW ? 16 : 32 * NB, w_f4 = wrows * SP, w_pieces = wrows / 16;
+    constexpr int WOFF = nsrc * NBUF * A_F4, ZOFF = WOFF + ntc * w_f4, BOFF = ZOFF + SP;
+    const int ntiles_n = a.cout / (32 * NB);
+    const int ntile = blockIdx.x % ntiles_n, n0 = ntile * 32 * NB;
+    const int istart = blockIdx.x / ntiles_n, istep = gridDim.x / ntiles_n;
+    const int items = a.n * nseg * nstrips;
+
+    for (int p = wv; p < ntc * w_pieces; p += NC) {      // the N tile's weights, once
+        const int tc = p / w_pieces, row = (p % w_pieces) * 16 + (lane >> 2);
+        const unsigned off = (unsigned)((n0 + row) * ktot + tc * 16 + (((lane & 3) ^ swz<16>(row)) * 4));
+        lds_ptr_t dst = (lds_ptr_t)&lds[WOFF + tc * w_f4 + (p % w_pieces) * 64];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, off * 4u, 0, 0, 0);
+    }
+    if (tid < SP) lds[ZOFF + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the accumulators start at the bias, read from LDS: a global fetch per step would queue behind the step's band requests)
+    if (tid < 8 * NB) lds[BOFF + tid] = *(const float4*)(a.bias + n0 + 4 * tid);
+
+    // piece q of a request of `nrows` image rows: (row q / (9 nsrc), source, 16-pixel piece); the waves take q = wv, wv + NC, ...
+    // (swz<16>(16 p + rl) does not depend on the piece p: a lane's byte offset inside a piece is fixed.)  Pixels outside the image --
+    // and whole rows above / below it -- are the descriptor's zero fill.
+    const int rl = lane >> 2;
+    const int lane_off = rl * 64 + (((lane & 3) ^ swz<16>(rl)) * 16);
+    auto issue_rows = [&](int img, int yy0, int nrows, int slot0, int x0, int ylast) {
+        const int per_row = A_PIECES * nsrc;
+        for (int q = wv; q < nrows * per_row; q += NC) {
+            const int rowi = q / per_row, rem = q - rowi * per_row;
+            const int sidx = rem / A_PIECES, p = rem - sidx * A_PIECES;
+            const int yy = yy0 + rowi;
+            if (yy > ylast) break;                             // (rows below the segment's halo are never multiplied)
+            int slot = slot0 + rowi;
+            if (slot >= NBUF) slot -= NBUF;
+            const bool ok = (unsigned)yy < (unsigned)H && (unsigned)(x0 - 1 + p * 16 + rl) < (unsigned)W;
+            const unsigned voff = ok ? (unsigned)(((img * H + yy) * W + x0 - 1) * 64 + p * 1024 + lane_off) : OOB_OFFSET;
+            lds_ptr_t dst = (lds_ptr_t)&lds[(sidx * NBUF + slot) * A_F4 + p * 64];
+            if (p * 16 + 16 <= A_ROWS) {
+                if (sidx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            } else if (lane < (A_ROWS - (A_PIECES - 1) * 16) * 4) {      // the last piece: its two real rows only
+                if (sidx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    const bool gru = NB == 1 && (a.epi == EPI_GRU_ZR || a.epi == EPI_GRU_OUT);      // (hidden == 16: c16_rows_eligible)
+    // timing ablation (EVR_ABLATE + EVR_ABLATE_ALL; results are garbage): 2 no band requests behind an item's first, 4 no epilogue
+    // (operands and stores), 8 no end-of-step wait
+    const int ablate = a.debug_ablate;
+    const int sw = swz<16>(r);
+    const int rr = RPB > 1 ? wv / 4 : 0;                  // image row of the step, column block
+    // a lane's weight row in tile 0.  HALFW: the tile holds rows 0..15 only; lanes 16..31 read them again -- their accumulator columns
+    // (output channels 16..31) are padding nobody stores
+    const float4* const wbase = &lds[WOFF + (r & (wrows - 1)) * SP];
+    const int idx = (wv & 3) * 32 + r;
+
+    for (int item = istart; item < items; item += istep) {
+        const int strip = item % nstrips;
+        const int t_ = item / nstrips;
+        const int seg = t_ % nseg, img = t_ / nseg;
+        const int x0 = strip * TM, y0 = seg * rseg;
+        const int y1 = (y0 + rseg < H) ? y0 + rseg : H;
+        // (everyone has left the previous item's last rows -- and, the first time, the weights and the bias are in place)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_rows(img, y0 - 1, RPB + 2, 0, x0, y1);      // rows y0-1 .. y0+RPB: the first step's
+        int slot_m1 = 0;                                  // ring slot of row ys - 1
+        const int x = x0 + idx;
+        f32x16 pre[NB];
+        EpiCtx ec;
+        // the epilogue's operands (residual / ConvGRU state) are requested ONE STEP ahead, behind the previous step's stores: neither
+        // their round trip nor the stores' is ever waited for on its own -- a step has ONE wait, for everything older than its stores
+        auto setup_step = [&](int ys) {
+            const int y = ys + rr;
+            const bool lane_ok = x < W && y < y1;
+            const int m = (img * H + (y < H ? y : H - 1)) * W + (x < W ? x : W - 1);
+            f32x16 dead[NB];
+            epi_setup<NB, false, false>(a, m, M, hw, n0, hh, dead, pre, ec, lane_ok, false);      // (its bias loads are dead: the accumulators start from LDS)
+            if (gru) gru_prefetch16(a, hh, pre[0], ec);
+            else epi_prefetch<NB, false, false>(a, n0, hh, pre, ec);
+        };
+        setup_step(y0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int ys = y0; ys < y1; ys += RPB) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {   // the next step's new rows ys+RPB+1 .. ys+2 RPB into the slots of the rows the previous step has left
+                int slot = slot_m1 + RPB + 2;
+                if (slot >= NBUF) slot -= NBUF;
+                if (ys + RPB < y1 && !(ablate & 2)) issue_rows(img, ys + RPB + 1, RPB, slot, x0, y1);
+            }
+            f32x16 acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = lds[BOFF + nb * 8 + 2 * q + hh];
+                    acc[nb][4 * q] = b4.x; acc[nb][4 * q + 1] = b4.y; acc[nb][4 * q + 2] = b4.z; acc[nb][4 * q + 3] = b4.w;
+                }
+            // the taps' fragments (x hi / lo of the pixel row, w hi / lo of the lane's output row) are read ONE TAP AHEAD of the MFMAs
+            // that use them, into the other half of f: left to itself hipcc reuses three register quads and every MFMA waits a full
+            // LDS latency for a read issued one MFMA earlier
+            static_assert(NB == 1, "the tap pipeline below is written for one 32-column block");
+            u32x4_t f[2][4];
+            // (per lane: the x fragments' offsets inside a band for the three columns, the w fragments' inside a weight tile -- lanes of
+            // rows the tile does not hold read the zero row through a negative tile offset)
+            auto load_tap = [&](int src, int tp, u32x4_t (&d)[4]) {      // src, tp = dy * 3 + dx: compile-time after unrolling
+                const int dy = tp / 3, dx = tp - dy * 3;
+                int slot = slot_m1 + rr + dy;
+                if (slot >= NBUF) slot -= NBUF;
+                const float4* la = &lds[(src * NBUF + slot) * A_F4 + (idx + dx) * SP];
+                const int swi = swz<16>(idx + dx);
+                d[0] = __builtin_bit_cast(u32x4_t, la[hh ^ swi]); d[1] = __builtin_bit_cast(u32x4_t, la[(2 + hh) ^ swi]);
+                const float4* lb = wbase + (tp * nsrc + src) * w_f4;
+                d[2] = __builtin_bit_cast(u32x4_t, lb[hh ^ sw]); d[3] = __builtin_bit_cast(u32x4_t, lb[(2 + hh) ^ sw]);
+            };
+            load_tap(0, 0, f[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int src = 0; src < nsrc; ++src) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int cur = (src * 9 + tp) & 1;
+                    if (tp + 1 < 9) load_tap(src, tp + 1, f[cur ^ 1]);
+                    else if (src + 1 < nsrc) load_tap(src + 1, 0, f[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);      // (the next tap's reads go out BEFORE this tap's MFMAs: 96 matrix cycles cover the LDS latency)
+                    const u32x4_t xh = f[cur][0], xl = f[cur][1], wh = f[cur][2], wl = f[cur][3];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl), __builtin_bit_cast(f16x8, xh), acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xl), acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), __builtin_bit_cast(f16x8, xh), acc[0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the next step's rows (requested a whole multiply phase ago), this step's operands and the previous step's stores
+            if (!(ablate & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(ablate & 4)) {
+                epi_finish<NB, false, false, true, NB == 1>(a, ec, n0, hh, acc, pre, img_out);
+                if (ys + RPB < y1) setup_step(ys + RPB);
+            } else if (acc[0][0] == 123.456f) img_out[0] = acc[0][1];
+            slot_m1 += RPB;
+            if (slot_m1 >= NBUF) slot_m1 -= NBUF;
+        }
+    }
+#endif
+}
+
+// rows per segment: about two items per resident block, even, at least 8 (the halo rows are fetched once more per segment)
+static void c16_rows_plan(const ConvArgs& a, int blocks, int* rseg, int* nseg, int* nstrips) {
+    const int H = a.hin, W = a.win;
+    *nstrips = (W + 127) / 128;
+    int want = (2 * blocks + a.n * *nstrips - 1) / (a.n * *nstrips);
+    if (want < 1) want = 1;
+    int rs = (H + want - 1) / want;
+    rs = (rs + 1) & ~1;
+    if (rs < 8) rs = 8;
+    *rseg = rs; *nseg = (H + rs - 1) / rs;
+}
+
+// EVR_C16_ROWS: 0 = the tile kernel everywhere, 2 = the row kernel whatever the size
+static int c16_rows_mode() {
+    static const int v = getenv("EVR_C16_ROWS") ? atoi(getenv("EVR_C16_ROWS")) : 1;
+    return v;
+}
+static bool c16_rows_eligible(const ConvArgs& a) {
+    if (c16_rows_mode() <= 0) return false;
+    if ((int64_t)a.n * a.hin * a.win >= (1LL << 26)) return false;      // (32-bit byte offsets of 64-B pixels)
+    if ((a.epi == EPI_GRU_ZR || a.epi == EPI_GRU_OUT) && a.hidden != 16) return false;      // (gru_prefetch16)
+    // (a small batch has too few (strip, segment) items to fill the chip: the tile kernel's 128-pixel tiles stay; EVR_C16_ROWS=2
+    // lifts the threshold -- the parity tests' small shapes)
+    return c16_rows_mode() >= 2 || (int64_t)a.n * ((a.win + 127) / 128) * ((a.hin + 7) / 8) >= 1024;
+}
+
+template <int NB, int RPB, int NSRC, bool HALFW>
+static int launch_c16_rows_t(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img, int per_cu) {
+    constexpr int NBUF = 2 * RPB + 2;
+    constexpr int wrows = HALFW ? 16 : 32 * NB;
+    const size_t lds_bytes = ((size_t)NSRC * NBUF * (128 + 2) * 4 + (size_t)9 * NSRC * wrows * 4 + 4 + 8 * NB) * sizeof(float4);
+    const int ntiles_n = a.cout / (32 * NB);
+    int rseg, nseg, nstrips;
+    c16_rows_plan(a, 256 * per_cu, &rseg, &nseg, &nstrips);
+    int64_t items = (int64_t)a.n * nseg * nstrips;
+    int blocks = 256 * per_cu;
+    if (blocks > items) blocks = (int)items;
+    static std::atomic<unsigned> attr_done[64];
+    int dev = 0;
+    EVR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_relaxed)) {
+        EVR_HIP(hipFuncSetAttribute((const void*)conv3x3_c16_rows_kernel<NB, RPB, NSRC, HALFW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr_done[dev].store(1, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((conv3x3_c16_rows_kernel<NB, RPB, NSRC, HALFW>), dim3((unsigned)(blocks * ntiles_n)), dim3(256 * RPB), lds_bytes, stream,
+                       d_args, img, rseg, nseg, nstrips);
+    EVR_LAUNCH_CHECK();
+    return EVR_OK;
+}
+
+template <int NB>
+static int launch_c16_rows(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
+    const int nsrc = (a.in_mode == IN_CAT && a.c1) ? 2 : 1;
+    const bool half_w = NB == 1 && a.n_valid <= 16;
+    // rows per step and blocks per CU: EVR_C16_ROWS_1=<rows>,<blocks> for the one-source layers, EVR_C16_ROWS_2 for the two-source ones
+    // (A/B).  LDS: one source, 1 row = 4 x 8.3 + 18 (9) KB -> three blocks; two sources, 2 rows = 12 x 8.3 + 36 (18) KB -> one block of 8 waves
+    static const int r1 = [] { const char* e = getenv("EVR_C16_ROWS_1"); return e ? atoi(e) : 1; }();
+    static const int b1 = [] { const char* e = getenv("EVR_C16_ROWS_1"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    static const int r2 = [] { const char* e = getenv("EVR_C16_ROWS_2"); return e ? atoi(e) : 2; }();
+    static const int b2 = [] { const char* e = getenv("EVR_C16_ROWS_2"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+    const int rows = nsrc == 1 ? r1 : 2, bl = nsrc == 1 ? b1 : b2;      // (two sources: always two rows per step -- one row per step leaves four waves on the CU)
+    (void)r2;
+    const int per_cu = bl > 0 ? bl : (rows == 2 ? 1 : (nsrc == 1 ? 3 : 1));
+    if (rows == 2) {
+        if (nsrc == 1) return half_w ? launch_c16_rows_t<NB, 2, 1, true>(a, d_args, stream, img, per_cu) : launch_c16_rows_t<NB, 2, 1, false>(a, d_args, stream, img, per_cu);
+        return half_w ? launch_c16_rows_t<NB, 2, 2, true>(a, d_args, stream, img, per_cu) : launch_c16_rows_t<NB, 2, 2, false>(a, d_args, stream, img, per_cu);
+    }
+    return half_w ? launch_c16_rows_t<NB, 1, 1, true>(a, d_args, stream, img, per_cu) : launch_c16_rows_t<NB, 1, 1, false>(a, d_args, stream, img, per_cu);
+}
+
 static bool c16_eligible(const ConvArgs& a, int kc) {
     if (!(a.x3 == 3 && a.in_packed && kc == 16 && a.tp.ntaps == 9 && a.stride == 1 && a.tp.ngroups == 1)) return false;
     if (a.c0 != 16 || !(a.in_mode == IN_SINGLE || a.c1 == 16)) return false;
@@ -2404,6 +2694,7 @@ int EVR_LAUNCH_NAME(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, i
 #if EVR_ARITH == 3
     if (c16_eligible(a, kc)) {
         EVR_REQUIRE(a.acc_scale > 0.f && a.div_hw_sh < 32, "conv3x3_c16: plan without accumulator scale / fastdiv");
+        if (c16_rows_eligible(a)) return launch_c16_rows<1>(a, d_args, stream, img);
         return launch_c16<1>(a, d_args, stream, img);
     }
 #endif

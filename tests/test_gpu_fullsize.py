@@ -217,6 +217,48 @@ def test_firenet_real_weights_240x180_k_events(tmp_path):
         assert float(np.abs(img - want).max()) < IMG_ATOL, i
 
 
+_ROWS_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+from conftest import load_npz
+from evreal_amd import model
+w = load_npz('firenet_weights.npz')
+H, W, n = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+m = model.FireNet_legacy(unet_kwargs=dict(num_bins=5, recurrent_block_type='convgru', base_num_channels=16,
+                                          num_residual_blocks=2, kernel_size=3, norm='none'))
+m.load_state_dict({k: w[k] for k in w.files})
+g = torch.Generator().manual_seed(5)
+outs = []
+m.reset_states()
+for i in range(3):
+    v = (torch.randn((n, 5, H, W), generator=g) * (torch.rand((n, 5, H, W), generator=g) < 0.2)).cuda()
+    outs.append(m(v)['image'].cpu().numpy())
+np.save(sys.argv[2], np.stack(outs))
+"""
+
+
+@pytest.mark.parametrize('H,W,n', [(180, 240, 24), (260, 346, 12), (100, 131, 40)])
+def test_firenet_row_kernel_is_bit_identical_to_the_tile_kernel(tmp_path, H, W, n):
+    """Round 6: launches big enough to fill the chip take conv3x3_c16_rows_kernel (128-column strips walked row by row, every input
+    row fetched once) instead of conv3x3_c16_kernel (128 linear pixels, three shifted bands).  Per pixel both run the same MFMA
+    sequence, so three recurrent FireNet steps (shipped checkpoint; batches of 24 x 240x180, 12 x 346x260 -- three strips, the last
+    ragged -- and 40 x 131x100 -- padded to 112 rows, a ragged second strip) must agree BIT FOR BIT: the default selection, the row
+    kernel forced with the other step heights, and EVR_C16_ROWS=0."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in [('tile', {'EVR_C16_ROWS': '0'}), ('default', {}), ('rows', {'EVR_C16_ROWS': '2'}),
+                      ('rows_alt', {'EVR_C16_ROWS': '2', 'EVR_C16_ROWS_1': '2', 'EVR_C16_ROWS_2': '1'})]:
+        out = str(tmp_path / f'{name}.npy')
+        r = subprocess.run([sys.executable, '-c', _ROWS_SCRIPT, root, out, str(H), str(W), str(n)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got[name] = np.load(out)
+    assert np.isfinite(got['tile']).all() and float(np.abs(got['tile']).max()) > 0
+    for name in ('default', 'rows', 'rows_alt'):
+        assert np.array_equal(got[name].view(np.uint32), got['tile'].view(np.uint32)), name
+
+
 def test_colornet_970x624_streams_vs_oracle():
     """BS-ERGB-sized colour pass (even crop of 970x625): the four half-resolution streams (485x312 -> 488x312) and the
     full-resolution stream (970x624 -> 976x624) against the oracle run stream by stream, as model/model.py:85-99 does."""

@@ -11,6 +11,8 @@ The default arithmetic since round 4 is `h3` (three f16 products per term on H2 
                      image gate 1e-4; again on the wide / twin band kernels.
 * EVR_ARITH=mx    -- f16 + MX-fp8 cross terms on PACKED tensors for every layout; again on the band kernels and the implicit GEMM.
 * EVR_FIRENET_PAD32=1 -- FireNet's trained checkpoints on the 32-channel kernels (default: the unpadded 16-channel h3 kernel), in h3 and mx.
+* EVR_C16_ROWS=2 -- FireNet's 16-channel layers on the row-walking kernel (round 6; by default only launches big enough to fill the
+                     chip take it), 1 and 2 image rows per step; EVR_C16_ROWS=0 -- the 128-pixel tile kernel everywhere.
 The switches are read when the library plans its launches, hence one fresh interpreter per mode.
 """
 import os
@@ -50,6 +52,18 @@ def test_parity_with_wide_band_kernel_on_small_shapes():
 def test_parity_with_twin_band_kernel_on_small_shapes():
     # its two-blocks-per-CU form (256 x 128 tiles, one band buffer), the default for ConvLSTM layers of up to 256 input channels
     _run({'EVR_BAND_MIN': '1', 'EVR_WIDE_MIN': '1', 'EVR_WIDE': '2', 'EVR_PROG_WIDE_MIN': '1'})
+
+
+def test_parity_with_firenet_row_kernel_on_small_shapes():
+    _run({'EVR_C16_ROWS': '2'})
+
+
+def test_parity_with_firenet_row_kernel_other_step_heights():
+    _run({'EVR_C16_ROWS': '2', 'EVR_C16_ROWS_1': '2', 'EVR_C16_ROWS_2': '1'})
+
+
+def test_parity_with_firenet_tile_kernel_everywhere():
+    _run({'EVR_C16_ROWS': '0'})
 
 
 def test_parity_in_exact_fp32_mode():
