@@ -17,7 +17,7 @@ for l in open(f'{O}/pmc_raw.md'):
     m = re.match(r'\| `(.*?)` \| (\w+) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|', l)
     if m:
         rows.setdefault(m.group(1), {})[m.group(2)] = (float(m.group(4)), float(m.group(5)), int(m.group(3)))
-print('| kernel | launches | avg us | clock GHz | matrix busy | parked (waitcnt/barrier) | issue-stalled | issuing | VALU per wave quad-cycle | LDS wait |')
+print('| kernel | launches | avg us | clock GHz | matrix busy | parked (waitcnt/barrier) | issue-stalled | issuing | VALU instructions per wave quad-cycle (SQ_WAVE_CYCLES counts quad-cycles) | LDS wait |')
 print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
 for k, d in sorted(rows.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', (0, 0, 0))[1] * kv[1].get('GRBM_GUI_ACTIVE', (0, 0, 0))[2]):
     if 'GRBM_GUI_ACTIVE' not in d or 'SQ_WAVE_CYCLES' not in d: continue
@@ -26,5 +26,5 @@ for k, d in sorted(rows.items(), key=lambda kv: -kv[1].get('GRBM_GUI_ACTIVE', (0
     wc = d['SQ_WAVE_CYCLES'][0]; b = d.get('SQ_VALU_MFMA_BUSY_CYCLES', (0,))[0]
     wa = d.get('SQ_WAIT_ANY', (0,))[0]; wi = d.get('SQ_WAIT_INST_ANY', (0,))[0]; ai = d.get('SQ_ACTIVE_INST_ANY', (0,))[0]
     va = d.get('SQ_INSTS_VALU', (0,))[0]; wl = d.get('SQ_WAIT_INST_LDS', (0,))[0]
-    print(f"| `{k}` | {n} | {us:.1f} | {g / 8 / us / 1e3:.2f} | {b / 1024 / (g / 8):.2f} | {wi / wc:.2f} | {(wa - wi) / wc:.2f} | {ai / wc:.2f} | {va / (wc / 4):.3f} | {wl / wc:.3f} |")
+    print(f"| `{k}` | {n} | {us:.1f} | {g / 8 / us / 1e3:.2f} | {b / 1024 / (g / 8):.2f} | {wi / wc:.2f} | {(wa - wi) / wc:.2f} | {ai / wc:.2f} | {va / wc:.3f} | {wl / wc:.3f} |")
 PY
