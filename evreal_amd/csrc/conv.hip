@@ -1704,7 +1704,9 @@ __global__ __launch_bounds__(256 * RPB, (RPB == 1 ? 3 : 2)) void conv3x3_c16_row
             int slot = slot0 + rowi;
             if (slot >= NBUF) slot -= NBUF;
             const bool ok = (unsigned)yy < (unsigned)H && (unsigned)(x0 - 1 + p * 16 + rl) < (unsigned)W;
-            const unsigned voff = ok ? (unsigned)(((img * H + yy) * W + x0 - 1) * 64 + p * 1024 + lane_off) : OOB_OFFSET;
+            // (unsigned arithmetic: pixel index x 64 B reaches 2^32 at the 2^26 pixels c16_rows_eligible admits, and x0 - 1 is -1 in
+            // the first strip -- both wrap to the right offset for every lane that is `ok`)
+            const unsigned voff = ok ? ((unsigned)((img * H + yy) * W + x0 - 1) * 64u + (unsigned)(p * 1024 + lane_off)) : OOB_OFFSET;
             lds_ptr_t dst = (lds_ptr_t)&lds[(sidx * NBUF + slot) * A_F4 + p * 64];
             if (p * 16 + 16 <= A_ROWS) {
                 if (sidx) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, 0, 0, 0);

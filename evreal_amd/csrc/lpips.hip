@@ -556,7 +556,7 @@ extern "C" int evr_lpips_forward(evr_lpips* m, const float* img, const float* re
     hipStream_t stream = (hipStream_t)stream_;
     EVR_REQUIRE(m && img && ref && out && n >= 1 && H >= 1 && W >= 1, "evr_lpips_forward: bad argument");
     int rc;
-    if (m->H != H || m->W != W || n > m->cap) if ((rc = lpips_buffers(m, n, H, W, stream))) return rc;
+    if (m->H != H || m->W != W || n > m->cap) if ((rc = lpips_buffers(m, n, H, W, stream))) { m->release(); m->H = m->W = 0; return rc; }      // (a half-built set of buffers must not look like capacity)
     if (!m->cur || m->cur->n != n) if ((rc = lpips_plan(m, n, stream))) return rc;
     const evr_lpips::Plan& P = *m->cur;
     ConvArgs* const d_args = m->d_args + 4 * (m->cur - m->plans);
