@@ -255,6 +255,9 @@ size_t evr_metrics_workspace_bytes(int n, int H, int W);
  * tensors: the metric's state_dict with pyiqa's names ("net.slice1.0.weight" ... "net.slice5.10.bias",
  * "lin0.model.1.weight" ... "lin4.model.1.weight").  img, ref: [n,H,W] in [0,1] (clip: clamp first);
  * out: double [n].  PARITY UNPINNED: pyiqa and its downloaded weights are unavailable offline.
+ * The handle owns its feature buffers: sized for the largest n seen at the current H x W (they only grow; a new H x W
+ * re-allocates), with the launch plans of the last eight distinct n cached -- a call whose n was seen before, or is below
+ * the capacity, neither synchronises nor allocates.  One handle is used from one host thread and one stream at a time.
  */
 typedef struct evr_lpips evr_lpips;
 int evr_lpips_create(const evr_tensor* tensors, int n_tensors, evr_lpips** out);
