@@ -424,7 +424,7 @@ int launch_conv_igemm_m6(const ConvArgs& a, const ConvArgs* d_args, int kc, int 
 void wino_pack_weights(const std::vector<float>& w, int n_gemm, int cin, int lstm_hidden, std::vector<float>& out);
 bool wino_enabled();
 bool wino_eligible(const ConvArgs& a);
-int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream);
+int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img = nullptr);
 inline void set_wino_grid(ConvArgs& a) {
     a.wino_th = (a.hin + 1) / 2; a.wino_tw = (a.win + 1) / 2;
     fastdiv_magic((unsigned)(a.wino_th * a.wino_tw), &a.wdiv_t_mul, &a.wdiv_t_sh);

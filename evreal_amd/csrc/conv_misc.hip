@@ -15,7 +15,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // conv.hip is compiled three times (build.py): -DEVR_ARITH=2 carries the f16 + MX-fp8 split kernels and the exact-fp32 ones,
 // -DEVR_ARITH=3 the three-f16-product kernels on H2 tensors, -DEVR_ARITH=4 the f16 + MX-fp6 kernels on P6 tensors.
 int launch_conv_igemm(const ConvArgs& a, const ConvArgs* d_args, int kc, int wm, int nb, hipStream_t stream, float* img) {
-    if (a.x3 == 0 && a.wgt_wino && wino_eligible(a)) return launch_conv_wino(a, d_args, stream);      // exact-fp32 3x3 stride-1 layers: Winograd F(2x2, 3x3)
+    if (a.x3 == 0 && a.wgt_wino && wino_eligible(a)) return launch_conv_wino(a, d_args, stream, img);      // exact-fp32 3x3 stride-1 layers: Winograd F(2x2, 3x3)
     if (a.x3 == 3) return launch_conv_igemm_h3(a, d_args, kc, wm, nb, stream, img);
     if (a.x3 == 4) return launch_conv_igemm_m6(a, d_args, kc, wm, nb, stream, img);
     return launch_conv_igemm_mx(a, d_args, kc, wm, nb, stream, img);

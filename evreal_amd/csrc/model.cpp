@@ -379,9 +379,15 @@ int finish_conv(evr_model* m, Conv& c) {
     }
     // exact-fp32 mode: the 3x3 stride-1 layers whose shape wino.hip covers (ConvLSTM gates, residual convolutions) get their
     // Winograd-domain weights too -- G g G^T in fp64 -- and run F(2x2, 3x3): 2.25x fewer fp32 MFMAs (EVR_WINO=0: direct form only)
-    if (c.x3 == 0 && c.kc == 32 && wino_enabled() && c.k == 3 && c.stride == 1 && !c.transposed && c.tp.ngroups == 1 && c.cin0 % 8 == 0 &&
-        (c.cin1 == 0 || c.cin1 == c.cin0) && c.n_gemm % 64 == 0 && c.n_valid == c.n_gemm &&
-        ((c.epi == EPI_LSTM && c.hidden % 16 == 0) || c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU || c.epi == EPI_RESIDUAL_RELU)) {
+    // (round 6, later: the k5 s2 transposed decoders too -- their four phases are 3x3 convolutions on the input grid sharing one input
+    // transform, 16 instead of 25 multiplies per 2x2 outputs and phase; EVR_WINO_TCONV=0: direct form)
+    static const bool wino_tconv = getenv("EVR_WINO_TCONV") ? atoi(getenv("EVR_WINO_TCONV")) != 0 : true;
+    const bool wino_plain = c.k == 3 && !c.transposed && c.tp.ngroups == 1 && c.n_valid == c.n_gemm &&
+        ((c.epi == EPI_LSTM && c.hidden % 16 == 0) || c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU || c.epi == EPI_RESIDUAL_RELU);
+    const bool wino_t = wino_tconv && c.transposed && c.tp.ngroups == 4 && c.tp.ntaps == 9 && c.cin1 == 0 && c.n_valid % 32 == 0 && c.n_gemm == 4 * c.n_valid &&
+        (c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU);
+    if (c.x3 == 0 && c.kc == 32 && wino_enabled() && c.stride == 1 && (wino_plain || wino_t) && c.cin0 % 8 == 0 &&
+        (c.cin1 == 0 || c.cin1 == c.cin0) && c.n_gemm % 64 == 0) {
         std::vector<float> u;
         wino_pack_weights(c.w, c.n_gemm, c.cin0 + c.cin1, c.epi == EPI_LSTM ? c.hidden : 0, u);
         if ((rc = upload(u, &c.d_wino))) return rc;

@@ -64,13 +64,28 @@ bool wino_enabled() {
 
 // host-side test of a launch plan (model.cpp sets wgt_wino only for layers that pass the shape part of this)
 bool wino_eligible(const ConvArgs& a) {
-    if (!a.wgt_wino || a.x3 != 0 || a.pred_w || a.tp.ngroups != 1 || a.tp.ntaps != 9 || a.stride != 1 || a.os != 1) return false;
-    if (a.hout != a.hm || a.wout != a.wm || a.hm != a.hin || a.wm != a.win) return false;
-    if (a.c0 % 8 || (a.in_mode == IN_CAT && a.c1 != a.c0) || a.cout % 64 || a.n_valid != a.cout) return false;
+    if (!a.wgt_wino || a.x3 != 0 || a.tp.ntaps != 9 || a.stride != 1) return false;
+    if (a.hm != a.hin || a.wm != a.win) return false;
+    // a transposed convolution (k5 s2: four sub-pixel phases of <= 3x3 taps on the INPUT grid, prep_tconv) is one 3x3 convolution with
+    // 4 x cout columns whose 32-column blocks each belong to one phase: same transforms, the epilogue scatters to (2y + py, 2x + px)
+    const bool tconv = a.tp.ngroups == 4 && a.os == 2;
+    if (tconv) {
+        if (a.hout != 2 * a.hm || a.wout != 2 * a.wm || a.cout != 4 * a.cout_total || a.n_valid != a.cout_total || a.cout_total % 32) return false;
+        if (!(a.tp.inter ? a.tp.grp_cols == 32 : a.tp.grp_cols == a.cout_total)) return false;
+        if (a.in_mode != IN_SINGLE || a.residual) return false;
+    } else {
+        if (a.tp.ngroups != 1 || a.os != 1 || a.hout != a.hm || a.wout != a.wm || a.n_valid != a.cout) return false;
+    }
+    if (a.c0 % 8 || (a.in_mode == IN_CAT && a.c1 != a.c0) || a.cout % 64) return false;
     if (((a.c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) / 8) % 2) return false;      // (the chunk loop is unrolled by its two LDS buffers)
     if (a.in_packed || a.out_packed || a.res_packed || a.padd_packed || a.state_packed) return false;
-    if ((int64_t)a.n * a.hin * a.win * (a.epi == EPI_LSTM ? a.hidden : a.cout_total) * 4 > 0xBFFF0000LL) return false;      // (EPI_OOB, wino.hip)
-    if (a.epi == EPI_LSTM) return a.hidden % 16 == 0 && a.cout == 4 * a.hidden;
+    if ((int64_t)a.n * a.hout * a.wout * (a.epi == EPI_LSTM ? a.hidden : a.cout_total) * 4 > 0xBFFF0000LL) return false;      // (EPI_OOB, wino.hip)
+    if (a.epi == EPI_LSTM) return !tconv && a.hidden % 16 == 0 && a.cout == 4 * a.hidden;
+    // (a fused 1x1 prediction layer: only where a wave's 32 columns are ALL of a pixel's channels -- the last transposed decoder; its skip
+    // term is the whole skip tensor (post_add: the exact-fp32 head kernel writes no per-pixel dot product) or one float per pixel)
+    if (a.pred_w) return tconv && a.cout_total == 32 && (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU);
+    if (!a.out) return false;
+    if (tconv) return a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU;
     return (a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU || a.epi == EPI_RESIDUAL_RELU) && a.cout_total == a.cout;
 }
 
@@ -116,8 +131,8 @@ constexpr int UV_F4 = 2048;      // float4 per 32-KB image: [pos 16][half 2][lan
 // accumulator -- measured no different and is gone): bit 1 = no side work at all (no DMA, transform or patch loads after the first chunk: results are garbage); bit 2 = side work on
 // cache-hot addresses (always chunk 0's weights and patch: garbage) -- separates the side work's issue cost from its memory latency;
 // bits 3 / 4 / 5 = no weight DMA / no patch loads / no transform and V stores after an item's first chunk
-template <bool LSTM, bool FAST, int VAR = 0>
-__global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap, int total) {
+template <bool LSTM, bool FAST, int VAR = 0, bool PRED = false>
+__global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap, int total, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
     // four separate LDS objects: hipcc's waitcnt insertion then knows that an LDS-DMA into one U buffer does not alias the fragment
@@ -232,7 +247,9 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     unsigned eoff[4];  // byte offset of the lane's first channel at the tile's 4 output pixels (py * 2 + px)
     f4 eb[4];          // bias runs of the lane's 4 x 4 rows
     f4 ecp[4];         // ConvLSTM: cell state of the lane's 4 channels at those pixels
-    const unsigned out_bytes = (unsigned)a.n * (unsigned)H * (unsigned)W * (unsigned)(LSTM ? a.hidden : a.cout_total) * 4u;
+    const bool tconv = !LSTM && a.os == 2;      // (four sub-pixel phases: wino_eligible)
+    const unsigned out_bytes = (unsigned)a.n * (unsigned)a.hout * (unsigned)a.wout * (unsigned)(LSTM ? a.hidden : a.cout_total) * 4u;
+    unsigned bcol0 = 0;      // the lane's first GEMM column (its bias run; = its first output channel except for a transposed convolution)
     auto epi_prefetch = [&]() {
         const int me = mt * 64 + wt * 32 + (lane & 31);
         const bool evalid = me < Mt;
@@ -240,12 +257,23 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         const int eimg = fdiv(mme, wdt_mul, wdt_sh), erem = mme - eimg * tpi;
         const int ety = fdiv(erem, wdw_mul, wdw_sh), etx = erem - ety * tw;
         const unsigned cpp = (unsigned)(LSTM ? a.hidden : a.cout_total) * 4u;
-        const unsigned chan0 = LSTM ? (unsigned)(cb * 16 + wc * 8 + 4 * hl) : (unsigned)(cb * 64 + wc * 32 + 4 * hl);
-        const unsigned ebase = (unsigned)((eimg * H + 2 * ety) * W + 2 * etx) * cpp + chan0 * 4u;
+        unsigned chan0 = LSTM ? (unsigned)(cb * 16 + wc * 8 + 4 * hl) : (unsigned)(cb * 64 + wc * 32 + 4 * hl);
+        bcol0 = chan0;
+        // output pixel of the tile's input pixel (Y, X): (Y, X) itself, or (2 Y + py, 2 X + px) of the wave's phase (its 32 columns
+        // are one phase: ConvTaps::inter, or phase-major groups of >= 32 columns)
+        int osc = 1, ofy = 0, ofx = 0;
+        if (tconv) {
+            const int col0 = cb * 64 + wc * 32;
+            const int g = a.tp.inter ? ((col0 >> 5) & 3) : col0 / a.tp.grp_cols;
+            chan0 = (unsigned)((a.tp.inter ? (((col0 >> 7) << 5) + (col0 & 31)) : col0 - g * a.tp.grp_cols) + 4 * hl);
+            osc = 2; ofy = a.tp.grp_ofy[g]; ofx = a.tp.grp_ofx[g];
+        }
+        const unsigned Wo = (unsigned)a.wout;
+        const unsigned ebase = (unsigned)((eimg * a.hout + osc * 2 * ety + ofy) * a.wout + osc * 2 * etx + ofx) * cpp + chan0 * 4u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bool ok = evalid && 2 * ety + (p >> 1) < H && 2 * etx + (p & 1) < W;
-            const unsigned o = ebase + (unsigned)(p >> 1) * (unsigned)W * cpp + (unsigned)(p & 1) * cpp;
+            const unsigned o = ebase + (unsigned)((p >> 1) * osc) * Wo * cpp + (unsigned)((p & 1) * osc) * cpp;
             eoff[p] = ok ? o : EPI_OOB;
         }
         const __amdgpu_buffer_rsrc_t rsb = make_rsrc(a.bias, (unsigned)a.cout * 4u);
@@ -258,7 +286,7 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
             for (int p = 0; p < 4; ++p) ecp[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rss, eoff[p], 0, 0));
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) eb[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsb, chan0 * 4u + 32u * q, 0, 0));
+            for (int q = 0; q < 4; ++q) if constexpr (!PRED) eb[q] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsb, bcol0 * 4u + 32u * q, 0, 0));
         }
     };
 
@@ -472,10 +500,71 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rso, eoff[p] + 32u * q, 0, 0);
                 }
             };
+            if constexpr (PRED) {
+                // fused prediction layer (model/unet.py:136-138; conv.hip epi_finish's `pw` path): the wave's 32 rows are the 32 channels of
+                // one sub-pixel phase, so an output pixel's dot product closes inside the lane pair -- nothing is stored but the image
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+                const __amdgpu_buffer_rsrc_t rspw = make_rsrc(a.pred_w, (unsigned)a.cout_total * 4u);
+                // (the tile's first output pixel and the lane's first channel, decoded again here: six registers the main loop does not have)
+                const int col0 = cb * 64 + wc * 32;
+                const int pg = a.tp.inter ? ((col0 >> 5) & 3) : col0 / a.tp.grp_cols;
+                const __amdgpu_buffer_rsrc_t rsbias = make_rsrc(a.bias, (unsigned)a.cout * 4u);
+                const unsigned pchan0 = (unsigned)((a.tp.inter ? (((col0 >> 7) << 5) + (col0 & 31)) : col0 - pg * a.tp.grp_cols) + 4 * hl);
+                auto pgroup = [&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    // (bias and prediction weights of the run fetched here, not a step ahead: 256 cache-hot bytes, and 16 registers the last step keeps)
+                    const f4 pw = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rspw, pchan0 * 4u + 32u * q, 0, 0));
+                    const f4 bq = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsbias, (unsigned)(col0 + 4 * hl) * 4u + 32u * q, 0, 0));
+                    f4 sv[4];      // skip_sum fused into the producer (model_util.py:4-5): added after the activation, as in group()
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) sv[p] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsp, eoff[p] + 32u * q, 0, 0));
+                    float y0[4], y1[4], y2[4], y3[4];
+                    otrans(std::integral_constant<int, 4 * q + 0>{}, y0);
+                    otrans(std::integral_constant<int, 4 * q + 1>{}, y1);
+                    otrans(std::integral_constant<int, 4 * q + 2>{}, y2);
+                    otrans(std::integral_constant<int, 4 * q + 3>{}, y3);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        f4 v = {y0[p], y1[p], y2[p], y3[p]};
+                        v += bq;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { const float t = (relu ? fmaxf(v[i], 0.f) : v[i]) + sv[p][i]; part[p] = fmaf(t, pw[i], part[p]); }
+                    }
+                };
+                pgroup(I0{}); __builtin_amdgcn_sched_barrier(0);
+                pgroup(I1{}); __builtin_amdgcn_sched_barrier(0);
+                pgroup(I2{}); __builtin_amdgcn_sched_barrier(0);
+                pgroup(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
+                // (buffer operations with 32-bit offsets, pixels that do not exist / the lane pair's upper half / pixels outside the crop carry
+                // EPI_OOB: no branch, no 64-bit address per pixel -- this epilogue has no registers for them)
+                const unsigned npix = (unsigned)a.n * (unsigned)a.hout * (unsigned)a.wout;
+                const __amdgpu_buffer_rsrc_t rsd = make_rsrc(a.pred_skip_dot ? a.pred_skip_dot : a.pred_w, a.pred_skip_dot ? npix * 4u : 0u);
+                const __amdgpu_buffer_rsrc_t rsv = make_rsrc(a.prev_rec ? a.prev_rec : img_out, a.prev_rec ? npix * 4u : 0u);
+                const __amdgpu_buffer_rsrc_t rsi = make_rsrc(img_out, (unsigned)a.n * (unsigned)a.crop_h * (unsigned)a.crop_w * 4u);
+                const int me = mt * 64 + wt * 32 + (lane & 31);
+                const int pimg = fdiv(me < Mt ? me : 0, wdt_mul, wdt_sh), erem = (me < Mt ? me : 0) - pimg * tpi;
+                const int ety = fdiv(erem, wdw_mul, wdw_sh), etx = erem - ety * tw;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float pp = part[p];
+                    pp += __shfl_xor(pp, 32, 64);
+                    const int oy = 2 * (2 * ety + (p >> 1)) + a.tp.grp_ofy[pg], ox = 2 * (2 * etx + (p & 1)) + a.tp.grp_ofx[pg];
+                    const bool live = hl == 0 && eoff[p] != EPI_OOB;
+                    const unsigned po = live ? (unsigned)((pimg * a.hout + oy) * a.wout + ox) * 4u : EPI_OOB;
+                    float sres = pp + a.pred_b;
+                    sres += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsd, po, 0, 0));
+                    if (a.pred_sigmoid) sres = sigmoid_t<false>(sres);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sres), rsv, po, 0, 0);
+                    const int y = oy - a.crop_y0, x = ox - a.crop_x0;
+                    const bool in = live && (unsigned)y < (unsigned)a.crop_h && (unsigned)x < (unsigned)a.crop_w;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sres), rsi, in ? (unsigned)((pimg * a.crop_h + y) * a.crop_w + x) * 4u : EPI_OOB, 0, 0);
+                }
+            } else {
             group(I0{}); __builtin_amdgcn_sched_barrier(0);
             group(I1{}); __builtin_amdgcn_sched_barrier(0);
             group(I2{}); __builtin_amdgcn_sched_barrier(0);
             group(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (!has_next) break;
         item += stride; cb = cbn; mt = mtn;
@@ -485,8 +574,9 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
 
 }  // namespace wino
 
-int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream) {
+int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     EVR_REQUIRE(wino_eligible(a), "conv_wino: the plan is not a 3x3 stride-1 fp32 convolution this kernel covers");
+    EVR_REQUIRE(!a.pred_w || img, "conv_wino: a fused prediction needs the image buffer");
     EVR_REQUIRE(a.wino_th == (a.hin + 1) / 2 && a.wino_tw == (a.win + 1) / 2 && a.wdiv_t_sh < 32 && a.wdiv_tw_sh < 32, "conv_wino: plan without tile grid");
     EVR_REQUIRE((int64_t)a.n * a.hin * a.win * a.c0 * 4 < 0xFFFFFF00LL, "conv_wino: input tensor exceeds the buffer-descriptor range");
     const int64_t Mt = (int64_t)a.n * a.wino_th * a.wino_tw;
@@ -498,12 +588,14 @@ int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stre
     const unsigned grid = (unsigned)(total < nblocks ? total : nblocks);
     static const int var = getenv("EVR_WINO_VAR") ? atoi(getenv("EVR_WINO_VAR")) : 0;
     if (a.epi == EPI_LSTM) {
-        if (!fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
-        else if (var == 2) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 2>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
-        else if (var == 4) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 4>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
-        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        if (!fast_act) hipLaunchKernelGGL((wino::wino_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
+        else if (var == 2) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 2>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
+        else if (var == 4) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 4>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
+        else hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
+    } else if (a.pred_w) {
+        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false, 0, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
     } else {
-        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total);
+        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
     }
     EVR_LAUNCH_CHECK();
     return EVR_OK;
