@@ -114,6 +114,7 @@ struct ConvArgs {
     const float* wgt_wino;
     int wino_th, wino_tw;
     unsigned wdiv_t_mul, wdiv_t_sh, wdiv_tw_mul, wdiv_tw_sh;
+    int wino_s2d;             // 0, or 1 + log2(cin / 8): a k5 stride-2 convolution on the Winograd kernel in space-to-depth form (wgt_wino from its s2d weights)
     int wino_order;           // 1: items of a launch ordered 8 tile blocks x 4 column blocks per XCD round (wino.hip); 0: column block fastest
 };
 // A split launch has at most 512 blocks (one per resident slot) of 64 KB of partial accumulators each
@@ -426,7 +427,10 @@ bool wino_enabled();
 bool wino_eligible(const ConvArgs& a);
 int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img = nullptr);
 inline void set_wino_grid(ConvArgs& a) {
-    a.wino_th = (a.hin + 1) / 2; a.wino_tw = (a.win + 1) / 2;
+    // (wino_s2d: a k5 stride-2 convolution read in space-to-depth form -- a 3x3 stride-1 convolution over 2x2 pixel blocks with 4 cin
+    // channels: the tiles live on the block grid hm x wm)
+    const int gh = a.wino_s2d ? a.hm : a.hin, gw = a.wino_s2d ? a.wm : a.win;
+    a.wino_th = (gh + 1) / 2; a.wino_tw = (gw + 1) / 2;
     fastdiv_magic((unsigned)(a.wino_th * a.wino_tw), &a.wdiv_t_mul, &a.wdiv_t_sh);
     fastdiv_magic((unsigned)a.wino_tw, &a.wdiv_tw_mul, &a.wdiv_tw_sh);
     a.wino_order = getenv("EVR_WINO_ORDER") ? atoi(getenv("EVR_WINO_ORDER")) : 1;

@@ -49,6 +49,7 @@ struct Conv {   // one prepared implicit-GEMM convolution
     int n_gemm = 0, n_valid = 0;
     int k = 3, stride = 1;
     bool transposed = false;
+    int wino_s2d = 0;           // exact-fp32 mode, k5 s2 layers: 1 + log2(cin / 8) when d_wino holds the space-to-depth Winograd weights
     int epi = EPI_BIAS, hidden = 0;
     ConvTaps tp;
     int x3 = 0;                 // arithmetic mode (conv.h arith_mode): 2 / 3 = weights packed for that split kernel family, 0 = fp32
@@ -386,6 +387,26 @@ int finish_conv(evr_model* m, Conv& c) {
         ((c.epi == EPI_LSTM && c.hidden % 16 == 0) || c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU || c.epi == EPI_RESIDUAL_RELU);
     const bool wino_t = wino_tconv && c.transposed && c.tp.ngroups == 4 && c.tp.ntaps == 9 && c.cin1 == 0 && c.n_valid % 32 == 0 && c.n_gemm == 4 * c.n_valid &&
         (c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU);
+    // ... and the k5 stride-2 encoders: in space-to-depth form (prep_s2d's weight layout) they are 3x3 stride-1 convolutions over 2x2
+    // pixel blocks with 4 cin channels, 36 (tap, phase) pairs of which 25 carry weights -- Winograd needs 16 (EVR_WINO_S2D=0: direct form)
+    static const bool wino_s2d_on = getenv("EVR_WINO_S2D") ? atoi(getenv("EVR_WINO_S2D")) != 0 : true;
+    if (c.x3 == 0 && c.kc == 32 && wino_enabled() && wino_s2d_on && c.k == 5 && c.stride == 2 && !c.transposed && c.tp.ngroups == 1 && c.tp.ntaps == 25 &&
+        c.cin1 == 0 && c.cin0 % 8 == 0 && ((c.cin0 / 8) & (c.cin0 / 8 - 1)) == 0 && c.n_gemm % 64 == 0 && c.n_valid == c.n_gemm &&
+        (c.epi == EPI_BIAS || c.epi == EPI_BIAS_RELU)) {
+        const int cin = c.cin0;
+        std::vector<float> w2((size_t)c.n_gemm * 9 * 4 * cin, 0.f), u;
+        for (int row = 0; row < c.n_gemm; ++row)
+            for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx)
+                for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+                    const int ky = 2 * dy + py + 2, kx = 2 * dx + px + 2;
+                    if (ky < 0 || ky > 4 || kx < 0 || kx > 4) continue;
+                    memcpy(&w2[((size_t)row * 9 + (dy + 1) * 3 + dx + 1) * 4 * cin + (py * 2 + px) * cin], &c.w[((size_t)row * 25 + ky * 5 + kx) * cin],
+                           (size_t)cin * sizeof(float));
+                }
+        wino_pack_weights(w2, c.n_gemm, 4 * cin, 0, u);
+        if ((rc = upload(u, &c.d_wino))) return rc;
+        c.wino_s2d = 1 + __builtin_ctz((unsigned)(cin / 8));
+    }
     if (c.x3 == 0 && c.kc == 32 && wino_enabled() && c.stride == 1 && (wino_plain || wino_t) && c.cin0 % 8 == 0 &&
         (c.cin1 == 0 || c.cin1 == c.cin0) && c.n_gemm % 64 == 0) {
         std::vector<float> u;
@@ -891,7 +912,7 @@ void plan_conv(evr_model* m, int ci, int n, int hin, int win, const ConvIO& io, 
         a.acc_scale = (c.x3 == 3) ? std::ldexp(1.0f, -(c.mx_e + H2_ACT_EXP)) : (c.x3 == 4 ? std::ldexp(1.0f, -c.mx_e) : 1.0f);
         a.mx_sa = 127 - MX_LO_EXP; a.mx_sb = 127 - c.mx_e; a.group_store = use_group_store(); set_fastdiv(a);
         a.wgt2 = c.d_w2; a.prog = c.d_prog; a.prog_steps = c.prog_steps;
-        a.wgt_wino = c.d_wino; set_wino_grid(a);
+        a.wgt_wino = c.d_wino; a.wino_s2d = c.wino_s2d; set_wino_grid(a);
         a.sat = m->d_sat ? m->d_sat + ci : nullptr;
         a.in_packed = io.in_packed; a.out_packed = io.out_packed; a.res_packed = io.res_packed;
         a.padd_packed = io.padd_packed; a.state_packed = io.state_packed;

@@ -64,7 +64,19 @@ bool wino_enabled() {
 
 // host-side test of a launch plan (model.cpp sets wgt_wino only for layers that pass the shape part of this)
 bool wino_eligible(const ConvArgs& a) {
-    if (!a.wgt_wino || a.x3 != 0 || a.tp.ntaps != 9 || a.stride != 1) return false;
+    if (!a.wgt_wino || a.x3 != 0) return false;
+    if (a.wino_s2d) {
+        // a k5 stride-2 convolution as the 3x3 stride-1 convolution over 2x2 pixel blocks it is (model.cpp prep_s2d): 4 cin channels
+        // (phase-major) on the hm x wm block grid -- 16 instead of 25 multiplies per output and input channel
+        if (a.tp.ntaps != 25 || a.stride != 2 || a.tp.ngroups != 1 || a.os != 1 || a.in_mode != IN_SINGLE) return false;
+        if (a.hin != 2 * a.hm || a.win != 2 * a.wm || a.hout != a.hm || a.wout != a.wm) return false;
+        if (a.c0 % 8 || a.wino_s2d != 1 + __builtin_ctz((unsigned)(a.c0 / 8)) || (a.c0 / 8) != (1 << (a.wino_s2d - 1))) return false;
+        if (a.cout % 64 || a.n_valid != a.cout || a.cout_total != a.cout || a.pred_w || !a.out || a.residual) return false;
+        if (a.in_packed || a.out_packed || a.padd_packed) return false;
+        if ((int64_t)a.n * a.hout * a.wout * a.cout_total * 4 > 0xBFFF0000LL) return false;
+        return a.epi == EPI_BIAS || a.epi == EPI_BIAS_RELU;
+    }
+    if (a.tp.ntaps != 9 || a.stride != 1) return false;
     if (a.hm != a.hin || a.wm != a.win) return false;
     // a transposed convolution (k5 s2: four sub-pixel phases of <= 3x3 taps on the INPUT grid, prep_tconv) is one 3x3 convolution with
     // 4 x cout columns whose 32-column blocks each belong to one phase: same transforms, the epilogue scatters to (2y + py, 2x + px)
@@ -131,7 +143,7 @@ constexpr int UV_F4 = 2048;      // float4 per 32-KB image: [pos 16][half 2][lan
 // accumulator -- measured no different and is gone): bit 1 = no side work at all (no DMA, transform or patch loads after the first chunk: results are garbage); bit 2 = side work on
 // cache-hot addresses (always chunk 0's weights and patch: garbage) -- separates the side work's issue cost from its memory latency;
 // bits 3 / 4 / 5 = no weight DMA / no patch loads / no transform and V stores after an item's first chunk
-template <bool LSTM, bool FAST, int VAR = 0, bool PRED = false>
+template <bool LSTM, bool FAST, int VAR = 0, bool PRED = false, bool S2D = false>
 __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restrict__ ap, int total, float* __restrict__ img_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvArgs& a = *ap;
@@ -142,7 +154,8 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wv & 1, wc = wv >> 1;
-    const int H = a.hin, W = a.win, tw = a.wino_tw, tpi = a.wino_th * tw;
+    const int s2d = S2D ? a.wino_s2d : 0;      // (0, or 1 + log2(cin / 8): the input is read in space-to-depth form -- its own instantiation: the others have no register for it)
+    const int H = s2d ? a.hm : a.hin, W = s2d ? a.wm : a.win, tw = a.wino_tw, tpi = a.wino_th * tw;
     const int Mt = a.n * tpi;
     const int ncb = a.cout >> 6;
     // PERSISTENT blocks (one per CU: 128 KB of LDS, 512 registers per lane): block b runs on XCD b % 8; every XCD owns a contiguous
@@ -160,16 +173,18 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     }
     if (item >= item_end) return;
     const int c0 = a.c0;
-    const int nch = (c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) >> 3;      // (even: checked at launch)
-    const int nch0 = c0 >> 3;
-    const unsigned in_bytes = (unsigned)a.n * (unsigned)H * (unsigned)W * (unsigned)c0 * 4u;
+    const int nch = s2d ? (c0 >> 1) : ((c0 + (a.in_mode == IN_CAT ? a.c1 : 0)) >> 3);      // (even: checked at launch; s2d: 4 phases x c0 / 8)
+    const int nch0 = s2d ? nch : (c0 >> 3);
+    const unsigned in_bytes = (unsigned)a.n * (unsigned)a.hin * (unsigned)a.win * (unsigned)c0 * 4u;
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(a.wgt_wino, (unsigned)a.cout * (unsigned)(nch * 8) * 64u);
     const unsigned wdt_mul = a.wdiv_t_mul, wdt_sh = a.wdiv_t_sh, wdw_mul = a.wdiv_tw_mul, wdw_sh = a.wdiv_tw_sh;
 
     // ---- input-transform role: thread = (tile tt of the block's 64, channel pair cp of the chunk's 8 channels)
     const int tt = tid >> 2, cp = tid & 3;
     unsigned poff[16];
-    const unsigned pixb = (unsigned)c0 * 4u, rowb = (unsigned)W * pixb;
+    // (s2d: grid pixel (y, x) is the 2x2 block at (2y, 2x) of the real image; a chunk's phase (py, px) moves the descriptor's base)
+    constexpr int psc = S2D ? 2 : 1;
+    const unsigned pixb = (unsigned)(c0 * psc) * 4u, rowb = (unsigned)(a.win * psc) * (unsigned)c0 * 4u;
     auto set_patch_offsets = [&](int mt) {
         const int m = mt * 64 + tt;
         const bool tvalid = m < Mt;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
         const int ty = fdiv(rem, wdw_mul, wdw_sh), tx = rem - ty * tw;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
         // (one multiply chain, then adds: with a product per pixel hipcc guards each of the 16 offsets with its own branch)
-        const unsigned base = (unsigned)((img * H + y0) * W + x0) * pixb + (unsigned)(cp * 8);      // (wraps for y0 / x0 = -1: never used then)
+        const unsigned base = (unsigned)((img * a.hin + psc * y0) * a.win + psc * x0) * (unsigned)c0 * 4u + (unsigned)(cp * 8);      // (wraps for y0 / x0 = -1: never used then)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -195,6 +210,10 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
     f2 T[16];      // its column pass
     const float* const in0p = a.in0; const float* const in1p = a.in1 ? a.in1 : a.in0;      // (kept in SGPRs: no scalar load per chunk)
     auto patch_rsrc = [&](int c) {
+        if constexpr (S2D) {      // chunk c = phase c >> (s2d - 1) (py * 2 + px), channels 8 (c & (c0 / 8 - 1)) ...
+            const int ph = c >> (s2d - 1), cc = c & ((1 << (s2d - 1)) - 1);
+            return make_rsrc(in0p + (size_t)(((ph >> 1) * a.win + (ph & 1)) * c0 + cc * 8), in_bytes);
+        }
         const bool second = c >= nch0;
         const float* src = (second ? in1p : in0p) + (size_t)((second ? c - nch0 : c) * 8);
         return make_rsrc(src, in_bytes);
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(256) void wino_f32_kernel(const ConvArgs* __restric
 int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stream, float* img) {
     EVR_REQUIRE(wino_eligible(a), "conv_wino: the plan is not a 3x3 stride-1 fp32 convolution this kernel covers");
     EVR_REQUIRE(!a.pred_w || img, "conv_wino: a fused prediction needs the image buffer");
-    EVR_REQUIRE(a.wino_th == (a.hin + 1) / 2 && a.wino_tw == (a.win + 1) / 2 && a.wdiv_t_sh < 32 && a.wdiv_tw_sh < 32, "conv_wino: plan without tile grid");
+    EVR_REQUIRE(a.wino_th == ((a.wino_s2d ? a.hm : a.hin) + 1) / 2 && a.wino_tw == ((a.wino_s2d ? a.wm : a.win) + 1) / 2 && a.wdiv_t_sh < 32 && a.wdiv_tw_sh < 32, "conv_wino: plan without tile grid");
     EVR_REQUIRE((int64_t)a.n * a.hin * a.win * a.c0 * 4 < 0xFFFFFF00LL, "conv_wino: input tensor exceeds the buffer-descriptor range");
     const int64_t Mt = (int64_t)a.n * a.wino_th * a.wino_tw;
     const int64_t total = ((Mt + 63) / 64) * (a.cout / 64);
@@ -592,6 +611,8 @@ int launch_conv_wino(const ConvArgs& a, const ConvArgs* d_args, hipStream_t stre
         else if (var == 2) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 2>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
         else if (var == 4) hipLaunchKernelGGL((wino::wino_f32_kernel<true, true, 4>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
         else hipLaunchKernelGGL((wino::wino_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
+    } else if (a.wino_s2d) {
+        hipLaunchKernelGGL((wino::wino_f32_kernel<false, false, 0, false, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
     } else if (a.pred_w) {
         hipLaunchKernelGGL((wino::wino_f32_kernel<false, false, 0, true>), dim3(grid), dim3(256), 0, stream, d_args, (int)total, img);
     } else {

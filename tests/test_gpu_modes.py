@@ -6,7 +6,9 @@ The default arithmetic since round 4 is `h3` (three f16 products per term on H2 
   (EVR_WIDE=0), once with the 256 x 256-tile ConvLSTM kernel and once with its twin form (EVR_WIDE_MIN=1: the golden sequences are
   small, so the fill threshold is lowered).
 * EVR_NO_BAND=1 -- the split implicit-GEMM kernels for every layer.
-* EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations (Winograd F(2x2, 3x3) for the 3x3 stride-1 layers; again with EVR_WINO=0).
+* EVR_FP32=1      -- exact fp32-MFMA arithmetic and PLAIN activations (Winograd F(2x2, 3x3) for the 3x3 stride-1 layers, the transposed
+                     decoders -- four phases, the last with the prediction fused -- and the k5 s2 encoders in space-to-depth form; again
+                     with EVR_WINO_TCONV=0 EVR_WINO_S2D=0 (decoders / encoders on the direct implicit GEMM) and with EVR_WINO=0).
 * EVR_ARITH=mx6   -- the opt-in fast mode: f16 + MX-fp6 cross terms on P6 tensors for the E2VID-type layouts (the others narrow to mx),
                      image gate 1e-4; again on the wide / twin band kernels.
 * EVR_ARITH=mx    -- f16 + MX-fp8 cross terms on PACKED tensors for every layout; again on the band kernels and the implicit GEMM.
@@ -69,6 +71,10 @@ def test_parity_with_firenet_tile_kernel_everywhere():
 def test_parity_in_exact_fp32_mode():
     # (since round 6 the 3x3 stride-1 layers of this mode run Winograd F(2x2, 3x3): csrc/wino.hip)
     _run({'EVR_FP32': '1'})
+
+
+def test_parity_in_exact_fp32_mode_winograd_for_the_plain_3x3_layers_only():
+    _run({'EVR_FP32': '1', 'EVR_WINO_TCONV': '0', 'EVR_WINO_S2D': '0'})
 
 
 def test_parity_in_exact_fp32_mode_direct_form():
