@@ -40,9 +40,9 @@ VARIANTS = {'conv.hip': [('', ['-DEVR_ARITH=2']), ('.h3', ['-DEVR_ARITH=3']), ('
 
 
 # ... with one measured exception: the fused-prediction instantiation of the Winograd kernel (wino.hip, PRED = true) runs at the
-# 256 + 256 register cap and hipcc parks 11 loop-invariant set-up dwords in scratch -- stored before an item's main loop, reloaded
+# 256 + 256 register cap and hipcc parks up to 19 loop-invariant set-up dwords (76 B per lane) in scratch -- stored before an item's main loop, reloaded
 # in its epilogue, nothing inside the MFMA steps (the accumulators stay in AGPRs: the epilogue reads them with v_accvgpr_read)
-SCRATCH_ALLOW = {'wino_f32_kernelILb0ELb0ELi0ELb1E': 128}
+SCRATCH_ALLOW = {'wino_f32_kernelILb0ELb0ELi0ELb1E': 96}
 
 
 def _check_no_scratch(fname, remarks):
